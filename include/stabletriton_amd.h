@@ -1,0 +1,125 @@
+/*
+ * stabletriton_amd - C ABI of the MI355X (gfx950) operator library.
+ *
+ * This is the drop-in boundary for the SDXL-UNet denoise hot path: each entry
+ * point is what the reference's fx leaf wrapper for the same operator would
+ * bind instead of its Triton/xformers launch.  Plain pointers and sizes only;
+ * every pointer is DEVICE memory unless noted; `stream` is a hipStream_t
+ * passed as void*.  Launches are asynchronous on `stream`, never synchronise
+ * the host and never allocate, so they are legal inside hipGraph capture
+ * (reference requirement: optimizers/cuda/graphs.py:72-108 captures on a side
+ * stream).  Return value: 0 = launched, non-zero = rejected before launch
+ * (see st_last_error()); the Python host turns non-zero into an exception,
+ * mirroring the reference's assert/RuntimeError behaviour
+ * (kernels/linear.py:181-188, kernels/geglu.py:29-30).
+ */
+#ifndef STABLETRITON_AMD_H
+#define STABLETRITON_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element types of activations/weights; accumulation is always fp32 */
+enum { ST_F32 = 0, ST_BF16 = 1 };
+
+/* activation-tensor layouts for the image-shaped ops */
+enum { ST_NCHW = 0, ST_NHWC = 1 };
+
+/* st_linear / st_conv2d epilogue flags (bit-or) */
+enum {
+    ST_EPI_BIAS      = 1,   /* + bias[n]                                         */
+    ST_EPI_SILU      = 2,   /* y = y * sigmoid(y)         (after bias)            */
+    ST_EPI_GEGLU     = 4,   /* W has 2F rows; out[m][j] = y[j] * gelu_erf(y[F+j]) */
+    ST_EPI_RESIDUAL  = 8,   /* + residual[m][n]           (after activation)      */
+    ST_EPI_ROWBIAS   = 16   /* + rowbias[batch(m)][n]     (time-embedding add)    */
+};
+
+int         st_abi_version(void);          /* bumps on any signature change */
+const char* st_last_error(void);           /* host string, thread-local     */
+
+/* GroupNorm (+SiLU).  Replaces reference group_norm_wrapper
+ * (optimizers/replace_groupnorm.py:18-19 -> kernels/groupnorm.py:128-161).
+ * x,y: (N,C,H,W) logical, `layout` physical; gamma,beta: C elements of `dtype`;
+ * workspace: st_group_norm_workspace_bytes() bytes of scratch.  Statistics are
+ * fp32, biased variance, y = (x-mean)*rsqrt(var+eps)*gamma+beta, then
+ * y*sigmoid(y) if `silu`. */
+size_t st_group_norm_workspace_bytes(int N, int C, int HW, int groups);
+int st_group_norm(const void* x, const void* gamma, const void* beta, void* y,
+                  int N, int C, int HW, int groups, float eps, int silu,
+                  int layout, int dtype, void* workspace, void* stream);
+
+/* LayerNorm over the last dimension.  Replaces layer_norm_wrapper
+ * (optimizers/replace_layernorm.py:17-24 -> kernels/layer_norm.py:282-335);
+ * eps is used as given (the reference's fp16 clamp to 1.6e-5 is a defect,
+ * SURVEY.md section 7).  x,y: (rows, C) contiguous. */
+int st_layer_norm(const void* x, const void* gamma, const void* beta, void* y,
+                  int rows, int C, float eps, int dtype, void* stream);
+
+/* GEGLU elementwise: out[m][j] = state[m][j] * gelu_erf(gate[m][j]).
+ * Replaces geglu_triton (optimizers/replace_geglu.py:23-27 ->
+ * kernels/geglu.py:18-35).  Row strides are in elements, so the two halves of
+ * one projection output can be passed without copies. */
+int st_geglu(const void* state, const void* gate, void* out, int rows, int F,
+             long ld_state, long ld_gate, long ld_out, int dtype, void* stream);
+
+/* Linear: y[M,N] = epilogue(x[M,K] * W[N,K]^T).  Replaces linear_wrapper /
+ * linear_wrapper_functional (optimizers/replace_linear.py:20-34 ->
+ * kernels/linear.py:173-222).  W is (N,K) row-major exactly as nn.Linear
+ * stores it.  lda/ldc/ldr are row strides in elements.  With ST_EPI_GEGLU,
+ * W has 2N rows and y has N columns.  rows_per_batch is only read with
+ * ST_EPI_ROWBIAS (rowbias is (M/rows_per_batch, N) contiguous). */
+int st_linear(const void* x, const void* W, const void* bias, const void* residual,
+              const void* rowbias, void* y, int M, int N, int K,
+              long lda, long ldc, long ldr, int rows_per_batch,
+              int epilogue, int dtype, void* stream);
+
+/* Fused attention core: out = softmax(q k^T * scale) v per head, no mask.
+ * Replaces attention_wrapper (optimizers/replace_attention.py:60-68); inputs
+ * keep the (B, T, H*D) / (B, S, H*D) projection layout of unet_pt.py:133-142.
+ * ld* are token strides in elements (>= H*D), batch strides are T*ldq etc. */
+int st_attention(const void* q, const void* k, const void* v, void* out,
+                 int B, int T, int S, int H, int D,
+                 long ldq, long ldk, long ldv, long ldo,
+                 float scale, int dtype, void* stream);
+
+/* conv2d on NHWC activations as implicit GEMM; W is (Cout, R, S, Cin)
+ * contiguous (= channels_last nn.Conv2d weight).  Covers the resnet-block
+ * convolutions of unet_pt.py:74-95,246-266,430,467 that the reference leaves
+ * to cuDNN (optimizations.txt:5).  `upsample2x` folds a nearest 2x upsample of
+ * the input into the gather (unet_pt.py:264-266).  Epilogue flags as for
+ * st_linear; rowbias is (N_batch, Cout) (the time-embedding projection,
+ * unet_pt.py:82-83), residual is NHWC (N,Hout,Wout,Cout). */
+int st_conv2d(const void* x, const void* W, const void* bias, const void* residual,
+              const void* rowbias, void* y, int N, int Hin, int Win, int Cin,
+              int Cout, int R, int S, int stride, int pad, int upsample2x,
+              int epilogue, int dtype, void* stream);
+
+/* Euler-discrete update of the fp32 latent and preparation of the next UNet
+ * input (restated diffusers EulerDiscreteScheduler, see
+ * stabletriton_amd/scheduler.py; the reference leaves this loop to the
+ * third-party pipeline, implementations/Diffusers/load_sdxl_pipeline.py:39-46):
+ *   i = *step;  latent += eps * dsigma[i];  next_in = latent * in_scale[i+1]
+ * (cast to `dtype`).  All three tensors are elementwise-aligned (same layout),
+ * n elements.  `step` lives on the device so one captured step graph can be
+ * replayed down the table; st_step_advance does *step = (*step + 1) % n_steps. */
+int st_euler_step(float* latent, const void* eps, void* next_in, const float* dsigma,
+                  const float* in_scale, const int* step, long n, int n_steps,
+                  int dtype, void* stream);
+int st_step_advance(int* step, int n_steps, void* stream);
+
+/* Sinusoidal timestep features (unet_pt.py:17-36; target of the reference's
+ * fuse_timesteps pass, optimizers/replace_timesteps.py:33-58):
+ *   out[b][j] = cos(t_b * f_j), out[b][dim/2 + j] = sin(t_b * f_j),
+ *   f_j = exp(-ln(1e4) * j / (dim/2)),  t_b = t[(step ? *step : 0) + b*t_stride].
+ * t is fp32 on the device; out is (batch, dim) of `dtype`. */
+int st_timestep_features(const float* t, long t_stride, const int* step, void* out,
+                         int batch, int dim, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,170 @@
+"""TEST INFRASTRUCTURE - generates tests/golden/*.npz from the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference).  It imports the
+reference's eager model file standalone (it depends on torch only; the package
+__init__ pulls xformers/diffusers, which are absent - SURVEY.md 8c), loads the
+build's synthetic weights into it by parameter name and records outputs.  The
+fixtures are data (inputs are regenerated from seeds; outputs are stored); no
+reference source is copied.
+
+    python oracle/make_golden.py f1 f2          # seconds .. a minute
+    python oracle/make_golden.py f3_64          # ~4 min   (50 Euler steps, latent 64)
+    python oracle/make_golden.py f3_128         # ~20 min  (50 Euler steps, latent 128)
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from stabletriton_amd import synth                     # noqa: E402
+from stabletriton_amd.scheduler import euler_discrete_tables  # noqa: E402
+from oracle import unet_oracle as orc                  # noqa: E402
+
+REF_FILE = "/root/reference/src/stabletriton/optimizers/unet_pt.py"
+OUT = os.path.join(ROOT, "tests", "golden")
+WEIGHT_SEED, INPUT_SEED = 0, 1234
+
+
+def load_reference():
+    spec = importlib.util.spec_from_file_location("ref_unet_pt", REF_FILE)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def meta():
+    return dict(torch_version=torch.__version__, weight_seed=WEIGHT_SEED, input_seed=INPUT_SEED,
+                generated=time.strftime("%Y-%m-%d"))
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrays.items()}, **{"meta_" + k: np.asarray(v) for k, v in meta().items()})
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+F2_STRIDE = 31          # prime, so the kept elements walk across rows and columns
+
+
+def subsample(t: torch.Tensor) -> torch.Tensor:
+    """Large per-op outputs are stored as every 31st element of the flattened
+    tensor (tests apply the same rule to their own output)."""
+    return t.flatten()[::F2_STRIDE].clone() if t.numel() > 20000 else t
+
+
+_REF_UNET = None
+
+
+def ref_unet(ref):
+    global _REF_UNET
+    if _REF_UNET is None:
+        t0 = time.time()
+        m = ref.UNet2DConditionModel().eval()
+        synth.fill_module_(m, WEIGHT_SEED)
+        print(f"reference UNet built + filled in {time.time() - t0:.0f}s; params",
+              sum(p.numel() for p in m.parameters()))
+        _REF_UNET = m
+    return _REF_UNET
+
+
+@torch.no_grad()
+def f1(ref):
+    """BASELINE config #1: one eager CPU fp32 step at 512x512 (latent 64)."""
+    m = ref_unet(ref)
+    x = synth.denoise_inputs(1, 64, INPUT_SEED)
+    t = torch.tensor(999.0)
+    out = m(x["latent"], t, x["encoder_hidden_states"],
+            {"text_embeds": x["text_embeds"], "time_ids": x["time_ids"]})[0]
+    # cross-check the restatement right here, on the same weights
+    sd = {k: v for k, v in m.state_dict().items()}
+    mine = orc.unet_forward(sd, x["latent"], t, x["encoder_hidden_states"], x["text_embeds"], x["time_ids"])
+    print("F1 |oracle - reference| max =", float((mine - out).abs().max()), " |ref| max =", float(out.abs().max()))
+    save("f1_unet_step_latent64", out=out, timestep=999.0, latent_hw=64)
+
+
+@torch.no_grad()
+def f2(ref):
+    """Per-op fixtures at real SDXL widths (outputs of the reference's own sub-modules)."""
+    arrays = {}
+
+    def filled(mod, prefix):
+        for n, p in mod.named_parameters():
+            p.copy_(synth.param_tensor(f"{prefix}.{n}", tuple(p.shape), WEIGHT_SEED))
+        return mod.eval()
+
+    # attention, self (T=256) and cross (S=77), C = 640 and 1280 (unet_pt.py:98-147)
+    for c in (640, 1280):
+        a = filled(ref.Attention(c), f"f2.attn_self{c}")
+        x = synth.normal(f"f2.attn_self{c}.x", (1, 256, c), INPUT_SEED)
+        arrays[f"attn_self{c}"] = a(x)
+        a = filled(ref.Attention(c, 2048), f"f2.attn_cross{c}")
+        ctx = synth.normal(f"f2.attn_cross{c}.ctx", (1, 77, 2048), INPUT_SEED)
+        arrays[f"attn_cross{c}"] = a(x, ctx)
+    # resnet blocks (unet_pt.py:54-95)
+    for cin, cout, sc in ((320, 320, False), (960, 320, True)):
+        r = filled(ref.ResnetBlock2D(cin, cout, conv_shortcut=sc), f"f2.res{cin}_{cout}")
+        x = synth.normal(f"f2.res{cin}_{cout}.x", (1, cin, 16, 16), INPUT_SEED)
+        temb = synth.normal(f"f2.res{cin}_{cout}.temb", (1, 1280), INPUT_SEED)
+        arrays[f"res{cin}_{cout}"] = r(x, temb)
+    # GEGLU (unet_pt.py:150-158)
+    g = filled(ref.GEGLU(640, 2560), "f2.geglu")
+    arrays["geglu"] = g(synth.normal("f2.geglu.x", (1, 64, 640), INPUT_SEED))
+    # spatial transformer, depth 1 (unet_pt.py:213-243)
+    tr = filled(ref.Transformer2DModel(640, 640, 1), "f2.xfmr")
+    x = synth.normal("f2.xfmr.x", (1, 640, 16, 16), INPUT_SEED)
+    ctx = synth.normal("f2.xfmr.ctx", (1, 77, 2048), INPUT_SEED)
+    arrays["xfmr"] = tr(x, ctx)
+    # sinusoidal features (unet_pt.py:17-36)
+    tt = torch.tensor([999.0, 500.0, 1.0, 1024.0, 0.0])
+    arrays["timesteps320"] = ref.Timesteps(320)(tt)
+    arrays["timesteps256"] = ref.Timesteps(256)(tt)
+    # GroupNorm at the non-power-of-two group sizes SDXL uses (C/32 = 10,20,30,40,60,80)
+    for c, eps in ((320, 1e-5), (640, 1e-6), (960, 1e-5), (1280, 1e-6), (1920, 1e-5), (2560, 1e-5)):
+        gn = filled(torch.nn.GroupNorm(32, c, eps=eps), f"f2.gn{c}")
+        x = synth.normal(f"f2.gn{c}.x", (1, c, 8, 8), INPUT_SEED)
+        arrays[f"gn{c}"] = gn(x)
+    save("f2_ops", **{k: subsample(v) for k, v in arrays.items()})
+
+
+@torch.no_grad()
+def f3(ref, hw):
+    """50-step Euler loop driving the reference UNet (same loop code as the build uses)."""
+    m = ref_unet(ref)
+    x = synth.denoise_inputs(1, hw, INPUT_SEED)
+    tables = euler_discrete_tables(50)
+    cond = {"text_embeds": x["text_embeds"], "time_ids": x["time_ids"]}
+    t0 = time.time()
+    trace = []
+
+    def fn(x_in, t):
+        e = m(x_in, t, x["encoder_hidden_states"], cond)[0]
+        trace.append(float(e.abs().mean()))
+        if len(trace) % 5 == 0:
+            print(f"  step {len(trace)} |eps| mean {trace[-1]:.4f}  {time.time() - t0:.0f}s", flush=True)
+        return e
+
+    final = orc.euler_denoise(fn, x["latent"], tables)
+    save(f"f3_euler50_latent{hw}", final=final, eps_abs_mean=np.asarray(trace, dtype=np.float32), latent_hw=hw)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(os.cpu_count() or 8)
+    ref = load_reference()
+    for what in sys.argv[1:] or ["f1", "f2"]:
+        if what == "f1":
+            f1(ref)
+        elif what == "f2":
+            f2(ref)
+        elif what.startswith("f3_"):
+            f3(ref, int(what[3:]))
+        else:
+            raise SystemExit(f"unknown fixture {what}")

@@ -1,0 +1,191 @@
+"""TEST INFRASTRUCTURE - NOT PRODUCT CODE.
+
+CPU fp32 restatement of the reference's eager SDXL UNet forward
+(/root/reference/src/stabletriton/optimizers/unet_pt.py), written as plain
+functions over a Diffusers-keyed state_dict.  Only tests/, bench.py's
+`cpu_baseline` leg and __graft_entry__.smoke() may import this package; the
+product path (stabletriton_amd/) never does.
+
+Pinning: oracle/make_golden.py imports the reference module in the build
+container, loads identical synthetic weights into it and records its outputs
+under tests/golden/; tests/test_oracle_golden.py checks this restatement
+against those vectors.  The reference has no golden vectors of its own
+(SURVEY.md section 4).
+
+Each function cites the reference lines it follows.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+
+def _has(sd: SD, key: str) -> bool:
+    return key in sd
+
+
+def _count(sd: SD, fmt: str) -> int:
+    n = 0
+    while fmt.format(n) in sd:
+        n += 1
+    return n
+
+
+def linear(sd: SD, p: str, x):
+    return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
+
+
+def conv(sd: SD, p: str, x, stride=1, padding=1):
+    return F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride=stride, padding=padding)
+
+
+def group_norm(sd: SD, p: str, x, eps: float, groups: int = 32):
+    return F.group_norm(x, groups, sd[p + ".weight"], sd[p + ".bias"], eps)
+
+
+def layer_norm(sd: SD, p: str, x):
+    w = sd[p + ".weight"]
+    return F.layer_norm(x, w.shape, w, sd[p + ".bias"], 1e-5)
+
+
+def timestep_features(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """unet_pt.py:22-36 - cos first, then sin; exponent = -ln(1e4) * i / half."""
+    half = dim // 2
+    exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32)
+    exponent = exponent / (half - 0.0)
+    emb = t[:, None].float() * torch.exp(exponent)[None, :]
+    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+
+
+def timestep_mlp(sd: SD, p: str, x):
+    """unet_pt.py:46-51."""
+    return linear(sd, p + ".linear_2", F.silu(linear(sd, p + ".linear_1", x)))
+
+
+def resnet_block(sd: SD, p: str, x, temb, groups: int = 32):
+    """unet_pt.py:74-95."""
+    h = F.silu(group_norm(sd, p + ".norm1", x, 1e-5, groups))
+    h = conv(sd, p + ".conv1", h)
+    h = h + linear(sd, p + ".time_emb_proj", F.silu(temb))[:, :, None, None]
+    h = F.silu(group_norm(sd, p + ".norm2", h, 1e-5, groups))
+    h = conv(sd, p + ".conv2", h)
+    if _has(sd, p + ".conv_shortcut.weight"):
+        x = conv(sd, p + ".conv_shortcut", x, padding=0)
+    return x + h
+
+
+def attention_core(q, k, v, heads: int):
+    """unet_pt.py:133-142: softmax(q k^T / sqrt(d)) v per head; q,k,v are (B,T,H*d)."""
+    b, t, c = q.shape
+    d = c // heads
+    q = q.view(b, t, heads, d).transpose(1, 2)
+    k = k.view(b, k.shape[1], heads, d).transpose(1, 2)
+    v = v.view(b, v.shape[1], heads, d).transpose(1, 2)
+    s = torch.matmul(q, k.transpose(-2, -1)) * (d ** -0.5)
+    o = torch.matmul(torch.softmax(s, dim=-1), v)
+    return o.transpose(1, 2).contiguous().view(b, t, c)
+
+
+def attention(sd: SD, p: str, x, context=None, head_dim: int = 64):
+    """unet_pt.py:121-147."""
+    src = x if context is None else context
+    q = linear(sd, p + ".to_q", x)
+    k = linear(sd, p + ".to_k", src)
+    v = linear(sd, p + ".to_v", src)
+    o = attention_core(q, k, v, q.shape[-1] // head_dim)
+    return linear(sd, p + ".to_out.0", o)
+
+
+def geglu(x_proj):
+    """unet_pt.py:155-158: exact-erf GELU on the second half."""
+    a, g = x_proj.chunk(2, dim=-1)
+    return a * F.gelu(g)
+
+
+def transformer_layer(sd: SD, p: str, x, context, head_dim: int = 64):
+    """unet_pt.py:189-210."""
+    x = attention(sd, p + ".attn1", layer_norm(sd, p + ".norm1", x), None, head_dim) + x
+    x = attention(sd, p + ".attn2", layer_norm(sd, p + ".norm2", x), context, head_dim) + x
+    h = geglu(linear(sd, p + ".ff.net.0.proj", layer_norm(sd, p + ".norm3", x)))
+    return linear(sd, p + ".ff.net.2", h) + x
+
+
+def spatial_transformer(sd: SD, p: str, x, context, groups: int = 32, head_dim: int = 64):
+    """unet_pt.py:223-243 (GroupNorm eps is 1e-6 here, unet_pt.py:216)."""
+    b, c, h, w = x.shape
+    y = group_norm(sd, p + ".norm", x, 1e-6, groups)
+    y = y.permute(0, 2, 3, 1).reshape(b, h * w, c)
+    y = linear(sd, p + ".proj_in", y)
+    for i in range(_count(sd, p + ".transformer_blocks.{}.norm1.weight")):
+        y = transformer_layer(sd, f"{p}.transformer_blocks.{i}", y, context, head_dim)
+    y = linear(sd, p + ".proj_out", y)
+    y = y.reshape(b, h, w, c).permute(0, 3, 1, 2).contiguous()
+    return y + x
+
+
+def unet_forward(sd: SD, sample, timestep, encoder_hidden_states, text_embeds, time_ids,
+                 groups: int = 32, head_dim: int = 64, time_proj_dim: Optional[int] = None,
+                 add_time_proj_dim: Optional[int] = None) -> torch.Tensor:
+    """unet_pt.py:469-542.  Topology is read off the state_dict keys."""
+    if time_proj_dim is None:
+        time_proj_dim = sd["time_embedding.linear_1.weight"].shape[1]
+    if add_time_proj_dim is None:
+        add_time_proj_dim = (sd["add_embedding.linear_1.weight"].shape[1] - text_embeds.shape[1]) // time_ids.shape[1]
+    b = sample.shape[0]
+    t = timestep.reshape(-1).expand(b)
+    emb = timestep_mlp(sd, "time_embedding", timestep_features(t, time_proj_dim).to(sample.dtype))
+    tid = timestep_features(time_ids.flatten(), add_time_proj_dim).reshape(b, -1)
+    add = torch.cat([text_embeds, tid], dim=-1).to(emb.dtype)
+    emb = emb + timestep_mlp(sd, "add_embedding", add)
+
+    x = conv(sd, "conv_in", sample)
+    skips: List[torch.Tensor] = [x]
+    n_down = _count(sd, "down_blocks.{}.resnets.0.norm1.weight")
+    for i in range(n_down):
+        p = f"down_blocks.{i}"
+        for j in range(_count(sd, p + ".resnets.{}.norm1.weight")):
+            x = resnet_block(sd, f"{p}.resnets.{j}", x, emb, groups)
+            if _has(sd, f"{p}.attentions.{j}.norm.weight"):
+                x = spatial_transformer(sd, f"{p}.attentions.{j}", x, encoder_hidden_states, groups, head_dim)
+            skips.append(x)
+        if _has(sd, p + ".downsamplers.0.conv.weight"):
+            x = conv(sd, p + ".downsamplers.0.conv", x, stride=2)      # unet_pt.py:246-254
+            skips.append(x)
+
+    x = resnet_block(sd, "mid_block.resnets.0", x, emb, groups)        # unet_pt.py:404-413
+    x = spatial_transformer(sd, "mid_block.attentions.0", x, encoder_hidden_states, groups, head_dim)
+    x = resnet_block(sd, "mid_block.resnets.1", x, emb, groups)
+
+    for i in range(_count(sd, "up_blocks.{}.resnets.0.norm1.weight")):
+        p = f"up_blocks.{i}"
+        for j in range(_count(sd, p + ".resnets.{}.norm1.weight")):
+            x = torch.cat([x, skips.pop()], dim=1)                     # unet_pt.py:352-357
+            x = resnet_block(sd, f"{p}.resnets.{j}", x, emb, groups)
+            if _has(sd, f"{p}.attentions.{j}.norm.weight"):
+                x = spatial_transformer(sd, f"{p}.attentions.{j}", x, encoder_hidden_states, groups, head_dim)
+        if _has(sd, p + ".upsamplers.0.conv.weight"):
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")     # unet_pt.py:264-266
+            x = conv(sd, p + ".upsamplers.0.conv", x)
+
+    x = F.silu(group_norm(sd, "conv_norm_out", x, 1e-5, groups))       # unet_pt.py:538-540
+    return conv(sd, "conv_out", x)
+
+
+def euler_denoise(unet_fn, latent_unit, tables, n_steps: Optional[int] = None) -> torch.Tensor:
+    """Euler-discrete epsilon-prediction loop (restated diffusers==0.21.2
+    EulerDiscreteScheduler, see stabletriton_amd/scheduler.py header; parity of
+    the scheduler arithmetic itself is unpinned).  `unet_fn(x_in, t)` returns
+    eps; `latent_unit` is unit-variance noise; state is kept in fp32."""
+    x = latent_unit.float() * tables.init_noise_sigma
+    n = tables.n_steps if n_steps is None else n_steps
+    in_scale, dsigma = tables.in_scale(), tables.dsigma()
+    for i in range(n):
+        x_in = x * float(in_scale[i])
+        eps = unet_fn(x_in, torch.tensor(float(tables.timesteps[i])))
+        x = x + eps.float() * float(dsigma[i])
+    return x

@@ -1,0 +1,89 @@
+"""In-tree build of the gfx950 operator library with hipcc (no cmake, no JIT cache).
+
+`python -m stabletriton_amd.build` or `build_library()` compiles every
+csrc/*.hip to an object (in parallel) and links
+stabletriton_amd/lib/libstabletriton_amd.so.  The .so is git-ignored but
+travels with the repo snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+LIBNAME = "libstabletriton_amd.so"
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wno-unused-result"]
+
+
+def lib_path() -> str:
+    return os.path.join(LIBDIR, LIBNAME)
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; the operator library cannot be built")
+    return exe
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest(path: str) -> str:
+    h = hashlib.sha256()
+    for dep in [path, os.path.join(CSRC, "common.h"), os.path.join(PKG, "..", "include", "stabletriton_amd.h")]:
+        with open(dep, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = _hipcc()
+    jobs = []
+    for src in _sources():
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(objdir, src[:-4] + ".o")
+        stamp = obj + ".sha"
+        dg = _digest(sp)
+        fresh = (not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dg)
+        jobs.append((sp, obj, stamp, dg, fresh))
+
+    def compile_one(job):
+        sp, obj, stamp, dg, fresh = job
+        if fresh:
+            return obj
+        cmd = [hipcc, *FLAGS, "-c", sp, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {sp}:\n{r.stderr}")
+        with open(stamp, "w") as f:
+            f.write(dg)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        objs = list(ex.map(compile_one, jobs))
+    out = lib_path()
+    if force or not os.path.exists(out) or any(not j[4] for j in jobs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", *objs, "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+    return out
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

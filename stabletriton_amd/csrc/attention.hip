@@ -1,0 +1,291 @@
+// Fused attention core for gfx950: out = softmax(q k^T * scale) v, per head, no
+// mask, head_dim 64 (every SDXL-base/refiner head).  Row A of SURVEY.md 8a:
+// replaces the eager matmul/softmax/matmul of unet_pt.py:133-142 without ever
+// materialising the (B,H,T,S) score tensor.
+//
+// bf16 kernel (flash style, v_mfma_f32_32x32x16_bf16):
+//   * one wave owns 32 query rows; a block of NW waves walks the keys in tiles
+//     of 64 staged through LDS (register-staged double buffer, K and V images
+//     XOR-swizzled per 16-byte chunk so the fragment reads are conflict-free);
+//   * scores are computed transposed, S^T = K Q^T, so a lane holds 32 scores of
+//     ONE query row: row max / row sum are in-register plus one half-wave swap;
+//   * the S^T accumulator is reused directly as the B operand of O^T = V^T P^T
+//     (no LDS round trip for P); V^T fragments come from ds_read_b64_tr_b16
+//     on the row-major V image;
+//   * keys beyond S (the 77-token text context) are zero-filled and masked.
+// fp32 kernel ("strict" parity mode): plain FMA online softmax, one query row
+// per thread.
+#include "common.h"
+
+static constexpr int ATT_D = 64;
+static constexpr int ATT_KV = 64;          // keys per tile
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+typedef __attribute__((address_space(3))) const char lds_cchar;
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(lds_cchar*)p; }
+
+// four transposed 4x16 block reads (ds_read_b64_tr_b16) issued back to back, one wait
+__device__ __forceinline__ void lds_read_tr16_x4(const void* p0, const void* p1, const void* p2, const void* p3,
+                                                 u32x2& r0, u32x2& r1, u32x2& r2, u32x2& r3) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %4\n\t"
+        "ds_read_b64_tr_b16 %1, %5\n\t"
+        "ds_read_b64_tr_b16 %2, %6\n\t"
+        "ds_read_b64_tr_b16 %3, %7\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+        : "v"(lds_addr(p0)), "v"(lds_addr(p1)), "v"(lds_addr(p2)), "v"(lds_addr(p3))
+        : "memory");
+}
+
+__device__ __forceinline__ int swz_k(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 1) << 2; }
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                            const bf16* __restrict__ V, bf16* __restrict__ O,
+                                                            int T, int S, long ldq, long ldk, long ldv, long ldo, float scale_log2e) {
+    constexpr int NT = NW * 64;
+    constexpr int TILE_B = ATT_KV * 128;                 // bytes of one K (or V) tile image
+    constexpr int IT = (ATT_KV * 8) / NT;                // 16-byte chunks per thread per image
+    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_B];   // [buf][K|V]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = (blockIdx.x * NW + wave) * 32;
+    const int qrow = min(q0 + r32, T - 1);
+
+    const bf16* Qb = Q + (size_t)b * T * ldq + (size_t)head * ATT_D;
+    const bf16* Kb = K + (size_t)b * S * ldk + (size_t)head * ATT_D;
+    const bf16* Vb = V + (size_t)b * S * ldv + (size_t)head * ATT_D;
+
+    // Q^T fragments: lane (q = r32, h) holds d = 16ks + 8h .. +7
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (size_t)qrow * ldq + 16 * ks + 8 * h);
+
+    // staging slots
+    int st_row[IT], st_c[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) { const int id = t + i * NT; st_row[i] = id >> 3; st_c[i] = id & 7; }
+    u32x4 kreg[IT], vreg[IT];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int key = kt * ATT_KV + st_row[i];
+            const bool ok = key < S;
+            kreg[i] = ok ? *reinterpret_cast<const u32x4*>(Kb + (size_t)key * ldk + st_c[i] * 8) : zero4;
+            vreg[i] = ok ? *reinterpret_cast<const u32x4*>(Vb + (size_t)key * ldv + st_c[i] * 8) : zero4;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* kb = lds + buf * 2 * TILE_B;
+        char* vb = kb + TILE_B;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int row = st_row[i];
+            *reinterpret_cast<u32x4*>(kb + row * 128 + ((st_c[i] ^ swz_k(row)) << 4)) = kreg[i];
+            *reinterpret_cast<u32x4*>(vb + row * 128 + ((st_c[i] ^ swz_v(row)) << 4)) = vreg[i];
+        }
+    };
+
+    f32x16 o0 = {0}, o1 = {0};
+    float m = -1e30f, l = 0.f;
+    const int nkt = (S + ATT_KV - 1) / ATT_KV;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const char* kb = lds + cur * 2 * TILE_B;
+        const char* vb = kb + TILE_B;
+
+        // ---- S^T = K Q^T for 64 keys x 32 queries ----
+        f32x16 s0 = {0}, s1 = {0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = 2 * ks + h;
+            const int ra = r32, rb = 32 + r32;
+            bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kb + ra * 128 + ((c ^ swz_k(ra)) << 4));
+            bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kb + rb * 128 + ((c ^ swz_k(rb)) << 4));
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ks], s1, 0, 0, 0);
+        }
+        // mask the tail keys (only the last tile can have any)
+        if ((kt + 1) * ATT_KV > S) {
+            const int kbase = kt * ATT_KV + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kbase + (r & 3) + 8 * (r >> 2);
+                if (key >= S) s0[r] = -INFINITY;
+                if (key + 32 >= S) s1[r] = -INFINITY;
+            }
+        }
+        // ---- online softmax (scaled by scale*log2e, base-2 exponent) ----
+        float mx = s0[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx * scale_log2e);
+        const float alpha = fast_exp2(m - m_new);
+        m = m_new;
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = fast_exp2(fmaf(s0[r], scale_log2e, -m_new));
+            s1[r] = fast_exp2(fmaf(s1[r], scale_log2e, -m_new));
+            rs += s0[r] + s1[r];
+        }
+        l = l * alpha + rs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+
+        // ---- O^T += V^T P^T ; k-step s covers keys 16s .. 16s+15 of the tile ----
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 pb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pb[j] = (bf16)((s < 2) ? s0[8 * (s & 1) + j] : s1[8 * (s & 1) + j]);
+            const int q4 = (lane & 15) >> 2;
+            const int key0 = 16 * s + 4 * h + q4, key1 = key0 + 8;
+            const int sub = 8 * (lane & 1);
+            const int ch0 = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1), ch1 = ch0 + 4;
+            const char* row0 = vb + key0 * 128 + sub;
+            const char* row1 = vb + key1 * 128 + sub;
+            u32x2 lo0, hi0, lo1, hi1;
+            lds_read_tr16_x4(row0 + ((ch0 ^ swz_v(key0)) << 4), row1 + ((ch0 ^ swz_v(key1)) << 4),
+                             row0 + ((ch1 ^ swz_v(key0)) << 4), row1 + ((ch1 ^ swz_v(key1)) << 4), lo0, hi0, lo1, hi1);
+            u32x4 w0 = {lo0[0], lo0[1], hi0[0], hi0[1]};
+            u32x4 w1 = {lo1[0], lo1[1], hi1[0], hi1[1]};
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), pb, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1), pb, o1, 0, 0, 0);
+        }
+
+        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (q0 + r32 < T) {
+        bf16* orow = O + (size_t)b * T * ldo + (size_t)(q0 + r32) * ldo + (size_t)head * ATT_D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 a, c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = (bf16)(o0[4 * g + e] * inv); c[e] = (bf16)(o1[4 * g + e] * inv); }
+            *reinterpret_cast<bf16x4*>(orow + 8 * g + 4 * h) = a;
+            *reinterpret_cast<bf16x4*>(orow + 32 + 8 * g + 4 * h) = c;
+        }
+    }
+}
+
+// ---- fp32 strict kernel: thread = one query row, keys in tiles of 32 via LDS ----
+__global__ __launch_bounds__(128) void attn_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                       const float* __restrict__ V, float* __restrict__ O, int T, int S,
+                                                       long ldq, long ldk, long ldv, long ldo, float scale) {
+    constexpr int KT = 32;
+    __shared__ __attribute__((aligned(16))) float ks[KT][ATT_D];
+    __shared__ __attribute__((aligned(16))) float vs[KT][ATT_D];
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int qi = blockIdx.x * 128 + threadIdx.x;
+    const int qrow = min(qi, T - 1);
+    const float* qp = Q + (size_t)b * T * ldq + (size_t)qrow * ldq + (size_t)head * ATT_D;
+    const float* Kb = K + (size_t)b * S * ldk + (size_t)head * ATT_D;
+    const float* Vb = V + (size_t)b * S * ldv + (size_t)head * ATT_D;
+    float q[ATT_D], o[ATT_D];
+#pragma unroll
+    for (int d = 0; d < ATT_D; d += 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(qp + d);
+        q[d] = v[0]; q[d + 1] = v[1]; q[d + 2] = v[2]; q[d + 3] = v[3];
+        o[d] = o[d + 1] = o[d + 2] = o[d + 3] = 0.f;
+    }
+    float m = -1e30f, l = 0.f;
+    for (int k0 = 0; k0 < S; k0 += KT) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < KT * ATT_D / 4; i += 128) {
+            const int row = i / (ATT_D / 4), c = (i - row * (ATT_D / 4)) * 4;
+            const int key = k0 + row;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (key < S) {
+                kv = *reinterpret_cast<const f32x4*>(Kb + (size_t)key * ldk + c);
+                vv = *reinterpret_cast<const f32x4*>(Vb + (size_t)key * ldv + c);
+            }
+            *reinterpret_cast<f32x4*>(&ks[row][c]) = kv;
+            *reinterpret_cast<f32x4*>(&vs[row][c]) = vv;
+        }
+        __syncthreads();
+        const int nk = min(KT, S - k0);
+        float sc[KT];
+        float mx = -1e30f;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int d = 0; d < ATT_D; ++d) a = fmaf(q[d], ks[j][d], a);
+            a *= scale;
+            sc[j] = j < nk ? a : -1e30f;
+            mx = fmaxf(mx, sc[j]);
+        }
+        const float m_new = fmaxf(m, mx);
+        const float alpha = expf(m - m_new);
+        m = m_new;
+        l *= alpha;
+#pragma unroll
+        for (int d = 0; d < ATT_D; ++d) o[d] *= alpha;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            const float pj = j < nk ? expf(sc[j] - m_new) : 0.f;
+            l += pj;
+#pragma unroll
+            for (int d = 0; d < ATT_D; ++d) o[d] = fmaf(pj, vs[j][d], o[d]);
+        }
+    }
+    if (qi < T) {
+        float* op = O + (size_t)b * T * ldo + (size_t)qi * ldo + (size_t)head * ATT_D;
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int d = 0; d < ATT_D; d += 4) {
+            f32x4 v = {o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv};
+            *reinterpret_cast<f32x4*>(op + d) = v;
+        }
+    }
+}
+
+extern "C" int st_attention(const void* q, const void* k, const void* v, void* out, int B, int T, int S, int H, int D,
+                            long ldq, long ldk, long ldv, long ldo, float scale, int dtype, void* stream) {
+    ST_REQUIRE(q && k && v && out, "attention: null pointer");
+    ST_REQUIRE(B > 0 && T > 0 && S > 0 && H > 0, "attention: bad shape B=%d T=%d S=%d H=%d", B, T, S, H);
+    ST_REQUIRE(D == ATT_D, "attention: head_dim %d not supported (only %d)", D, ATT_D);
+    ST_REQUIRE(H <= 65535 && B <= 65535, "attention: too many heads/batches for one launch");
+    const int vec = dtype == ST_BF16 ? 8 : 4;
+    ST_REQUIRE(ldq % vec == 0 && ldk % vec == 0 && ldv % vec == 0 && ldo % 4 == 0, "attention: strides must keep 16-byte alignment");
+    ST_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 == 0, "attention: pointers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ST_BF16) {
+        const float c = scale * 1.4426950408889634f;
+        // 4 waves (128 rows) per block unless that leaves CUs idle
+        const long blocks4 = (long)cdiv(T, 128) * H * B;
+        if (blocks4 >= 256)
+            hipLaunchKernelGGL(attn_bf16_kernel<4>, dim3(cdiv(T, 128), H, B), dim3(256), 0, st, (const bf16*)q, (const bf16*)k,
+                               (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c);
+        else
+            hipLaunchKernelGGL(attn_bf16_kernel<2>, dim3(cdiv(T, 64), H, B), dim3(128), 0, st, (const bf16*)q, (const bf16*)k,
+                               (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c);
+    } else if (dtype == ST_F32) {
+        hipLaunchKernelGGL(attn_f32_kernel, dim3(cdiv(T, 128), H, B), dim3(128), 0, st, (const float*)q, (const float*)k,
+                           (const float*)v, (float*)out, T, S, ldq, ldk, ldv, ldo, scale);
+    } else {
+        return st_fail("attention: unsupported dtype %d", dtype);
+    }
+    return st_check_launch("attention");
+}

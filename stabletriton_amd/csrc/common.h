@@ -1,0 +1,78 @@
+// Shared device/host helpers for the gfx950 operator library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/stabletriton_amd.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// ---- host-side error plumbing -------------------------------------------------
+int st_fail(const char* fmt, ...);      // records message, returns non-zero
+int st_check_launch(const char* what);  // hipGetLastError -> status
+
+#define ST_REQUIRE(cond, ...) do { if (!(cond)) return st_fail(__VA_ARGS__); } while (0)
+
+// ---- element traits -----------------------------------------------------------
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int VEC = 4;                 // elements per 16-byte vector
+    static __device__ __forceinline__ float to_f(float v) { return v; }
+    static __device__ __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct Elem<bf16> {
+    static constexpr int VEC = 8;
+    static __device__ __forceinline__ float to_f(bf16 v) { return (float)v; }
+    static __device__ __forceinline__ bf16 from_f(float v) { return (bf16)v; }
+};
+
+// 16-byte vector of T, unpacked to floats and back
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    f32x4 v;
+    static constexpr int N = 4;
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <> struct Vec16<bf16> {
+    bf16x8 v;
+    static constexpr int N = 8;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16)x; }
+};
+
+template <typename T>
+__device__ __forceinline__ Vec16<T> load16(const T* p) {
+    Vec16<T> r;
+    r.v = *reinterpret_cast<const decltype(r.v)*>(p);
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ void store16(T* p, const Vec16<T>& r) {
+    *reinterpret_cast<decltype(r.v)*>(p) = r.v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// exact-erf GELU, as torch.nn.functional.gelu default (reference kernels/geglu.py:24)
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,427 @@
+// MFMA GEMM for gfx950: y[M,N] = epilogue(A[M,K] * W[N,K]^T), used for
+//   * nn.Linear (rows L of SURVEY.md 8a)              - dense A loader
+//   * conv2d on NHWC as implicit GEMM (row R)         - gather A loader
+// bf16 runs on v_mfma_f32_16x16x32_bf16, fp32 ("strict" parity mode) on
+// v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain); both accumulate in fp32.
+//
+// Structure: block tile BM x BN, K step = one 128-byte row segment (64 bf16 /
+// 32 fp32), LDS double buffer with a 16-byte-chunk XOR swizzle
+// (chunk ^= row & 7: conflict-free ds_read_b128 for the 16x16 fragment maps),
+// register-staged global->LDS so the next tile's loads fly under the MFMAs.
+// The MFMA is issued "swapped" (W fragment as the A operand, activation
+// fragment as B), so each lane ends up with 4 consecutive output columns of
+// one row and the epilogue stores 8/16 contiguous bytes per lane.
+#include "common.h"
+
+struct GemmArgs {
+    const void* A; const void* W; const void* bias; const void* residual; const void* rowbias; void* C;
+    int M, N, K;                 // N = output columns (with GEGLU: W has 2N rows)
+    long lda, ldc, ldr;
+    int rows_per_batch;
+    int epi;
+    // implicit-GEMM conv geometry (unused for dense)
+    int Hin, Win, Cin, Hout, Wout, S, stride, pad, ups;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+    typedef bf16x8 Frag;
+    static __device__ __forceinline__ void run(f32x4& acc, const Frag& a, const Frag& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    typedef f32x4 Frag;
+    // lane (r, q) holds k = 4q..4q+3 of this 16-wide k group; step j multiplies
+    // element j of both operands, so the k permutation is the same on both sides.
+    static __device__ __forceinline__ void run(f32x4& acc, const Frag& a, const Frag& b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+    }
+};
+
+template <typename T> struct Out4;
+template <> struct Out4<bf16> {
+    static __device__ __forceinline__ void load(const bf16* p, float* f) {
+        bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = (float)v[i];
+    }
+    static __device__ __forceinline__ void store(bf16* p, const float* f) {
+        bf16x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (bf16)f[i];
+        *reinterpret_cast<bf16x4*>(p) = v;
+    }
+};
+template <> struct Out4<float> {
+    static __device__ __forceinline__ void load(const float* p, float* f) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = v[i];
+    }
+    static __device__ __forceinline__ void store(float* p, const float* f) {
+        f32x4 v = {f[0], f[1], f[2], f[3]};
+        *reinterpret_cast<f32x4*>(p) = v;
+    }
+};
+
+template <typename T, int BM, int BN, int WGM, int WGN, bool CONV, bool GEGLU>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int KB = 8 * VEC;                     // elements per 128-byte row segment
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int A_IT = (BM * 8 + NT - 1) / NT, B_IT = (BN * 8 + NT - 1) / NT;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    static_assert(!GEGLU || (TN % 2 == 0), "GEGLU pairs value/gate n-tiles inside one wave");
+    typedef typename Mma<T>::Frag Frag;
+
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tile_n = blockIdx.x / tiles_m, tile_m = blockIdx.x - tile_n * tiles_m;
+    const int m0 = tile_m * BM;
+    constexpr int BNO = GEGLU ? BN / 2 : BN;        // output columns per block
+    const int n0 = tile_n * BNO;
+
+    const T* __restrict__ Ap = (const T*)p.A;
+    const T* __restrict__ Wp = (const T*)p.W;
+
+    // ---- per-thread staging slots: fixed (row, chunk) for the whole K loop ----
+    const T* a_ptr[A_IT];      // dense: row base + chunk offset.  conv: image base + chunk offset
+    int a_iy[A_IT], a_ix[A_IT];
+    int a_lds[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int id = t + i * NT;
+        const int row = id >> 3, c = id & 7;
+        const int m = m0 + row;
+        a_ok[i] = (id < BM * 8) && (m < p.M);
+        a_lds[i] = row * 128 + ((c ^ (row & 7)) << 4);
+        if (CONV) {
+            const int hw = p.Hout * p.Wout;
+            const int mm = a_ok[i] ? m : 0;
+            const int img = mm / hw, rem = mm - img * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            a_iy[i] = oy * p.stride - p.pad;
+            a_ix[i] = ox * p.stride - p.pad;
+            a_ptr[i] = Ap + (size_t)img * p.Hin * p.Win * p.Cin + c * VEC;
+        } else {
+            a_iy[i] = c * VEC;          // k offset of this chunk inside the K step
+            a_ix[i] = 0;
+            a_ptr[i] = Ap + (size_t)(a_ok[i] ? m : 0) * p.lda + c * VEC;
+        }
+    }
+    const T* b_ptr[B_IT];
+    int b_lds[B_IT], b_k[B_IT];
+    bool b_ok[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int id = t + i * NT;
+        const int row = id >> 3, c = id & 7;
+        int wrow;                         // row of W feeding LDS row `row`
+        bool ok = id < BN * 8;
+        if (GEGLU) {
+            const int w_ = row / WTN, local = row - w_ * WTN;
+            const int half = local >= WTN / 2 ? 1 : 0;
+            const int ncol = n0 + w_ * (WTN / 2) + (local - half * (WTN / 2));
+            ok = ok && ncol < p.N;
+            wrow = ncol + half * p.N;
+        } else {
+            wrow = n0 + row;
+            ok = ok && wrow < p.N;
+        }
+        b_ok[i] = ok;
+        b_k[i] = c * VEC;
+        b_lds[i] = A_BYTES + row * 128 + ((c ^ (row & 7)) << 4);
+        b_ptr[i] = Wp + (size_t)(ok ? wrow : 0) * p.K + c * VEC;
+    }
+
+    u32x4 a_reg[A_IT], b_reg[B_IT];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * KB;
+        if (CONV) {
+            const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
+            const int r = tap / p.S, s = tap - r * p.S;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                int iy = a_iy[i] + r, ix = a_ix[i] + s;
+                bool ok;
+                if (p.ups) {
+                    ok = a_ok[i] && iy >= 0 && ix >= 0 && iy < 2 * p.Hin && ix < 2 * p.Win;
+                    iy >>= 1; ix >>= 1;
+                } else {
+                    ok = a_ok[i] && iy >= 0 && ix >= 0 && iy < p.Hin && ix < p.Win;
+                }
+                const T* src = a_ptr[i] + ((size_t)(ok ? iy : 0) * p.Win + (ok ? ix : 0)) * p.Cin + c0;
+                a_reg[i] = ok ? *reinterpret_cast<const u32x4*>(src) : zero4;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const bool ok = a_ok[i] && (k0 + a_iy[i] < p.K);
+                a_reg[i] = ok ? *reinterpret_cast<const u32x4*>(a_ptr[i] + k0) : zero4;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const bool ok = b_ok[i] && (k0 + b_k[i] < p.K);
+            b_reg[i] = ok ? *reinterpret_cast<const u32x4*>(b_ptr[i] + k0) : zero4;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* base = lds + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            if (t + i * NT < BM * 8) *reinterpret_cast<u32x4*>(base + a_lds[i]) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            if (t + i * NT < BN * 8) *reinterpret_cast<u32x4*>(base + b_lds[i]) = b_reg[i];
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int r16 = lane & 15, q = lane >> 4;
+    const int nk = (p.K + KB - 1) / KB;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const char* sa = lds + cur * STAGE;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int c = 4 * kk + q;
+            Frag fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * WTM + i * 16 + r16;
+                fa[i] = *reinterpret_cast<const Frag*>(sa + row * 128 + ((c ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * WTN + j * 16 + r16;
+                fb[j] = *reinterpret_cast<const Frag*>(sb + row * 128 + ((c ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], fb[j], fa[i]);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds rows m = .. + r16, columns n = .. + 4q .. 4q+3 ----
+    T* __restrict__ Cp = (T*)p.C;
+    const T* __restrict__ bias = (const T*)p.bias;
+    const T* __restrict__ Rp = (const T*)p.residual;
+    const T* __restrict__ RBp = (const T*)p.rowbias;
+    constexpr int TNO = GEGLU ? TN / 2 : TN;
+    constexpr int WTNO = GEGLU ? WTN / 2 : WTN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + r16;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TNO; ++j) {
+            const int n = n0 + wn * WTNO + j * 16 + 4 * q;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
+            const bool full = (n + 3 < p.N);
+            if (p.epi & ST_EPI_BIAS) {
+                if (full) { float b4[4]; Out4<T>::load(bias + n, b4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += b4[e];
+                } else {
+                    for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(bias[n + e]);
+                }
+            }
+            if (GEGLU) {
+                float g[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = acc[i][j + TN / 2][e];
+                if (p.epi & ST_EPI_BIAS) {
+                    if (full) { float b4[4]; Out4<T>::load(bias + p.N + n, b4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] += b4[e];
+                    } else {
+                        for (int e = 0; e < 4 && n + e < p.N; ++e) g[e] += Elem<T>::to_f(bias[p.N + n + e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_f(g[e]);
+            }
+            if (p.epi & ST_EPI_SILU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+            }
+            if (p.epi & ST_EPI_ROWBIAS) {
+                const T* rb = RBp + (size_t)(m / p.rows_per_batch) * p.N + n;
+                if (full) { float b4[4]; Out4<T>::load(rb, b4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += b4[e];
+                } else {
+                    for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(rb[e]);
+                }
+            }
+            if (p.epi & ST_EPI_RESIDUAL) {
+                const T* rr = Rp + (size_t)m * p.ldr + n;
+                if (full) { float b4[4]; Out4<T>::load(rr, b4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += b4[e];
+                } else {
+                    for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(rr[e]);
+                }
+            }
+            T* dst = Cp + (size_t)m * p.ldc + n;
+            if (full) Out4<T>::store(dst, v);
+            else for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = Elem<T>::from_f(v[e]);
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, bool CONV>
+static void launch_cfg(const GemmArgs& a, hipStream_t st) {
+    const size_t lds = 2 * (size_t)(BM + BN) * 128;
+    const int tiles_m = cdiv(a.M, BM);
+    if (a.epi & ST_EPI_GEGLU) {
+        const int tiles_n = cdiv(a.N, BN / 2);
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WGM, WGN, CONV, true>), dim3(tiles_m * tiles_n), dim3(WGM * WGN * 64), lds, st, a);
+    } else {
+        const int tiles_n = cdiv(a.N, BN);
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WGM, WGN, CONV, false>), dim3(tiles_m * tiles_n), dim3(WGM * WGN * 64), lds, st, a);
+    }
+}
+
+template <typename T, bool CONV>
+static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
+    // pick the largest tile that still gives every CU (256) a block
+    const long n_eff = (a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N;
+    auto tiles = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(n_eff, bn); };
+    if (tiles(128, 128) >= 240) launch_cfg<T, 128, 128, 2, 2, CONV>(a, st);
+    else if (tiles(128, 64) >= 200) launch_cfg<T, 128, 64, 2, 2, CONV>(a, st);
+    else launch_cfg<T, 64, 64, 2, 2, CONV>(a, st);
+    return st_check_launch(CONV ? "conv2d" : "linear");
+}
+
+static int check_epilogue(const char* who, const GemmArgs& a) {
+    ST_REQUIRE(!(a.epi & ST_EPI_BIAS) || a.bias, "%s: ST_EPI_BIAS without bias pointer", who);
+    ST_REQUIRE(!(a.epi & ST_EPI_RESIDUAL) || a.residual, "%s: ST_EPI_RESIDUAL without residual pointer", who);
+    ST_REQUIRE(!(a.epi & ST_EPI_ROWBIAS) || (a.rowbias && a.rows_per_batch > 0), "%s: ST_EPI_ROWBIAS needs rowbias and rows_per_batch", who);
+    ST_REQUIRE(!((a.epi & ST_EPI_GEGLU) && (a.epi & ST_EPI_SILU)), "%s: GEGLU and SILU are exclusive", who);
+    return 0;
+}
+
+extern "C" int st_linear(const void* x, const void* W, const void* bias, const void* residual, const void* rowbias, void* y,
+                         int M, int N, int K, long lda, long ldc, long ldr, int rows_per_batch, int epilogue, int dtype,
+                         void* stream) {
+    ST_REQUIRE(x && W && y, "linear: null pointer");
+    ST_REQUIRE(M > 0 && N > 0 && K > 0, "linear: bad shape M=%d N=%d K=%d", M, N, K);
+    const int vec = dtype == ST_BF16 ? 8 : 4;
+    ST_REQUIRE(dtype == ST_BF16 || dtype == ST_F32, "linear: unsupported dtype %d", dtype);
+    ST_REQUIRE(K % vec == 0 && lda % vec == 0, "linear: K=%d and lda=%ld must be multiples of %d", K, lda, vec);
+    ST_REQUIRE(ldc % 4 == 0 && (!(epilogue & ST_EPI_RESIDUAL) || ldr % 4 == 0), "linear: ldc/ldr must be multiples of 4");
+    ST_REQUIRE(((uintptr_t)x | (uintptr_t)W) % 16 == 0 && (uintptr_t)y % 16 == 0, "linear: pointers must be 16-byte aligned");
+    GemmArgs a = {};
+    a.A = x; a.W = W; a.bias = bias; a.residual = residual; a.rowbias = rowbias; a.C = y;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.rows_per_batch = rows_per_batch; a.epi = epilogue;
+    if (int e = check_epilogue("linear", a)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == ST_BF16 ? gemm_dispatch<bf16, false>(a, st) : gemm_dispatch<float, false>(a, st);
+}
+
+// ---- direct conv for thin inputs (conv_in: Cin = 4) ------------------------------
+// One thread per (pixel, 4 output channels); K = R*S*Cin is tiny so this is a
+// bandwidth-trivial kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_thin_kernel(const GemmArgs p, int R) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = p.N / 4;
+    if (idx >= (long)p.M * n4) return;
+    const int m = (int)(idx / n4), co = (int)(idx - (long)m * n4) * 4;
+    const int hw = p.Hout * p.Wout;
+    const int img = m / hw, rem = m - img * hw;
+    const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+    const T* x = (const T*)p.A;
+    const T* w = (const T*)p.W;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < R; ++r) {
+        int iy = oy * p.stride - p.pad + r;
+        if (iy < 0 || iy >= (p.ups ? 2 * p.Hin : p.Hin)) continue;
+        if (p.ups) iy >>= 1;
+        for (int s = 0; s < p.S; ++s) {
+            int ix = ox * p.stride - p.pad + s;
+            if (ix < 0 || ix >= (p.ups ? 2 * p.Win : p.Win)) continue;
+            if (p.ups) ix >>= 1;
+            const T* xp = x + (((size_t)img * p.Hin + iy) * p.Win + ix) * p.Cin;
+            const int kb = (r * p.S + s) * p.Cin;
+            for (int c = 0; c < p.Cin; ++c) {
+                const float xv = Elem<T>::to_f(xp[c]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += xv * Elem<T>::to_f(w[(size_t)(co + e) * p.K + kb + c]);
+            }
+        }
+    }
+    if (p.epi & ST_EPI_BIAS)
+        for (int e = 0; e < 4; ++e) acc[e] += Elem<T>::to_f(((const T*)p.bias)[co + e]);
+    if (p.epi & ST_EPI_SILU)
+        for (int e = 0; e < 4; ++e) acc[e] = silu_f(acc[e]);
+    if (p.epi & ST_EPI_ROWBIAS)
+        for (int e = 0; e < 4; ++e) acc[e] += Elem<T>::to_f(((const T*)p.rowbias)[(size_t)(m / p.rows_per_batch) * p.N + co + e]);
+    if (p.epi & ST_EPI_RESIDUAL)
+        for (int e = 0; e < 4; ++e) acc[e] += Elem<T>::to_f(((const T*)p.residual)[(size_t)m * p.ldr + co + e]);
+    Out4<T>::store((T*)p.C + (size_t)m * p.ldc + co, acc);
+}
+
+extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const void* residual, const void* rowbias, void* y,
+                         int N, int Hin, int Win, int Cin, int Cout, int R, int S, int stride, int pad, int upsample2x,
+                         int epilogue, int dtype, void* stream) {
+    ST_REQUIRE(x && W && y, "conv2d: null pointer");
+    ST_REQUIRE(N > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0,
+               "conv2d: bad geometry");
+    ST_REQUIRE(dtype == ST_BF16 || dtype == ST_F32, "conv2d: unsupported dtype %d", dtype);
+    ST_REQUIRE(!(epilogue & ST_EPI_GEGLU), "conv2d: GEGLU epilogue not supported");
+    ST_REQUIRE(Cout % 4 == 0, "conv2d: Cout=%d must be a multiple of 4", Cout);
+    const int He = upsample2x ? 2 * Hin : Hin, We = upsample2x ? 2 * Win : Win;
+    GemmArgs a = {};
+    a.A = x; a.W = W; a.bias = bias; a.residual = residual; a.rowbias = rowbias; a.C = y;
+    a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.S = S; a.stride = stride; a.pad = pad; a.ups = upsample2x ? 1 : 0;
+    a.Hout = (He + 2 * pad - R) / stride + 1;
+    a.Wout = (We + 2 * pad - S) / stride + 1;
+    ST_REQUIRE(a.Hout > 0 && a.Wout > 0, "conv2d: empty output");
+    a.M = N * a.Hout * a.Wout; a.N = Cout; a.K = R * S * Cin;
+    a.lda = 0; a.ldc = Cout; a.ldr = Cout; a.rows_per_batch = a.Hout * a.Wout; a.epi = epilogue;
+    if (int e = check_epilogue("conv2d", a)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    const int kb = dtype == ST_BF16 ? 64 : 32;
+    if (Cin % kb == 0) {
+        ST_REQUIRE(((uintptr_t)x | (uintptr_t)W | (uintptr_t)y) % 16 == 0, "conv2d: pointers must be 16-byte aligned");
+        return dtype == ST_BF16 ? gemm_dispatch<bf16, true>(a, st) : gemm_dispatch<float, true>(a, st);
+    }
+    // thin-input path
+    const long work = (long)a.M * (Cout / 4);
+    ST_REQUIRE(work / 256 < 2147483647L, "conv2d: too large for thin path");
+    if (dtype == ST_BF16)
+        hipLaunchKernelGGL(conv_thin_kernel<bf16>, dim3(cdiv(work, 256)), dim3(256), 0, st, a, R);
+    else
+        hipLaunchKernelGGL(conv_thin_kernel<float>, dim3(cdiv(work, 256)), dim3(256), 0, st, a, R);
+    return st_check_launch("conv2d(thin)");
+}

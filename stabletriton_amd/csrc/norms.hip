@@ -1,0 +1,349 @@
+// GroupNorm(+SiLU), LayerNorm and GEGLU for gfx950.  All three are HBM-bound:
+// 16-byte loads per lane, fp32 statistics, wave64 shuffles + LDS for the
+// cross-wave step.  (Rows G and E of SURVEY.md section 8a, LayerNorm is 8f-1.)
+#include "common.h"
+
+// =============================================================================
+// GroupNorm
+// -----------------------------------------------------------------------------
+// Three launches: partial statistics (enough blocks to fill 256 CUs even though
+// bs=1 has only 32 groups), a tiny Chan-combine of the partials, and the apply
+// pass.  Partials are (mean, M2, count) so the combine is numerically stable and
+// the result does not depend on the order blocks finish (deterministic).
+// =============================================================================
+
+static constexpr int GN_THREADS = 1024;
+static constexpr int GN_MAX_BLOCKS = 256;
+
+struct GnGeom {
+    int VC;      // 16-byte vectors per pixel row (NHWC)
+    int RP;      // pixel rows one block covers per pass
+    int NB;      // blocks per image
+    int P;       // pixels per block
+};
+
+template <typename T>
+static GnGeom gn_geom(int C, int HW) {
+    GnGeom g;
+    g.VC = C / Elem<T>::VEC;
+    g.RP = GN_THREADS / g.VC;
+    if (g.RP < 1) g.RP = 1;
+    int nb = (HW + g.RP - 1) / g.RP;
+    g.NB = nb < GN_MAX_BLOCKS ? nb : GN_MAX_BLOCKS;
+    g.P = (HW + g.NB - 1) / g.NB;
+    g.NB = (HW + g.P - 1) / g.P;
+    return g;
+}
+
+// NHWC partial statistics.  grid (NB, N), block 1024.  Thread (rp, col) owns one
+// 16-byte channel vector `col` of pixel rows rp, rp+RP, ...; per-channel sums
+// are then reduced over rp through LDS in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_nhwc(const T* __restrict__ x, float4* __restrict__ part,
+                                                            int C, int HW, int G, int VC, int RP, int P) {
+    constexpr int VEC = Elem<T>::VEC;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [RP][2][C]
+    const int n = blockIdx.y, b = blockIdx.x, NB = gridDim.x;
+    const int t = threadIdx.x;
+    const int rp = t / VC, col = t - rp * VC;
+    const int p0 = b * P, p1 = min(p0 + P, HW);
+    float s[VEC], ss[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { s[i] = 0.f; ss[i] = 0.f; }
+    if (rp < RP) {
+        const T* base = x + ((size_t)n * HW) * C + (size_t)col * VEC;
+        for (int p = p0 + rp; p < p1; p += RP) {
+            Vec16<T> v = load16(base + (size_t)p * C);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { float f = v.get(i); s[i] += f; ss[i] += f * f; }
+        }
+        float* row = smem + (size_t)rp * 2 * C;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { row[col * VEC + i] = s[i]; row[C + col * VEC + i] = ss[i]; }
+    }
+    __syncthreads();
+    // channel sums over rp, fixed order
+    for (int c = t; c < 2 * C; c += GN_THREADS) {
+        float a = 0.f;
+        for (int r = 0; r < RP; ++r) a += smem[(size_t)r * 2 * C + c];
+        smem[c] = a;               // row 0 becomes the total (each c touched by one thread)
+    }
+    __syncthreads();
+    if (t < G) {
+        const int cpg = C / G;
+        float S = 0.f, SS = 0.f;
+        for (int i = 0; i < cpg; ++i) { S += smem[t * cpg + i]; SS += smem[C + t * cpg + i]; }
+        const float cnt = (float)(max(p1 - p0, 0)) * (float)cpg;
+        float mean = cnt > 0.f ? S / cnt : 0.f;
+        float m2 = cnt > 0.f ? fmaxf(SS - S * mean, 0.f) : 0.f;
+        part[((size_t)n * NB + b) * G + t] = make_float4(mean, m2, cnt, 0.f);
+    }
+}
+
+// NCHW partial statistics: a group is one contiguous run of cpg*HW elements.
+// grid (NB, N*G), block 256; scalar loads (no alignment assumption).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_nchw(const T* __restrict__ x, float4* __restrict__ part,
+                                                     int C, int HW, int G, long chunk) {
+    const int ng = blockIdx.y, b = blockIdx.x, NB = gridDim.x;
+    const int n = ng / G, g = ng - n * G;
+    const int cpg = C / G;
+    const long total = (long)cpg * HW;
+    const T* base = x + ((size_t)n * C + (size_t)g * cpg) * HW;
+    const long i0 = (long)b * chunk, i1 = min(i0 + chunk, total);
+    float s = 0.f, ss = 0.f;
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) { float f = Elem<T>::to_f(base[i]); s += f; ss += f * f; }
+    __shared__ float red[2][4];
+    s = wave_sum(s); ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float S = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        float SS = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        float cnt = (float)max(i1 - i0, 0L);
+        float mean = cnt > 0.f ? S / cnt : 0.f;
+        float m2 = cnt > 0.f ? fmaxf(SS - S * mean, 0.f) : 0.f;
+        part[((size_t)n * NB + b) * G + g] = make_float4(mean, m2, cnt, 0.f);
+    }
+}
+
+// Chan et al. pairwise combine of the per-block partials -> (mean, rstd).
+__global__ void gn_finalize(const float4* __restrict__ part, float2* __restrict__ stats, int NB, int G, int NG, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NG) return;
+    const int n = i / G, g = i - n * G;
+    float mean = 0.f, m2 = 0.f, cnt = 0.f;
+    for (int b = 0; b < NB; ++b) {
+        float4 p = part[((size_t)n * NB + b) * G + g];
+        if (p.z > 0.f) {
+            float tot = cnt + p.z;
+            float d = p.x - mean;
+            mean += d * (p.z / tot);
+            m2 += p.y + d * d * (cnt * p.z / tot);
+            cnt = tot;
+        }
+    }
+    float var = m2 / cnt;
+    stats[i] = make_float2(mean, rsqrtf(var + eps));
+}
+
+template <typename T, bool SILU>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_nhwc(const T* __restrict__ x, const T* __restrict__ gamma,
+                                                            const T* __restrict__ beta, const float2* __restrict__ stats,
+                                                            T* __restrict__ y, int C, int HW, int G, int VC, int RP, int P) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int n = blockIdx.y, b = blockIdx.x;
+    const int t = threadIdx.x;
+    const int rp = t / VC, col = t - rp * VC;
+    if (rp >= RP) return;
+    const int p0 = b * P, p1 = min(p0 + P, HW);
+    const int cpg = C / G;
+    float mu[VEC], a[VEC], bt[VEC];
+    Vec16<T> gv = load16(gamma + col * VEC), bv = load16(beta + col * VEC);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        float2 st = stats[n * G + (col * VEC + i) / cpg];
+        mu[i] = st.x; a[i] = st.y * gv.get(i); bt[i] = bv.get(i);
+    }
+    const size_t base = ((size_t)n * HW) * C + (size_t)col * VEC;
+    for (int p = p0 + rp; p < p1; p += RP) {
+        Vec16<T> v = load16(x + base + (size_t)p * C), o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float f = (v.get(i) - mu[i]) * a[i] + bt[i];
+            if (SILU) f = silu_f(f);
+            o.set(i, f);
+        }
+        store16(y + base + (size_t)p * C, o);
+    }
+}
+
+template <typename T, bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_nchw(const T* __restrict__ x, const T* __restrict__ gamma,
+                                                     const T* __restrict__ beta, const float2* __restrict__ stats,
+                                                     T* __restrict__ y, int C, int HW, int G) {
+    const int nc = blockIdx.y;                 // n*C + c
+    const int n = nc / C, c = nc - n * C;
+    const float2 st = stats[n * G + c / (C / G)];
+    const float a = st.y * Elem<T>::to_f(gamma[c]), bt = Elem<T>::to_f(beta[c]);
+    const size_t base = (size_t)nc * HW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        float f = (Elem<T>::to_f(x[base + i]) - st.x) * a + bt;
+        if (SILU) f = silu_f(f);
+        y[base + i] = Elem<T>::from_f(f);
+    }
+}
+
+static size_t gn_ws_bytes(int N, int G) {
+    // partials for up to GN_MAX_BLOCKS blocks per image + final (mean, rstd)
+    return (size_t)N * GN_MAX_BLOCKS * G * sizeof(float4) + (size_t)N * G * sizeof(float2);
+}
+
+template <typename T>
+static int gn_launch(const void* x, const void* gamma, const void* beta, void* y, int N, int C, int HW, int G,
+                     float eps, int silu, int layout, void* ws, hipStream_t st) {
+    float4* part = (float4*)ws;
+    float2* stats = (float2*)((char*)ws + (size_t)N * GN_MAX_BLOCKS * G * sizeof(float4));
+    int NB;
+    if (layout == ST_NHWC) {
+        ST_REQUIRE(C % Elem<T>::VEC == 0, "group_norm NHWC: C=%d must be a multiple of %d", C, Elem<T>::VEC);
+        GnGeom g = gn_geom<T>(C, HW);
+        ST_REQUIRE(g.VC <= GN_THREADS, "group_norm NHWC: C=%d too wide", C);
+        size_t lds = (size_t)g.RP * 2 * C * sizeof(float);
+        ST_REQUIRE(lds <= 160 * 1024, "group_norm NHWC: LDS %zu too large", lds);
+        NB = g.NB;
+        hipLaunchKernelGGL(gn_stats_nhwc<T>, dim3(NB, N), dim3(GN_THREADS), lds, st, (const T*)x, part, C, HW, G, g.VC, g.RP, g.P);
+        hipLaunchKernelGGL(gn_finalize, dim3(cdiv(N * G, 64)), dim3(64), 0, st, part, stats, NB, G, N * G, eps);
+        if (silu)
+            hipLaunchKernelGGL((gn_apply_nhwc<T, true>), dim3(NB, N), dim3(GN_THREADS), 0, st, (const T*)x, (const T*)gamma,
+                               (const T*)beta, stats, (T*)y, C, HW, G, g.VC, g.RP, g.P);
+        else
+            hipLaunchKernelGGL((gn_apply_nhwc<T, false>), dim3(NB, N), dim3(GN_THREADS), 0, st, (const T*)x, (const T*)gamma,
+                               (const T*)beta, stats, (T*)y, C, HW, G, g.VC, g.RP, g.P);
+    } else {
+        const long total = (long)(C / G) * HW;
+        NB = (int)((total + 8191) / 8192);
+        if (NB > GN_MAX_BLOCKS) NB = GN_MAX_BLOCKS;
+        int want = cdiv(1024, N * G);            // keep ~1k blocks in flight at small N*G
+        if (NB > want && want >= 1) NB = want > 1 ? want : 1;
+        long chunk = (total + NB - 1) / NB;
+        NB = (int)((total + chunk - 1) / chunk);
+        hipLaunchKernelGGL(gn_stats_nchw<T>, dim3(NB, N * G), dim3(256), 0, st, (const T*)x, part, C, HW, G, chunk);
+        hipLaunchKernelGGL(gn_finalize, dim3(cdiv(N * G, 64)), dim3(64), 0, st, part, stats, NB, G, N * G, eps);
+        int bx = cdiv(HW, 256 * 4);
+        if (bx < 1) bx = 1;
+        if (silu)
+            hipLaunchKernelGGL((gn_apply_nchw<T, true>), dim3(bx, N * C), dim3(256), 0, st, (const T*)x, (const T*)gamma,
+                               (const T*)beta, stats, (T*)y, C, HW, G);
+        else
+            hipLaunchKernelGGL((gn_apply_nchw<T, false>), dim3(bx, N * C), dim3(256), 0, st, (const T*)x, (const T*)gamma,
+                               (const T*)beta, stats, (T*)y, C, HW, G);
+    }
+    return st_check_launch("group_norm");
+}
+
+extern "C" size_t st_group_norm_workspace_bytes(int N, int C, int HW, int groups) {
+    (void)C; (void)HW;
+    return gn_ws_bytes(N, groups);
+}
+
+extern "C" int st_group_norm(const void* x, const void* gamma, const void* beta, void* y, int N, int C, int HW,
+                             int groups, float eps, int silu, int layout, int dtype, void* workspace, void* stream) {
+    ST_REQUIRE(x && gamma && beta && y && workspace, "group_norm: null pointer");
+    ST_REQUIRE(N > 0 && C > 0 && HW > 0 && groups > 0 && C % groups == 0, "group_norm: bad shape N=%d C=%d HW=%d G=%d", N, C, HW, groups);
+    ST_REQUIRE(groups <= 1024 && N * C <= 65535 && N <= 65535, "group_norm: shape exceeds launch limits");
+    ST_REQUIRE(layout == ST_NCHW || layout == ST_NHWC, "group_norm: bad layout %d", layout);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ST_BF16) return gn_launch<bf16>(x, gamma, beta, y, N, C, HW, groups, eps, silu, layout, workspace, st);
+    if (dtype == ST_F32) return gn_launch<float>(x, gamma, beta, y, N, C, HW, groups, eps, silu, layout, workspace, st);
+    return st_fail("group_norm: unsupported dtype %d", dtype);
+}
+
+// =============================================================================
+// LayerNorm: one wave per row, row held in registers, exact two-pass variance.
+// =============================================================================
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
+                                                 const T* __restrict__ beta, T* __restrict__ y, int rows, int C, float eps) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int VC = C / VEC;
+    const T* xr = x + (size_t)row * C;
+    Vec16<T> v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int vc = lane + 64 * j;
+        if (vc < VC) {
+            v[j] = load16(xr + vc * VEC);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) s += v[j].get(i);
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        if (lane + 64 * j < VC) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { float d = v[j].get(i) - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    T* yr = y + (size_t)row * C;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int vc = lane + 64 * j;
+        if (vc < VC) {
+            Vec16<T> g = load16(gamma + vc * VEC), b = load16(beta + vc * VEC), o;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) o.set(i, (v[j].get(i) - mean) * rstd * g.get(i) + b.get(i));
+            store16(yr + vc * VEC, o);
+        }
+    }
+}
+
+template <typename T>
+static int ln_launch(const void* x, const void* g, const void* b, void* y, int rows, int C, float eps, hipStream_t st) {
+    constexpr int VEC = Elem<T>::VEC;
+    ST_REQUIRE(C % VEC == 0, "layer_norm: C=%d must be a multiple of %d", C, VEC);
+    const int nv = cdiv(C / VEC, 64);
+    ST_REQUIRE(nv <= 8, "layer_norm: C=%d too wide", C);
+    dim3 grid(cdiv(rows, 4)), block(256);
+#define LN_CASE(NV) case NV: hipLaunchKernelGGL((ln_kernel<T, NV>), grid, block, 0, st, (const T*)x, (const T*)g, (const T*)b, (T*)y, rows, C, eps); break;
+    switch (nv) { LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8) }
+#undef LN_CASE
+    return st_check_launch("layer_norm");
+}
+
+extern "C" int st_layer_norm(const void* x, const void* gamma, const void* beta, void* y, int rows, int C, float eps,
+                             int dtype, void* stream) {
+    ST_REQUIRE(x && gamma && beta && y, "layer_norm: null pointer");
+    ST_REQUIRE(rows > 0 && C > 0, "layer_norm: bad shape rows=%d C=%d", rows, C);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ST_BF16) return ln_launch<bf16>(x, gamma, beta, y, rows, C, eps, st);
+    if (dtype == ST_F32) return ln_launch<float>(x, gamma, beta, y, rows, C, eps, st);
+    return st_fail("layer_norm: unsupported dtype %d", dtype);
+}
+
+// =============================================================================
+// GEGLU: out = state * gelu_erf(gate), strided rows so no .contiguous() copies.
+// =============================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_kernel(const T* __restrict__ state, const T* __restrict__ gate, T* __restrict__ out,
+                                                    long nvec, int FV, long lds_, long ldg, long ldo) {
+    constexpr int VEC = Elem<T>::VEC;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const long r = i / FV;
+        const int c = (int)(i - r * FV) * VEC;
+        Vec16<T> a = load16(state + r * lds_ + c), g = load16(gate + r * ldg + c), o;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) o.set(k, a.get(k) * gelu_erf_f(g.get(k)));
+        store16(out + r * ldo + c, o);
+    }
+}
+
+template <typename T>
+static int geglu_launch(const void* s, const void* g, void* o, int rows, int F, long lds_, long ldg, long ldo, hipStream_t st) {
+    constexpr int VEC = Elem<T>::VEC;
+    ST_REQUIRE(F % VEC == 0 && lds_ % VEC == 0 && ldg % VEC == 0 && ldo % VEC == 0,
+               "geglu: F and row strides must be multiples of %d", VEC);
+    ST_REQUIRE(((uintptr_t)s | (uintptr_t)g | (uintptr_t)o) % 16 == 0, "geglu: pointers must be 16-byte aligned");
+    const long nvec = (long)rows * (F / VEC);
+    int grid = (int)((nvec + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(geglu_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)s, (const T*)g, (T*)o, nvec, F / VEC, lds_, ldg, ldo);
+    return st_check_launch("geglu");
+}
+
+extern "C" int st_geglu(const void* state, const void* gate, void* out, int rows, int F, long ld_state, long ld_gate,
+                        long ld_out, int dtype, void* stream) {
+    ST_REQUIRE(state && gate && out, "geglu: null pointer");
+    ST_REQUIRE(rows > 0 && F > 0, "geglu: bad shape rows=%d F=%d", rows, F);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ST_BF16) return geglu_launch<bf16>(state, gate, out, rows, F, ld_state, ld_gate, ld_out, st);
+    if (dtype == ST_F32) return geglu_launch<float>(state, gate, out, rows, F, ld_state, ld_gate, ld_out, st);
+    return st_fail("geglu: unsupported dtype %d", dtype);
+}

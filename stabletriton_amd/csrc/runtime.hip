@@ -1,0 +1,96 @@
+// Error plumbing, ABI version, and the small device-side pieces of the denoise
+// loop (Euler update, step counter, sinusoidal timestep features).
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+int st_fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+int st_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return st_fail("%s: launch failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" const char* st_last_error(void) { return g_err; }
+extern "C" int st_abi_version(void) { return 1; }
+
+// ---- Euler-discrete update ---------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void euler_kernel(float* __restrict__ latent, const T* __restrict__ eps, T* __restrict__ next_in,
+                                                    const float* __restrict__ dsigma, const float* __restrict__ in_scale,
+                                                    const int* __restrict__ step, long n, int n_steps) {
+    const int i = *step;
+    const float ds = dsigma[i];
+    const float sc = in_scale[i + 1 < n_steps ? i + 1 : n_steps - 1];
+    for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < n; j += (long)gridDim.x * 256) {
+        float x = latent[j] + Elem<T>::to_f(eps[j]) * ds;
+        latent[j] = x;
+        next_in[j] = Elem<T>::from_f(x * sc);
+    }
+}
+
+extern "C" int st_euler_step(float* latent, const void* eps, void* next_in, const float* dsigma, const float* in_scale,
+                             const int* step, long n, int n_steps, int dtype, void* stream) {
+    ST_REQUIRE(latent && eps && next_in && dsigma && in_scale && step, "euler_step: null pointer");
+    ST_REQUIRE(n > 0 && n_steps > 0, "euler_step: bad sizes");
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ST_BF16)
+        hipLaunchKernelGGL(euler_kernel<bf16>, dim3(grid), dim3(256), 0, st, latent, (const bf16*)eps, (bf16*)next_in, dsigma, in_scale, step, n, n_steps);
+    else if (dtype == ST_F32)
+        hipLaunchKernelGGL(euler_kernel<float>, dim3(grid), dim3(256), 0, st, latent, (const float*)eps, (float*)next_in, dsigma, in_scale, step, n, n_steps);
+    else
+        return st_fail("euler_step: unsupported dtype %d", dtype);
+    return st_check_launch("euler_step");
+}
+
+__global__ void step_advance_kernel(int* step, int n_steps) {
+    int s = *step + 1;
+    *step = s >= n_steps ? 0 : s;
+}
+
+extern "C" int st_step_advance(int* step, int n_steps, void* stream) {
+    ST_REQUIRE(step && n_steps > 0, "step_advance: bad arguments");
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, n_steps);
+    return st_check_launch("step_advance");
+}
+
+// ---- sinusoidal features (reference unet_pt.py:17-36; its fuse_timesteps pass,
+// optimizers/replace_timesteps.py:43-58, targets the same sub-graph) -----------
+template <typename T>
+__global__ void timestep_kernel(const float* __restrict__ t, long t_stride, const int* __restrict__ step,
+                                T* __restrict__ out, int batch, int dim) {
+    const int half = dim / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= batch * half) return;
+    const int b = idx / half, j = idx - b * half;
+    const int base = step ? *step : 0;
+    const float tv = t[base + b * t_stride];
+    // same fp32 op order as the eager module: (-ln(1e4) * j) / half, exp, * t
+    const float e = (-9.210340371976184f * (float)j) / (float)half;
+    const float a = tv * expf(e);
+    out[(size_t)b * dim + j] = Elem<T>::from_f(cosf(a));
+    out[(size_t)b * dim + half + j] = Elem<T>::from_f(sinf(a));
+}
+
+extern "C" int st_timestep_features(const float* t, long t_stride, const int* step, void* out, int batch, int dim,
+                                    int dtype, void* stream) {
+    ST_REQUIRE(t && out && batch > 0 && dim > 0 && dim % 2 == 0, "timestep_features: bad arguments");
+    const int n = batch * (dim / 2);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ST_BF16)
+        hipLaunchKernelGGL(timestep_kernel<bf16>, dim3(cdiv(n, 256)), dim3(256), 0, st, t, t_stride, step, (bf16*)out, batch, dim);
+    else if (dtype == ST_F32)
+        hipLaunchKernelGGL(timestep_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, t, t_stride, step, (float*)out, batch, dim);
+    else
+        return st_fail("timestep_features: unsupported dtype %d", dtype);
+    return st_check_launch("timestep_features");
+}

@@ -1,0 +1,250 @@
+"""Tensor-level launchers for the HIP operators (thin: shape/stride plumbing only).
+
+Ownership follows the reference's kernels (kernels/geglu.py:31,
+kernels/groupnorm.py:136-138, kernels/linear.py:193): the callee allocates and
+returns a fresh tensor from torch's caching allocator, inputs are never
+mutated, parameters are borrowed from the live module at call time.  Every
+launch goes to torch's current stream, so the ops are capturable.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _C
+from ._C import BackendError
+
+_workspaces = {}
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _rows2d(x: torch.Tensor):
+    """View x (..., K) as M rows with a uniform row stride; returns (tensor, M, ld)."""
+    K = x.shape[-1]
+    if x.dim() == 2 and x.stride(1) == 1:
+        return x, x.shape[0], x.stride(0)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    return x, x.numel() // K, K
+
+
+def _is_nhwc(x: torch.Tensor) -> bool:
+    return x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not (
+        x.is_contiguous() and x.shape[1] != 1 and (x.shape[2] * x.shape[3]) != 1)
+
+
+# ----------------------------------------------------------------------------- norms
+def group_norm(x: torch.Tensor, num_groups: int, weight: torch.Tensor, bias: torch.Tensor,
+               eps: float, silu: bool) -> torch.Tensor:
+    """(N,C,*) GroupNorm(+SiLU); NCHW-contiguous or channels_last in, same layout out."""
+    _C.require_device(x, weight, bias)
+    lib = _C.load()
+    if x.dim() < 3:
+        raise BackendError(f"group_norm expects (N, C, *) input, got {tuple(x.shape)}")
+    N, Cc = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * Cc)
+    if _is_nhwc(x):
+        layout = _C.ST_NHWC
+    else:
+        layout = _C.ST_NCHW
+        if not x.is_contiguous():
+            x = x.contiguous()
+    y = torch.empty_like(x)                     # preserve_format keeps NHWC strides
+    w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+    b = bias if bias.dtype == x.dtype else bias.to(x.dtype)
+    ws = _workspace(x.device, lib.st_group_norm_workspace_bytes(N, Cc, HW, num_groups))
+    _C.check(lib.st_group_norm(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups,
+                               float(eps), int(bool(silu)), layout, _C.dtype_code(x.dtype), ws.data_ptr(),
+                               _C.stream_ptr()), "group_norm")
+    return y
+
+
+def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> torch.Tensor:
+    _C.require_device(x, weight, bias)
+    lib = _C.load()
+    Cc = x.shape[-1]
+    if weight.numel() != Cc:
+        raise BackendError("layer_norm: only normalisation over the last dimension is supported")
+    xc = x if x.is_contiguous() else x.contiguous()
+    y = torch.empty_like(xc)
+    w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+    b = bias if bias.dtype == x.dtype else bias.to(x.dtype)
+    _C.check(lib.st_layer_norm(xc.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), xc.numel() // Cc, Cc,
+                               float(eps), _C.dtype_code(x.dtype), _C.stream_ptr()), "layer_norm")
+    return y
+
+
+def geglu(state: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
+    """state * gelu_erf(gate); accepts the two strided halves of one projection."""
+    _C.require_device(state, gate)
+    lib = _C.load()
+    if state.shape != gate.shape or state.dtype != gate.dtype:
+        raise BackendError("geglu: state and gate must have the same shape and dtype")
+    F = state.shape[-1]
+
+    def rows(t):
+        if t.stride(-1) == 1 and (t.dim() == 1 or all(
+                t.stride(i) == t.stride(i + 1) * t.shape[i + 1] for i in range(t.dim() - 2))):
+            return t, (t.stride(-2) if t.dim() >= 2 else F)
+        t = t.contiguous()
+        return t, F
+
+    s, lds = rows(state)
+    g, ldg = rows(gate)
+    out = torch.empty(state.shape, dtype=state.dtype, device=state.device)
+    _C.check(lib.st_geglu(s.data_ptr(), g.data_ptr(), out.data_ptr(), state.numel() // F, F, lds, ldg, F,
+                          _C.dtype_code(state.dtype), _C.stream_ptr()), "geglu")
+    return out
+
+
+# ----------------------------------------------------------------------------- linear
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, silu: bool = False,
+           geglu: bool = False, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """epilogue(x @ weight.T): +bias, then SiLU or GEGLU (weight has 2N rows), then +residual."""
+    _C.require_device(x, weight, bias, residual)
+    lib = _C.load()
+    K = x.shape[-1]
+    if weight.dim() != 2 or weight.shape[1] != K:
+        raise BackendError(f"linear: weight {tuple(weight.shape)} does not match input K={K}")
+    if weight.dtype != x.dtype:
+        raise BackendError(f"linear: weight dtype {weight.dtype} != input dtype {x.dtype} "
+                           "(convert the module once, the wrappers never mutate parameters)")
+    w = weight if weight.is_contiguous() else weight.contiguous()
+    x2, M, lda = _rows2d(x)
+    N = w.shape[0] // 2 if geglu else w.shape[0]
+    out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+    epi = 0
+    if bias is not None:
+        epi |= _C.EPI_BIAS
+        if bias.dtype != x.dtype:
+            bias = bias.to(x.dtype)
+    if silu:
+        epi |= _C.EPI_SILU
+    if geglu:
+        epi |= _C.EPI_GEGLU
+    ldr = 0
+    if residual is not None:
+        if residual.shape != out.shape or residual.dtype != x.dtype:
+            raise BackendError("linear: residual must match the output shape and dtype")
+        residual, _, ldr = _rows2d(residual)
+        epi |= _C.EPI_RESIDUAL
+    _C.check(lib.st_linear(x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
+                           lda, N, ldr, 0, epi, _C.dtype_code(x.dtype), _C.stream_ptr()), "linear")
+    return out
+
+
+# ----------------------------------------------------------------------------- attention
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int, scale: float) -> torch.Tensor:
+    """q (B,T,H*D), k/v (B,S,H*D) in projection layout -> (B,T,H*D)."""
+    _C.require_device(q, k, v)
+    lib = _C.load()
+    if q.dim() != 3 or k.dim() != 3 or v.dim() != 3:
+        raise BackendError("attention expects (B, T, H*D) tensors")
+    B, T, Cc = q.shape
+    S = k.shape[1]
+    D = Cc // num_heads
+
+    def tok(t):
+        if t.stride(2) == 1 and t.stride(0) == t.stride(1) * t.shape[1]:
+            return t, t.stride(1)
+        t = t.contiguous()
+        return t, t.shape[2]
+
+    q_, ldq = tok(q)
+    k_, ldk = tok(k)
+    v_, ldv = tok(v)
+    out = torch.empty((B, T, Cc), dtype=q.dtype, device=q.device)
+    _C.check(lib.st_attention(q_.data_ptr(), k_.data_ptr(), v_.data_ptr(), out.data_ptr(), B, T, S, num_heads, D,
+                              ldq, ldk, ldv, Cc, float(scale), _C.dtype_code(q.dtype), _C.stream_ptr()), "attention")
+    return out
+
+
+# ----------------------------------------------------------------------------- conv
+def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, padding: int, *,
+           upsample2x: bool = False, rowbias: Optional[torch.Tensor] = None,
+           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """NHWC implicit-GEMM conv.  x: (N,C,H,W) logical; returns a channels_last tensor.
+    rowbias (N,Cout) is added per image (time-embedding projection); residual is
+    (N,Cout,Hout,Wout) channels_last."""
+    _C.require_device(x, weight, bias, rowbias, residual)
+    lib = _C.load()
+    if x.dim() != 4 or weight.dim() != 4:
+        raise BackendError("conv2d expects 4-D input and weight")
+    if weight.dtype != x.dtype:
+        raise BackendError(f"conv2d: weight dtype {weight.dtype} != input dtype {x.dtype}")
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    w = weight if weight.is_contiguous(memory_format=torch.channels_last) else weight.contiguous(
+        memory_format=torch.channels_last)
+    N, Cin, H, W = x.shape
+    Cout, _, R, S = w.shape
+    He, We = (2 * H, 2 * W) if upsample2x else (H, W)
+    Ho = (He + 2 * padding - R) // stride + 1
+    Wo = (We + 2 * padding - S) // stride + 1
+    out = torch.empty((N, Cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    epi = 0
+    if bias is not None:
+        epi |= _C.EPI_BIAS
+        if bias.dtype != x.dtype:
+            bias = bias.to(x.dtype)
+    if rowbias is not None:
+        if rowbias.shape != (N, Cout) or rowbias.dtype != x.dtype:
+            raise BackendError("conv2d: rowbias must be (N, Cout) of the input dtype")
+        rowbias = rowbias.contiguous()
+        epi |= _C.EPI_ROWBIAS
+    if residual is not None:
+        if residual.shape != out.shape or residual.dtype != x.dtype:
+            raise BackendError("conv2d: residual must match the output")
+        if not residual.is_contiguous(memory_format=torch.channels_last):
+            residual = residual.contiguous(memory_format=torch.channels_last)
+        epi |= _C.EPI_RESIDUAL
+    _C.check(lib.st_conv2d(x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(rowbias), out.data_ptr(),
+                           N, H, W, Cin, Cout, R, S, stride, padding, int(upsample2x), epi,
+                           _C.dtype_code(x.dtype), _C.stream_ptr()), "conv2d")
+    return out
+
+
+# ----------------------------------------------------------------------------- loop pieces
+def timestep_features(t: torch.Tensor, dim: int, dtype: torch.dtype, step: Optional[torch.Tensor] = None,
+                      batch: Optional[int] = None, t_stride: int = 1) -> torch.Tensor:
+    _C.require_device(t)
+    lib = _C.load()
+    t32 = t if t.dtype == torch.float32 else t.float()
+    t32 = t32.contiguous()
+    nb = t32.numel() if batch is None else batch
+    out = torch.empty((nb, dim), dtype=dtype, device=t.device)
+    _C.check(lib.st_timestep_features(t32.data_ptr(), t_stride, _ptr(step), out.data_ptr(), nb, dim,
+                                      _C.dtype_code(dtype), _C.stream_ptr()), "timestep_features")
+    return out
+
+
+def euler_step(latent: torch.Tensor, eps: torch.Tensor, next_in: torch.Tensor, dsigma: torch.Tensor,
+               in_scale: torch.Tensor, step: torch.Tensor) -> None:
+    """In place: latent (fp32) += eps*dsigma[*step]; next_in = latent*in_scale[*step+1]."""
+    _C.require_device(latent, eps, next_in, dsigma, in_scale, step)
+    lib = _C.load()
+    if latent.dtype != torch.float32 or eps.dtype != next_in.dtype:
+        raise BackendError("euler_step: latent must be fp32 and eps/next_in share a dtype")
+    if not (latent.stride() == eps.stride() == next_in.stride()) or latent.numel() != eps.numel():
+        raise BackendError("euler_step: latent, eps and next_in must share one dense layout")
+    _C.check(lib.st_euler_step(latent.data_ptr(), eps.data_ptr(), next_in.data_ptr(), dsigma.data_ptr(),
+                               in_scale.data_ptr(), step.data_ptr(), latent.numel(), dsigma.numel(),
+                               _C.dtype_code(eps.dtype), _C.stream_ptr()), "euler_step")
+
+
+def step_advance(step: torch.Tensor, n_steps: int) -> None:
+    _C.require_device(step)
+    _C.check(_C.load().st_step_advance(step.data_ptr(), n_steps, _C.stream_ptr()), "step_advance")

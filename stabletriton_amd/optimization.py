@@ -1,0 +1,74 @@
+"""Compile entry point: `model = optimize_model(model, cuda_graph)`.
+
+Same surface as reference src/stabletriton/optimization.py:10-38 (README.md:5
+calls it `compile`): trace the eager module with torch.fx, run the rewrite
+passes in a fixed order (fused variants claim their nodes first), optionally
+wrap `forward` in the shape-keyed hipGraph cache.  The returned GraphModule is
+callable with the original forward signature; the caller re-attaches `.config`
+(implementations/Diffusers/load_sdxl_pipeline.py:29-34) or uses
+`stabletriton_amd.hooks`.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+from torch import fx, nn
+
+from . import _C
+from .optimizers import (fuse_attention, fuse_geglu, fuse_geglu_into_linear, fuse_residual_adds, fuse_temb_add,
+                         fuse_timesteps, keep_channels_last, make_dynamic_graphed_callable, remove_dropout,
+                         replace_conv, replace_group_norm, replace_group_norm_activation, replace_layer_norm,
+                         replace_linear, replace_linear_activ)
+
+
+def replace_backend(gm: fx.GraphModule, fuse: bool = True) -> fx.GraphModule:
+    """Pass pipeline.  The first eight passes and their order are the reference's
+    (optimization.py:10-22); replace_linear is enabled (the MFMA GEMM is the
+    product here), replace_conv / epilogue fusions / layout are additions."""
+    stats: Dict[str, int] = {}
+    stats["dropout"] = remove_dropout(gm)
+    stats["attention"] = fuse_attention(gm)
+    stats["geglu"] = fuse_geglu(gm)
+    stats["linear_silu"] = replace_linear_activ(gm, nn.SiLU())
+    stats["group_norm_silu"] = replace_group_norm_activation(gm, nn.SiLU())
+    stats["group_norm"] = replace_group_norm(gm)
+    stats["layer_norm"] = replace_layer_norm(gm)
+    stats["linear"] = replace_linear(gm)
+    stats["timesteps"] = fuse_timesteps(gm)
+    stats["conv"] = replace_conv(gm)
+    if fuse:
+        stats["geglu_in_gemm"] = fuse_geglu_into_linear(gm)
+        stats["temb_rowbias"] = fuse_temb_add(gm)
+        stats["residual_adds"] = fuse_residual_adds(gm)
+    stats["channels_last_views"] = keep_channels_last(gm)
+    gm.graph.eliminate_dead_code()
+    gm.graph.lint()
+    gm.recompile()
+    gm.rewrite_stats = stats
+    return gm
+
+
+def run_compiler(gm: fx.GraphModule) -> fx.GraphModule:
+    return replace_backend(gm)
+
+
+def optimize_model(model: nn.Module, cuda_graph: bool = True, fuse: bool = True) -> fx.GraphModule:
+    # same preconditions as the reference (optimization.py:29-33), for ROCm
+    assert torch.cuda.is_available(), "a ROCm GPU is required to use stabletriton_amd"
+    major, _ = torch.cuda.get_device_capability()
+    if major < 9:
+        raise RuntimeError("a CDNA GPU (gfx9xx; built and tuned for gfx950 / MI355X) is required")
+    p0 = next(model.parameters())
+    assert p0.device.type == "cuda", "Model must be on GPU"
+    if p0.dtype not in (torch.bfloat16, torch.float32):
+        raise RuntimeError(f"model dtype {p0.dtype} not supported: use bfloat16 (fast) or float32 (strict parity)")
+    _C.load()                                  # fail now, loudly, if the HIP library is missing
+    model = model.eval().to(memory_format=torch.channels_last)      # conv weights -> (Cout,R,S,Cin) strides
+    gm = replace_backend(fx.symbolic_trace(model), fuse=fuse)
+    if cuda_graph:
+        gm.forward = make_dynamic_graphed_callable(gm.forward)
+    return gm
+
+
+compile = optimize_model

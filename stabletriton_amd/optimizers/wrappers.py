@@ -1,0 +1,83 @@
+"""fx leaf functions: the operator boundary of the compiled graph.
+
+Names and argument meaning follow the reference's `torch.fx.wrap`-registered
+wrappers so a graph rewritten by either project calls the same symbols
+(SURVEY.md 8b): attention_wrapper (optimizers/replace_attention.py:60-71),
+geglu_triton (replace_geglu.py:23-30), group_norm_wrapper
+(replace_groupnorm.py:18-21), layer_norm_wrapper (replace_layernorm.py:17-27),
+linear_wrapper / linear_wrapper_functional (replace_linear.py:20-37),
+timestep_wrapper (replace_timesteps.py:33-40).  Here each one launches a
+hand-written gfx950 kernel through the C ABI (stabletriton_amd/ops.py).
+Unlike the reference, wrappers never mutate the module's parameters
+(replace_layernorm.py:19-22 / replace_linear.py:28-32 down-cast them in place).
+
+conv2d_wrapper and the *_fused wrappers are additions: the reference leaves
+convolutions to cuDNN and the epilogues unfused (optimizations.txt:5,13-66).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .. import ops
+
+
+def attention_wrapper(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, output: Optional[torch.Tensor],
+                      sm_scale: float, num_heads: int, head_dim: int) -> torch.Tensor:
+    """q,k,v in (B, T|S, H*D) projection layout; `output` is accepted and ignored
+    exactly as in the reference."""
+    if q.shape[-1] != num_heads * head_dim:
+        raise ops.BackendError(f"attention_wrapper: C={q.shape[-1]} != num_heads*head_dim={num_heads * head_dim}")
+    return ops.attention(q, k, v, num_heads, sm_scale)
+
+
+def geglu_triton(state: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
+    return ops.geglu(state, gate)
+
+
+def group_norm_wrapper(v: torch.Tensor, groupnorm: nn.GroupNorm, activation: bool) -> torch.Tensor:
+    return ops.group_norm(v, groupnorm.num_groups, groupnorm.weight, groupnorm.bias, groupnorm.eps, activation)
+
+
+def layer_norm_wrapper(v: torch.Tensor, layernorm: nn.LayerNorm) -> torch.Tensor:
+    return ops.layer_norm(v, layernorm.weight, layernorm.bias, layernorm.eps)
+
+
+def linear_wrapper_functional(v: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                              activation: bool) -> torch.Tensor:
+    return ops.linear(v, weight, bias, silu=activation)
+
+
+def linear_wrapper(v: torch.Tensor, linear: nn.Linear, activation: bool) -> torch.Tensor:
+    return linear_wrapper_functional(v, linear.weight, linear.bias, activation)
+
+
+def timestep_wrapper(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """cos|sin features of a 1-D fp32 timestep tensor, (len(t), dim) fp32."""
+    return ops.timestep_features(t, dim, torch.float32)
+
+
+# ---- additions -------------------------------------------------------------------------------
+def conv2d_wrapper(v: torch.Tensor, conv: nn.Conv2d, upsample2x: bool = False,
+                   rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    s, p = conv.stride, conv.padding
+    if s[0] != s[1] or p[0] != p[1] or conv.dilation != (1, 1) or conv.groups != 1 or isinstance(p, str):
+        raise ops.BackendError("conv2d_wrapper: only square stride/padding, dilation 1, groups 1")
+    return ops.conv2d(v, conv.weight, conv.bias, s[0], p[0], upsample2x=upsample2x, rowbias=rowbias, residual=residual)
+
+
+def linear_geglu_wrapper(v: torch.Tensor, linear: nn.Linear) -> torch.Tensor:
+    """GEGLU projection with the gate applied in the GEMM epilogue (unet_pt.py:155-158)."""
+    return ops.linear(v, linear.weight, linear.bias, geglu=True)
+
+
+def linear_residual_wrapper(v: torch.Tensor, linear: nn.Linear, residual: torch.Tensor) -> torch.Tensor:
+    return ops.linear(v, linear.weight, linear.bias, residual=residual)
+
+
+for _name in ("attention_wrapper", "geglu_triton", "group_norm_wrapper", "layer_norm_wrapper", "linear_wrapper",
+              "linear_wrapper_functional", "timestep_wrapper", "conv2d_wrapper", "linear_geglu_wrapper",
+              "linear_residual_wrapper"):
+    torch.fx.wrap(_name)

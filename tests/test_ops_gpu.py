@@ -1,0 +1,190 @@
+"""Per-operator parity: HIP kernels (through the C ABI) vs the CPU oracle on the
+same seeded inputs.  fp32 = strict mode, bf16 = fast mode (tolerances in util.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unet_oracle as orc
+from stabletriton_amd import ops, synth
+from tests.util import assert_close, rounded
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def rnd(name, shape, scale=1.0):
+    return synth.normal(name, shape, 7) * scale
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("silu", [False, True])
+@pytest.mark.parametrize("cl", [False, True])
+@pytest.mark.parametrize("shape", [(1, 320, 16, 16), (2, 640, 8, 8), (1, 960, 32, 32), (1, 1920, 8, 8), (2, 2560, 4, 4),
+                                   (1, 64, 5, 7), (3, 128, 1, 1)])
+def test_group_norm(gpu, dtype, silu, cl, shape):
+    x = rnd("gn.x", shape) * 1.5 + 0.7
+    w = rnd("gn.w", (shape[1],)) * 0.2 + 1.0
+    b = rnd("gn.b", (shape[1],)) * 0.2
+    ref = F.group_norm(rounded(x, dtype), 32, rounded(w, dtype), rounded(b, dtype), 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    xg = x.to(gpu, dtype)
+    if cl:
+        xg = xg.contiguous(memory_format=torch.channels_last)
+    out = ops.group_norm(xg, 32, w.to(gpu, dtype), b.to(gpu, dtype), 1e-5, silu)
+    assert out.stride() == xg.stride()
+    assert_close(out, ref, dtype, "group_norm")
+
+
+def test_group_norm_3d_and_large_mean(gpu):
+    # 3-D input as in the reference's own self-test (kernels/groupnorm.py:163-169)
+    x = rnd("gn3.x", (1, 128, 32))
+    gn = torch.nn.GroupNorm(32, 128)
+    out = ops.group_norm(x.to(gpu), 32, gn.weight.detach().to(gpu), gn.bias.detach().to(gpu), gn.eps, False)
+    assert_close(out, gn(x), torch.float32, "group_norm 3d")
+    # mean >> std: the Chan-combined partials must not cancel
+    x = rnd("gn4.x", (1, 320, 64, 64)) * 0.1 + 30.0
+    ref = F.group_norm(x, 32, None, None, 1e-5)
+    one, zero = torch.ones(320, device=gpu), torch.zeros(320, device=gpu)
+    out = ops.group_norm(x.to(gpu).contiguous(memory_format=torch.channels_last), 32, one, zero, 1e-5, False)
+    assert_close(out, ref, torch.float32, "group_norm large mean", factor=5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(1, 64, 640), (2, 77, 1280), (5, 64), (3, 9, 2048)])
+def test_layer_norm(gpu, dtype, shape):
+    x = rnd("ln.x", shape) * 2 - 0.5
+    C = shape[-1]
+    w, b = rnd("ln.w", (C,)) * 0.2 + 1.0, rnd("ln.b", (C,)) * 0.2
+    ref = F.layer_norm(rounded(x, dtype), (C,), rounded(w, dtype), rounded(b, dtype), 1e-5)
+    out = ops.layer_norm(x.to(gpu, dtype), w.to(gpu, dtype), b.to(gpu, dtype), 1e-5)
+    assert_close(out, ref, dtype, "layer_norm")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,F_", [(64, 2560), (5, 8), (1024, 5120)])
+def test_geglu(gpu, dtype, rows, F_):
+    xp = rnd("geglu.x", (rows, 2 * F_)) * 2
+    ref = orc.geglu(rounded(xp, dtype))
+    xg = xp.to(gpu, dtype)
+    a, g = xg.chunk(2, dim=-1)                 # strided halves, no copies
+    assert_close(ops.geglu(a, g), ref, dtype, "geglu strided")
+    assert_close(ops.geglu(a.contiguous(), g.contiguous()), ref, dtype, "geglu contiguous")
+
+
+LIN_SHAPES = [(1024, 1280, 1280), (256, 640, 2560), (77, 2048, 640), (1, 1280, 320), (2, 320, 1280), (1000, 64, 200),
+              (130, 2816, 1280), (4096, 640, 640)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K,N", LIN_SHAPES)
+def test_linear(gpu, dtype, M, K, N):
+    x, w, b = rnd("lin.x", (M, K)), rnd("lin.w", (N, K)) * K ** -0.5, rnd("lin.b", (N,))
+    xr, wr, br = rounded(x, dtype), rounded(w, dtype), rounded(b, dtype)
+    xg, wg, bg = x.to(gpu, dtype), w.to(gpu, dtype), b.to(gpu, dtype)
+    assert_close(ops.linear(xg, wg, None), F.linear(xr, wr), dtype, "linear")
+    assert_close(ops.linear(xg, wg, bg), F.linear(xr, wr, br), dtype, "linear+bias")
+    assert_close(ops.linear(xg, wg, bg, silu=True), F.silu(F.linear(xr, wr, br)), dtype, "linear+bias+silu")
+    r = rnd("lin.r", (M, N))
+    assert_close(ops.linear(xg, wg, bg, residual=r.to(gpu, dtype)), F.linear(xr, wr, br) + rounded(r, dtype), dtype,
+                 "linear+bias+residual")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K,F_", [(1024, 640, 2560), (64, 128, 512), (100, 64, 40)])
+def test_linear_geglu(gpu, dtype, M, K, F_):
+    x, w, b = rnd("lg.x", (2, M // 2, K)), rnd("lg.w", (2 * F_, K)) * K ** -0.5, rnd("lg.b", (2 * F_,))
+    ref = orc.geglu(F.linear(rounded(x, dtype), rounded(w, dtype), rounded(b, dtype)))
+    out = ops.linear(x.to(gpu, dtype), w.to(gpu, dtype), b.to(gpu, dtype), geglu=True)
+    assert_close(out, ref, dtype, "linear+geglu")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,T,S,H", [(1, 256, 256, 10), (2, 128, 77, 5), (1, 1024, 1024, 20), (1, 100, 33, 2),
+                                     (1, 64, 1, 1), (1, 4096, 77, 10)])
+def test_attention(gpu, dtype, B, T, S, H):
+    C = H * 64
+    q, k, v = rnd("att.q", (B, T, C)), rnd("att.k", (B, S, C)), rnd("att.v", (B, S, C))
+    ref = orc.attention_core(rounded(q, dtype), rounded(k, dtype), rounded(v, dtype), H)
+    out = ops.attention(q.to(gpu, dtype), k.to(gpu, dtype), v.to(gpu, dtype), H, 64 ** -0.5)
+    assert_close(out, ref, dtype, "attention")
+
+
+def test_attention_peaked_softmax(gpu):
+    """Force the online-softmax rescale: one key dominates late in the sequence."""
+    B, T, S, H = 1, 128, 320, 2
+    q, k, v = rnd("attp.q", (B, T, 128)), rnd("attp.k", (B, S, 128)), rnd("attp.v", (B, S, 128))
+    k[:, 300] = q[:, 5] * 6.0
+    k[:, 10] = q[:, 70] * 3.0
+    for dtype in DTYPES:
+        ref = orc.attention_core(rounded(q, dtype), rounded(k, dtype), rounded(v, dtype), H)
+        out = ops.attention(q.to(gpu, dtype), k.to(gpu, dtype), v.to(gpu, dtype), H, 0.125)
+        assert_close(out, ref, dtype, "attention peaked")
+
+
+CONVS = [  # N, Cin, H, W, Cout, k, stride, pad, upsample
+    (1, 320, 32, 32, 320, 3, 1, 1, False), (2, 64, 16, 16, 128, 3, 1, 1, False), (1, 640, 32, 32, 640, 3, 2, 1, False),
+    (1, 960, 16, 16, 320, 1, 1, 0, False), (1, 128, 16, 16, 128, 3, 1, 1, True), (1, 4, 32, 32, 320, 3, 1, 1, False),
+    (2, 320, 24, 24, 4, 3, 1, 1, False), (1, 192, 9, 7, 64, 3, 1, 1, False), (1, 64, 9, 7, 64, 3, 2, 1, False)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv2d(gpu, dtype, cfg):
+    N, Cin, H, W, Cout, k, stride, pad, ups = cfg
+    x = rnd("conv.x", (N, Cin, H, W))
+    w = rnd("conv.w", (Cout, Cin, k, k)) * (Cin * k * k) ** -0.5
+    b = rnd("conv.b", (Cout,))
+    xr = rounded(x, dtype)
+    if ups:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xr, rounded(w, dtype), rounded(b, dtype), stride=stride, padding=pad)
+    cl = torch.channels_last
+    xg, wg, bg = x.to(gpu, dtype).contiguous(memory_format=cl), w.to(gpu, dtype).contiguous(memory_format=cl), b.to(gpu, dtype)
+    out = ops.conv2d(xg, wg, bg, stride, pad, upsample2x=ups)
+    assert out.is_contiguous(memory_format=cl)
+    assert_close(out, ref, dtype, "conv2d")
+    rb, res = rnd("conv.rb", (N, Cout)), rnd("conv.res", tuple(ref.shape))
+    out = ops.conv2d(xg, wg, bg, stride, pad, upsample2x=ups, rowbias=rb.to(gpu, dtype),
+                     residual=res.to(gpu, dtype).contiguous(memory_format=cl))
+    assert_close(out, ref + rounded(rb, dtype)[:, :, None, None] + rounded(res, dtype), dtype, "conv2d+rowbias+residual")
+    # NCHW-contiguous input is accepted too (converted once inside the op)
+    assert_close(ops.conv2d(x.to(gpu, dtype), wg, bg, stride, pad, upsample2x=ups), ref, dtype, "conv2d nchw in")
+
+
+def test_timestep_features(gpu):
+    t = torch.tensor([999.0, 500.0, 1.0, 1024.0, 0.0])
+    for dim in (320, 256):
+        out = ops.timestep_features(t.to(gpu), dim, torch.float32)
+        ref = orc.timestep_features(t, dim)
+        assert (out.cpu() - ref).abs().max() < 2e-4          # fp32 sin/cos of arguments up to 1e3 rad
+
+
+def test_euler_step(gpu):
+    from stabletriton_amd.scheduler import euler_discrete_tables
+    tb = euler_discrete_tables(50)
+    ds, sc = torch.tensor(tb.dsigma()).to(gpu), torch.tensor(tb.in_scale()).to(gpu)
+    step = torch.tensor([3], dtype=torch.int32, device=gpu)
+    lat = rnd("eu.lat", (1, 4, 16, 16)) * 10
+    eps = rnd("eu.eps", (1, 4, 16, 16))
+    for dtype in DTYPES:
+        lg, eg = lat.to(gpu).clone(), eps.to(gpu, dtype)
+        nxt = torch.empty_like(eg)
+        ops.euler_step(lg, eg, nxt, ds, sc, step)
+        ref = lat + rounded(eps, dtype) * float(tb.dsigma()[3])
+        assert (lg.cpu() - ref).abs().max() < 1e-5
+        assert_close(nxt, ref * float(tb.in_scale()[4]), dtype, "euler next_in")
+    ops.step_advance(step, 50)
+    assert int(step.item()) == 4
+
+
+def test_ops_fail_loudly(gpu):
+    x = torch.randn(4, 64)
+    w = torch.randn(8, 64)
+    with pytest.raises(ops.BackendError):
+        ops.linear(x, w)                                   # CPU tensors: no fallback
+    with pytest.raises(ops.BackendError):
+        ops.linear(x.to(gpu).half(), w.to(gpu).half())     # fp16 is not a supported dtype
+    with pytest.raises(ops.BackendError):
+        ops.attention(torch.zeros(1, 8, 96, device=gpu), torch.zeros(1, 8, 96, device=gpu),
+                      torch.zeros(1, 8, 96, device=gpu), 3, 1.0)   # head_dim 32 unsupported
