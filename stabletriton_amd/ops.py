@@ -17,6 +17,27 @@ from ._C import BackendError
 
 _workspaces = {}
 
+# Optional per-launch census used by bench.py's roofline leg: when a list is
+# installed, every launcher appends (family, flops, bytes, start_event, end_event)
+# with the events recorded on the launch stream around the C call.
+_census = None
+
+
+def set_census(store) -> None:
+    global _census
+    _census = store
+
+
+def _timed(family: str, flops: float, nbytes: float, fn, *args) -> int:
+    if _census is None:
+        return fn(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    status = fn(*args)
+    e1.record()
+    _census.append((family, flops, nbytes, e0, e1))
+    return status
+
 
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     key = (device.type, device.index)
@@ -42,8 +63,8 @@ def _rows2d(x: torch.Tensor):
 
 
 def _is_nhwc(x: torch.Tensor) -> bool:
-    return x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not (
-        x.is_contiguous() and x.shape[1] != 1 and (x.shape[2] * x.shape[3]) != 1)
+    # a tensor that is contiguous in both senses (C == 1 or H*W == 1) takes the NCHW kernel
+    return x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
 
 
 # ----------------------------------------------------------------------------- norms
@@ -66,7 +87,7 @@ def group_norm(x: torch.Tensor, num_groups: int, weight: torch.Tensor, bias: tor
     w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
     b = bias if bias.dtype == x.dtype else bias.to(x.dtype)
     ws = _workspace(x.device, lib.st_group_norm_workspace_bytes(N, Cc, HW, num_groups))
-    _C.check(lib.st_group_norm(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups,
+    _C.check(_timed("group_norm", 0.0, 2.0 * x.numel() * x.element_size(), lib.st_group_norm, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups,
                                float(eps), int(bool(silu)), layout, _C.dtype_code(x.dtype), ws.data_ptr(),
                                _C.stream_ptr()), "group_norm")
     return y
@@ -82,7 +103,7 @@ def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: f
     y = torch.empty_like(xc)
     w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
     b = bias if bias.dtype == x.dtype else bias.to(x.dtype)
-    _C.check(lib.st_layer_norm(xc.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), xc.numel() // Cc, Cc,
+    _C.check(_timed("layer_norm", 0.0, 2.0 * xc.numel() * xc.element_size(), lib.st_layer_norm, xc.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), xc.numel() // Cc, Cc,
                                float(eps), _C.dtype_code(x.dtype), _C.stream_ptr()), "layer_norm")
     return y
 
@@ -105,7 +126,7 @@ def geglu(state: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
     s, lds = rows(state)
     g, ldg = rows(gate)
     out = torch.empty(state.shape, dtype=state.dtype, device=state.device)
-    _C.check(lib.st_geglu(s.data_ptr(), g.data_ptr(), out.data_ptr(), state.numel() // F, F, lds, ldg, F,
+    _C.check(_timed("geglu", 0.0, 3.0 * state.numel() * state.element_size(), lib.st_geglu, s.data_ptr(), g.data_ptr(), out.data_ptr(), state.numel() // F, F, lds, ldg, F,
                           _C.dtype_code(state.dtype), _C.stream_ptr()), "geglu")
     return out
 
@@ -141,7 +162,8 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
             raise BackendError("linear: residual must match the output shape and dtype")
         residual, _, ldr = _rows2d(residual)
         epi |= _C.EPI_RESIDUAL
-    _C.check(lib.st_linear(x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
+    _C.check(_timed("linear", 2.0 * M * w.shape[0] * K, float((M * K + w.numel() + M * N) * x.element_size()),
+                    lib.st_linear, x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
                            lda, N, ldr, 0, epi, _C.dtype_code(x.dtype), _C.stream_ptr()), "linear")
     return out
 
@@ -167,7 +189,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int,
     k_, ldk = tok(k)
     v_, ldv = tok(v)
     out = torch.empty((B, T, Cc), dtype=q.dtype, device=q.device)
-    _C.check(lib.st_attention(q_.data_ptr(), k_.data_ptr(), v_.data_ptr(), out.data_ptr(), B, T, S, num_heads, D,
+    _C.check(_timed("attention_self" if S == T else "attention_cross", 4.0 * B * num_heads * T * S * D,
+                    float((2 * q.numel() + k.numel() + v.numel()) * q.element_size()), lib.st_attention, q_.data_ptr(), k_.data_ptr(), v_.data_ptr(), out.data_ptr(), B, T, S, num_heads, D,
                               ldq, ldk, ldv, Cc, float(scale), _C.dtype_code(q.dtype), _C.stream_ptr()), "attention")
     return out
 
@@ -211,7 +234,8 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
         if not residual.is_contiguous(memory_format=torch.channels_last):
             residual = residual.contiguous(memory_format=torch.channels_last)
         epi |= _C.EPI_RESIDUAL
-    _C.check(lib.st_conv2d(x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(rowbias), out.data_ptr(),
+    _C.check(_timed("conv2d", 2.0 * N * Ho * Wo * Cout * R * S * Cin,
+                    float((x.numel() + w.numel() + out.numel()) * x.element_size()), lib.st_conv2d, x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(rowbias), out.data_ptr(),
                            N, H, W, Cin, Cout, R, S, stride, padding, int(upsample2x), epi,
                            _C.dtype_code(x.dtype), _C.stream_ptr()), "conv2d")
     return out
