@@ -66,6 +66,80 @@ template <> struct Out4<float> {
     }
 };
 
+// ---- shared epilogue: lane (r16, q) holds rows m = .. + r16, columns n = .. + 4q .. 4q+3 ----
+template <typename T, int TM, int TN, int WTM, int WTN, bool GEGLU>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                              int r16, int q) {
+    T* __restrict__ Cp = (T*)p.C;
+    const T* __restrict__ bias = (const T*)p.bias;
+    const T* __restrict__ Rp = (const T*)p.residual;
+    const T* __restrict__ RBp = (const T*)p.rowbias;
+    constexpr int TNO = GEGLU ? TN / 2 : TN;
+    constexpr int WTNO = GEGLU ? WTN / 2 : WTN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + r16;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TNO; ++j) {
+            const int n = n0 + wn * WTNO + j * 16 + 4 * q;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
+            const bool full = (n + 3 < p.N);
+            if (p.epi & ST_EPI_BIAS) {
+                if (full) { float b4[4]; Out4<T>::load(bias + n, b4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += b4[e];
+                } else {
+                    for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(bias[n + e]);
+                }
+            }
+            if (GEGLU) {
+                float g[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = acc[i][j + TN / 2][e];
+                if (p.epi & ST_EPI_BIAS) {
+                    if (full) { float b4[4]; Out4<T>::load(bias + p.N + n, b4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] += b4[e];
+                    } else {
+                        for (int e = 0; e < 4 && n + e < p.N; ++e) g[e] += Elem<T>::to_f(bias[p.N + n + e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_f(g[e]);
+            }
+            if (p.epi & ST_EPI_SILU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+            }
+            if (p.epi & ST_EPI_ROWBIAS) {
+                const T* rb = RBp + (size_t)(m / p.rows_per_batch) * p.N + n;
+                if (full) { float b4[4]; Out4<T>::load(rb, b4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += b4[e];
+                } else {
+                    for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(rb[e]);
+                }
+            }
+            if (p.epi & ST_EPI_RESIDUAL) {
+                const T* rr = Rp + (size_t)m * p.ldr + n;
+                if (full) { float b4[4]; Out4<T>::load(rr, b4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += b4[e];
+                } else {
+                    for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(rr[e]);
+                }
+            }
+            T* dst = Cp + (size_t)m * p.ldc + n;
+            if (full) Out4<T>::store(dst, v);
+            else for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = Elem<T>::from_f(v[e]);
+        }
+    }
+}
+
 template <typename T, int BM, int BN, int WGM, int WGN, bool CONV, bool GEGLU>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     constexpr int NT = WGM * WGN * 64;
@@ -227,74 +301,207 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds rows m = .. + r16, columns n = .. + 4q .. 4q+3 ----
-    T* __restrict__ Cp = (T*)p.C;
-    const T* __restrict__ bias = (const T*)p.bias;
-    const T* __restrict__ Rp = (const T*)p.residual;
-    const T* __restrict__ RBp = (const T*)p.rowbias;
-    constexpr int TNO = GEGLU ? TN / 2 : TN;
-    constexpr int WTNO = GEGLU ? WTN / 2 : WTN;
+    gemm_epilogue<T, TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wm, wn, r16, q);
+}
+
+// =============================================================================
+// v2: LDS-DMA multi-stage pipeline.  global_load_lds_dwordx4 writes each wave's
+// 1 KiB (8 rows x 128 B) straight into LDS; the XOR swizzle is applied on the
+// per-lane SOURCE address (the LDS destination of an LDS-DMA is lane-linear),
+// STAGES buffers keep STAGES-1 K-tiles in flight behind a counted vmcnt and a raw
+// s_barrier (a __syncthreads() would drain the DMA queue).  Rows outside M / N
+// and padded conv taps read from a 16-byte zero buffer, so no lane is masked.
+// =============================================================================
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+
+__device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)src, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, bool GEGLU>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs p) {
+    constexpr int NW = WGM * WGN;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int KB = 8 * VEC;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;      // 1-KiB row blocks per wave
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split evenly over the waves");
+    constexpr int G = A_IT + B_IT;                               // DMA instructions per wave per stage
+    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+    static_assert(!GEGLU || (TN % 2 == 0), "GEGLU pairs value/gate n-tiles inside one wave");
+    static_assert((STAGES - 2) * G <= 63, "vmcnt immediate");
+    typedef typename Mma<T>::Frag Frag;
+
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    // XCD-aware block order: blocks that share an XCD (blockIdx % 8) take consecutive
+    // tiles, so the W panel of a tile column is fetched into one L2, not eight
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
+    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int tile_n = wg / tiles_m, tile_m = wg - tile_n * tiles_m;
+    const int m0 = tile_m * BM;
+    constexpr int BNO = GEGLU ? BN / 2 : BN;
+    const int n0 = tile_n * BNO;
+
+    const T* __restrict__ Ap = (const T*)p.A;
+    const T* __restrict__ Wp = (const T*)p.W;
+    const T* zeros = reinterpret_cast<const T*>(g_zero16);
+
+    // ---- per-lane DMA sources: fixed (row, logical chunk) for the whole K loop ----
+    const int lr = lane >> 3;                     // row inside the 8-row block
+    const int lc = (lane & 7) ^ lr;               // logical 16-byte chunk this lane fetches (source-side swizzle)
+    const T* a_ptr[A_IT];
+    int a_adv[A_IT], a_iy[A_IT], a_ix[A_IT];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WTM + i * 16 + r16;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < TNO; ++j) {
-            const int n = n0 + wn * WTNO + j * 16 + 4 * q;
-            if (n >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
-            const bool full = (n + 3 < p.N);
-            if (p.epi & ST_EPI_BIAS) {
-                if (full) { float b4[4]; Out4<T>::load(bias + n, b4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += b4[e];
-                } else {
-                    for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(bias[n + e]);
-                }
-            }
-            if (GEGLU) {
-                float g[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = acc[i][j + TN / 2][e];
-                if (p.epi & ST_EPI_BIAS) {
-                    if (full) { float b4[4]; Out4<T>::load(bias + p.N + n, b4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) g[e] += b4[e];
-                    } else {
-                        for (int e = 0; e < 4 && n + e < p.N; ++e) g[e] += Elem<T>::to_f(bias[p.N + n + e]);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_f(g[e]);
-            }
-            if (p.epi & ST_EPI_SILU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-            }
-            if (p.epi & ST_EPI_ROWBIAS) {
-                const T* rb = RBp + (size_t)(m / p.rows_per_batch) * p.N + n;
-                if (full) { float b4[4]; Out4<T>::load(rb, b4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += b4[e];
-                } else {
-                    for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(rb[e]);
-                }
-            }
-            if (p.epi & ST_EPI_RESIDUAL) {
-                const T* rr = Rp + (size_t)m * p.ldr + n;
-                if (full) { float b4[4]; Out4<T>::load(rr, b4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += b4[e];
-                } else {
-                    for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(rr[e]);
-                }
-            }
-            T* dst = Cp + (size_t)m * p.ldc + n;
-            if (full) Out4<T>::store(dst, v);
-            else for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = Elem<T>::from_f(v[e]);
+    for (int i = 0; i < A_IT; ++i) {
+        const int row = (wave + i * NW) * 8 + lr;
+        const int m = m0 + row;
+        const bool ok = m < p.M;
+        if (CONV) {
+            const int hw = p.Hout * p.Wout;
+            const int mm = ok ? m : 0;
+            const int img = mm / hw, rem = mm - img * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            a_iy[i] = ok ? oy * p.stride - p.pad : -(1 << 28);
+            a_ix[i] = ox * p.stride - p.pad;
+            a_ptr[i] = Ap + (size_t)img * p.Hin * p.Win * p.Cin + lc * VEC;
+            a_adv[i] = 0;
+        } else {
+            a_ptr[i] = ok ? Ap + (size_t)m * p.lda + lc * VEC : zeros;
+            a_adv[i] = ok ? KB : 0;
+            a_iy[i] = a_ix[i] = 0;
         }
+    }
+    const T* b_ptr[B_IT];
+    int b_adv[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int row = (wave + i * NW) * 8 + lr;
+        int wrow;
+        bool ok;
+        if (GEGLU) {
+            const int w_ = row / WTN, local = row - w_ * WTN;
+            const int half = local >= WTN / 2 ? 1 : 0;
+            const int ncol = n0 + w_ * (WTN / 2) + (local - half * (WTN / 2));
+            ok = ncol < p.N;
+            wrow = ncol + half * p.N;
+        } else {
+            wrow = n0 + row;
+            ok = wrow < p.N;
+        }
+        b_ptr[i] = ok ? Wp + (size_t)wrow * p.K + lc * VEC : zeros;
+        b_adv[i] = ok ? KB : 0;
+    }
+
+    auto issue = [&](int kt, int buf) {
+        char* base = lds + buf * STAGE;
+        if (CONV) {
+            const int k0 = kt * KB;
+            const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
+            const int r = tap / p.S, s_ = tap - r * p.S;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                int iy = a_iy[i] + r, ix = a_ix[i] + s_;
+                bool ok;
+                if (p.ups) {
+                    ok = iy >= 0 && ix >= 0 && iy < 2 * p.Hin && ix < 2 * p.Win;
+                    iy >>= 1; ix >>= 1;
+                } else {
+                    ok = iy >= 0 && ix >= 0 && iy < p.Hin && ix < p.Win;
+                }
+                const T* src = ok ? a_ptr[i] + ((size_t)iy * p.Win + ix) * p.Cin + c0 : zeros;
+                dma16(src, base + (wave + i * NW) * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) dma16(a_ptr[i] + (size_t)kt * a_adv[i], base + (wave + i * NW) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) dma16(b_ptr[i] + (size_t)kt * b_adv[i], base + A_BYTES + (wave + i * NW) * 1024);
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int r16 = lane & 15, q = lane >> 4;
+    const int nk = p.K / KB;
+
+#pragma unroll
+    for (int s_ = 0; s_ < STAGES - 1; ++s_)
+        if (s_ < nk) issue(s_, s_);
+    if (nk >= STAGES - 1) wait_vmcnt<(STAGES - 2) * G>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
+    int cur = 0, nxt = STAGES - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + STAGES - 1 < nk;
+        if (more) issue(kt + STAGES - 1, nxt);
+        const char* sa = lds + cur * STAGE;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int c = 4 * kk + q;
+            Frag fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * WTM + i * 16 + r16;
+                fa[i] = *reinterpret_cast<const Frag*>(sa + row * 128 + ((c ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * WTN + j * 16 + r16;
+                fb[j] = *reinterpret_cast<const Frag*>(sb + row * 128 + ((c ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], fb[j], fa[i]);
+        }
+        // tile kt+1 must have landed (own DMAs), then everyone's; the barrier also
+        // retires every wave's reads of `cur` before it is refilled next iteration
+        if (more) wait_vmcnt<(STAGES - 2) * G>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
+        nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+    }
+    gemm_epilogue<T, TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wm, wn, r16, q);
+}
+
+template <typename K>
+static void allow_big_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV>
+static void launch_dma(const GemmArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)STAGES * (BM + BN) * 128;
+    const int tiles_m = cdiv(a.M, BM);
+    if (a.epi & ST_EPI_GEGLU) {
+        auto kfn = gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, CONV, true>;
+        static bool once = (allow_big_lds(kfn, lds), true);
+        (void)once;
+        hipLaunchKernelGGL(kfn, dim3(tiles_m * cdiv(a.N, BN / 2)), dim3(WGM * WGN * 64), lds, st, a);
+    } else {
+        auto kfn = gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, CONV, false>;
+        static bool once = (allow_big_lds(kfn, lds), true);
+        (void)once;
+        hipLaunchKernelGGL(kfn, dim3(tiles_m * cdiv(a.N, BN)), dim3(WGM * WGN * 64), lds, st, a);
     }
 }
 
@@ -316,9 +523,15 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
     // pick the largest tile that still gives every CU (256) a block
     const long n_eff = (a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N;
     auto tiles = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(n_eff, bn); };
-    if (tiles(128, 128) >= 240) launch_cfg<T, 128, 128, 2, 2, CONV>(a, st);
-    else if (tiles(128, 64) >= 200) launch_cfg<T, 128, 64, 2, 2, CONV>(a, st);
-    else launch_cfg<T, 64, 64, 2, 2, CONV>(a, st);
+    constexpr int KB = 128 / (int)sizeof(T);
+    const bool dma = (a.K % KB == 0);            // whole 128-byte K steps: LDS-DMA pipeline
+    if (tiles(128, 128) >= 240) {
+        if (dma) launch_dma<T, 128, 128, 2, 2, 3, CONV>(a, st); else launch_cfg<T, 128, 128, 2, 2, CONV>(a, st);
+    } else if (tiles(128, 64) >= 200) {
+        if (dma) launch_dma<T, 128, 64, 2, 2, 4, CONV>(a, st); else launch_cfg<T, 128, 64, 2, 2, CONV>(a, st);
+    } else {
+        if (dma) launch_dma<T, 64, 64, 2, 2, 4, CONV>(a, st); else launch_cfg<T, 64, 64, 2, 2, CONV>(a, st);
+    }
     return st_check_launch(CONV ? "conv2d" : "linear");
 }
 

@@ -107,24 +107,40 @@ __global__ __launch_bounds__(256) void gn_stats_nchw(const T* __restrict__ x, fl
     }
 }
 
-// Chan et al. pairwise combine of the per-block partials -> (mean, rstd).
-__global__ void gn_finalize(const float4* __restrict__ part, float2* __restrict__ stats, int NB, int G, int NG, float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// Chan et al. combine of the per-block partials -> (mean, rstd).  One wave per
+// (image, group): lanes fold their partials, then a fixed butterfly merges lanes.
+__device__ __forceinline__ void chan_merge(float& mean, float& m2, float& cnt, float pm, float p2, float pc) {
+    const float tot = cnt + pc;
+    if (pc > 0.f) {
+        const float d = pm - mean;
+        const float w = pc / tot;
+        mean += d * w;
+        m2 += p2 + d * d * (cnt * w);
+        cnt = tot;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize(const float4* __restrict__ part, float2* __restrict__ stats, int NB, int G, int NG, float eps) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (i >= NG) return;
     const int n = i / G, g = i - n * G;
     float mean = 0.f, m2 = 0.f, cnt = 0.f;
-    for (int b = 0; b < NB; ++b) {
-        float4 p = part[((size_t)n * NB + b) * G + g];
-        if (p.z > 0.f) {
-            float tot = cnt + p.z;
-            float d = p.x - mean;
-            mean += d * (p.z / tot);
-            m2 += p.y + d * d * (cnt * p.z / tot);
-            cnt = tot;
-        }
+    for (int b = lane; b < NB; b += 64) {
+        const float4 p = part[((size_t)n * NB + b) * G + g];
+        chan_merge(mean, m2, cnt, p.x, p.y, p.z);
     }
-    float var = m2 / cnt;
-    stats[i] = make_float2(mean, rsqrtf(var + eps));
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float pm = __shfl_xor(mean, o, 64), p2 = __shfl_xor(m2, o, 64), pc = __shfl_xor(cnt, o, 64);
+        // both partners must compute the same merged value: order the pair by lane
+        const bool low = (lane & o) == 0;
+        float am = low ? mean : pm, a2 = low ? m2 : p2, ac = low ? cnt : pc;
+        const float bm = low ? pm : mean, b2 = low ? p2 : m2, bc = low ? pc : cnt;
+        chan_merge(am, a2, ac, bm, b2, bc);
+        mean = am; m2 = a2; cnt = ac;
+    }
+    if (lane == 0) stats[i] = make_float2(mean, rsqrtf(m2 / cnt + eps));
 }
 
 template <typename T, bool SILU>
@@ -193,7 +209,7 @@ static int gn_launch(const void* x, const void* gamma, const void* beta, void* y
         ST_REQUIRE(lds <= 160 * 1024, "group_norm NHWC: LDS %zu too large", lds);
         NB = g.NB;
         hipLaunchKernelGGL(gn_stats_nhwc<T>, dim3(NB, N), dim3(GN_THREADS), lds, st, (const T*)x, part, C, HW, G, g.VC, g.RP, g.P);
-        hipLaunchKernelGGL(gn_finalize, dim3(cdiv(N * G, 64)), dim3(64), 0, st, part, stats, NB, G, N * G, eps);
+        hipLaunchKernelGGL(gn_finalize, dim3(cdiv(N * G, 4)), dim3(256), 0, st, part, stats, NB, G, N * G, eps);
         if (silu)
             hipLaunchKernelGGL((gn_apply_nhwc<T, true>), dim3(NB, N), dim3(GN_THREADS), 0, st, (const T*)x, (const T*)gamma,
                                (const T*)beta, stats, (T*)y, C, HW, G, g.VC, g.RP, g.P);
@@ -209,7 +225,7 @@ static int gn_launch(const void* x, const void* gamma, const void* beta, void* y
         long chunk = (total + NB - 1) / NB;
         NB = (int)((total + chunk - 1) / chunk);
         hipLaunchKernelGGL(gn_stats_nchw<T>, dim3(NB, N * G), dim3(256), 0, st, (const T*)x, part, C, HW, G, chunk);
-        hipLaunchKernelGGL(gn_finalize, dim3(cdiv(N * G, 64)), dim3(64), 0, st, part, stats, NB, G, N * G, eps);
+        hipLaunchKernelGGL(gn_finalize, dim3(cdiv(N * G, 4)), dim3(256), 0, st, part, stats, NB, G, N * G, eps);
         int bx = cdiv(HW, 256 * 4);
         if (bx < 1) bx = 1;
         if (silu)

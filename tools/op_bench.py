@@ -1,0 +1,101 @@
+"""Micro-benchmark of the HIP operators at the SDXL-base shapes (developer tool).
+Usage: python tools/op_bench.py [linear|conv|attn|norm|all]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stabletriton_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+dt = torch.bfloat16
+
+
+def timeit(fn, iters=50, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3      # us
+
+
+def rnd(*shape):
+    return (torch.rand(*shape, device=dev, dtype=torch.float32) * 2 - 1).to(dt)
+
+
+def linear():
+    # (M, K, N, count per step, geglu)
+    shapes = [(1024, 1280, 1280, 372, 0), (1024, 1280, 10240 // 2, 60, 1), (1024, 5120, 1280, 60, 0),
+              (4096, 640, 640, 70, 0), (4096, 640, 5120 // 2, 10, 1), (4096, 2560, 640, 10, 0),
+              (77, 2048, 1280, 120, 0), (77, 2048, 640, 20, 0), (1, 1280, 1280, 9, 0), (1024, 1280, 3840, 0, 0)]
+    tot = 0.0
+    for M, K, N, cnt, geglu in shapes:
+        x, w, b = rnd(M, K), rnd((2 * N if geglu else N), K) * K ** -0.5, rnd(2 * N if geglu else N)
+        us = timeit(lambda: ops.linear(x, w, b, geglu=bool(geglu)))
+        fl = 2.0 * M * K * (2 * N if geglu else N)
+        tot += us * cnt
+        print(f"linear M={M:5d} K={K:5d} N={N:5d} geglu={geglu}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s  x{cnt} = {us * cnt / 1e3:6.2f} ms")
+    print(f"linear total per step: {tot / 1e3:.2f} ms")
+
+
+def conv():
+    # (Cin, H, Cout, k, stride, ups, count)
+    shapes = [(320, 128, 320, 3, 1, 0, 7), (640, 64, 640, 3, 1, 0, 6), (1280, 32, 1280, 3, 1, 0, 10), (2560, 32, 1280, 3, 1, 0, 2),
+              (1920, 32, 1280, 3, 1, 0, 1), (1920, 64, 640, 3, 1, 0, 1), (1280, 64, 640, 3, 1, 0, 1), (960, 64, 640, 3, 1, 0, 1),
+              (960, 128, 320, 3, 1, 0, 1), (640, 128, 320, 3, 1, 0, 2), (320, 64, 640, 3, 1, 0, 1), (640, 32, 1280, 3, 1, 0, 1),
+              (320, 128, 320, 3, 2, 0, 1), (640, 64, 640, 3, 2, 0, 1), (1280, 32, 1280, 3, 1, 1, 1), (640, 64, 640, 3, 1, 1, 1),
+              (2560, 32, 1280, 1, 1, 0, 2), (960, 128, 320, 1, 1, 0, 1), (320, 128, 4, 3, 1, 0, 1), (4, 128, 320, 3, 1, 0, 1)]
+    tot = 0.0
+    cl = torch.channels_last
+    for Cin, H, Cout, k, st, ups, cnt in shapes:
+        x = rnd(1, Cin, H, H).contiguous(memory_format=cl)
+        w = (rnd(Cout, Cin, k, k) * (Cin * k * k) ** -0.5).contiguous(memory_format=cl)
+        b = rnd(Cout)
+        us = timeit(lambda: ops.conv2d(x, w, b, st, k // 2, upsample2x=bool(ups)), iters=20)
+        Ho = (H * (2 if ups else 1) + 2 * (k // 2) - k) // st + 1
+        fl = 2.0 * Ho * Ho * Cout * Cin * k * k
+        tot += us * cnt
+        print(f"conv Cin={Cin:5d} H={H:4d} Cout={Cout:5d} k={k} s={st} ups={ups}: {us:8.1f} us {fl / us / 1e6:7.1f} TF/s x{cnt} = {us * cnt / 1e3:6.2f} ms")
+    print(f"conv total per step: {tot / 1e3:.2f} ms")
+
+
+def attn():
+    tot = 0.0
+    for T, S, H, cnt in [(4096, 4096, 10, 10), (1024, 1024, 20, 60), (4096, 77, 10, 10), (1024, 77, 20, 60)]:
+        q, k, v = rnd(1, T, H * 64), rnd(1, S, H * 64), rnd(1, S, H * 64)
+        us = timeit(lambda: ops.attention(q, k, v, H, 0.125))
+        fl = 4.0 * H * T * S * 64
+        tot += us * cnt
+        print(f"attn T={T:5d} S={S:5d} H={H:3d}: {us:8.1f} us {fl / us / 1e6:7.1f} TF/s x{cnt} = {us * cnt / 1e3:6.2f} ms")
+    print(f"attention total per step: {tot / 1e3:.2f} ms")
+
+
+def norm():
+    cl = torch.channels_last
+    tot = 0.0
+    for C, H, cnt in [(320, 128, 8), (640, 128, 2), (960, 128, 1), (320, 64, 1), (640, 64, 11), (960, 64, 1), (1280, 64, 1),
+                      (1920, 64, 1), (640, 32, 1), (1280, 32, 16), (1920, 32, 1), (2560, 32, 2)]:
+        x = rnd(1, C, H, H).contiguous(memory_format=cl)
+        w, b = rnd(C), rnd(C)
+        us = timeit(lambda: ops.group_norm(x, 32, w, b, 1e-5, True))
+        by = 2.0 * x.numel() * 2
+        tot += us * cnt
+        print(f"group_norm C={C:5d} H={H:4d}: {us:7.1f} us {by / us / 1e3:7.1f} GB/s x{cnt} = {us * cnt / 1e3:6.2f} ms")
+    print(f"group_norm total per step: {tot / 1e3:.2f} ms")
+    for M, C, cnt in [(1024, 1280, 180), (4096, 640, 30)]:
+        x, w, b = rnd(M, C), rnd(C), rnd(C)
+        us = timeit(lambda: ops.layer_norm(x, w, b, 1e-5))
+        print(f"layer_norm M={M} C={C}: {us:7.1f} us {2.0 * x.numel() * 2 / us / 1e3:7.1f} GB/s x{cnt} = {us * cnt / 1e3:6.2f} ms")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    for name, fn in (("linear", linear), ("conv", conv), ("attn", attn), ("norm", norm)):
+        if what in (name, "all"):
+            fn()
