@@ -12,6 +12,7 @@
 // fragment as B), so each lane ends up with 4 consecutive output columns of
 // one row and the epilogue stores 8/16 contiguous bytes per lane.
 #include "common.h"
+#include <stdlib.h>
 
 struct GemmArgs {
     const void* A; const void* W; const void* bias; const void* residual; const void* rowbias; void* C;
@@ -21,6 +22,7 @@ struct GemmArgs {
     int epi;
     // implicit-GEMM conv geometry (unused for dense)
     int Hin, Win, Cin, Hout, Wout, S, stride, pad, ups;
+    unsigned long long* probe;   // diagnostic builds only (-DST_PROBE): per-wave phase cycle sums
 };
 
 template <typename T> struct Mma;
@@ -321,11 +323,35 @@ __device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)src, (lds_void_t*)lds_wave_base, 16, 0, 0);
 }
 
+// number of a stage's G DMA entries that the first NG-1 MFMA groups issue (entry e goes with group e*NG/G)
+constexpr int dma_before_last_group(int G, int NG) {
+    int n = 0;
+    for (int e = 0; e < G; ++e) n += (e * NG / G < NG - 1) ? 1 : 0;
+    return n;
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, bool GEGLU>
+#ifdef ST_PROBE
+__device__ __forceinline__ unsigned long long probe_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define PROBE_DECL unsigned long long pr_t0 = 0, pr_a = 0, pr_b = 0, pr_c = 0, pr_d = 0, pr_x = 0; (void)pr_x;
+#define PROBE_STAMP(var) unsigned long long var = probe_now();
+#define PROBE_ADD(acc, t1, t0) acc += (t1) - (t0);
+#else
+#define PROBE_DECL
+#define PROBE_STAMP(var)
+#define PROBE_ADD(acc, t1, t0)
+#endif
+
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV, bool GEGLU>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs p) {
     constexpr int NW = WGM * WGN;
     constexpr int VEC = 16 / (int)sizeof(T);
@@ -334,9 +360,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;      // 1-KiB row blocks per wave
     static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split evenly over the waves");
-    constexpr int G = A_IT + B_IT;                               // DMA instructions per wave per stage
-    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+    constexpr int G = (A_IT + B_IT) * U;                         // DMA instructions per wave per stage
+    constexpr int A_BYTES = BM * 128, TILE = (BM + BN) * 128, STAGE = TILE * U;   // a stage = U consecutive K tiles
     static_assert(!GEGLU || (TN % 2 == 0), "GEGLU pairs value/gate n-tiles inside one wave");
+    static_assert(STAGES >= 3, "the last DMA share of a stage is issued after the barrier: needs >= 3 buffers");
     static_assert((STAGES - 2) * G <= 63, "vmcnt immediate");
     typedef typename Mma<T>::Frag Frag;
 
@@ -406,14 +433,20 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         b_adv[i] = ok ? KB : 0;
     }
 
-    auto issue = [&](int kt, int buf) {
-        char* base = lds + buf * STAGE;
-        if (CONV) {
-            const int k0 = kt * KB;
-            const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
-            const int r = tap / p.S, s_ = tap - r * p.S;
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) {
+    // DMA list of a stage: for each of its U tiles, A_IT activation pieces then B_IT weight pieces.
+    // `issue_range` emits entries [lo, hi) so the loop can spread them between MFMA groups
+    // (back-to-back DMAs serialise in the address unit while the matrix pipe idles).
+    constexpr int PER_TILE = A_IT + B_IT;
+    auto issue_one = [&](int st, int buf, int e) {
+        const int u = e / PER_TILE, i = e - u * PER_TILE;
+        const int kt = st * U + u;
+        char* base = lds + buf * STAGE + u * TILE;
+        if (i < A_IT) {
+            const T* src;
+            if (CONV) {
+                const int k0 = kt * KB;
+                const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
+                const int r = tap / p.S, s_ = tap - r * p.S;
                 int iy = a_iy[i] + r, ix = a_ix[i] + s_;
                 bool ok;
                 if (p.ups) {
@@ -422,15 +455,19 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
                 } else {
                     ok = iy >= 0 && ix >= 0 && iy < p.Hin && ix < p.Win;
                 }
-                const T* src = ok ? a_ptr[i] + ((size_t)iy * p.Win + ix) * p.Cin + c0 : zeros;
-                dma16(src, base + (wave + i * NW) * 1024);
+                src = ok ? a_ptr[i] + ((size_t)iy * p.Win + ix) * p.Cin + c0 : zeros;
+            } else {
+                src = a_ptr[i] + (size_t)kt * a_adv[i];
             }
+            dma16(src, base + (wave + i * NW) * 1024);
         } else {
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) dma16(a_ptr[i] + (size_t)kt * a_adv[i], base + (wave + i * NW) * 1024);
+            const int j = i - A_IT;
+            dma16(b_ptr[j] + (size_t)kt * b_adv[j], base + A_BYTES + (wave + j * NW) * 1024);
         }
+    };
+    auto issue = [&](int st, int buf) {
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) dma16(b_ptr[i] + (size_t)kt * b_adv[i], base + A_BYTES + (wave + i * NW) * 1024);
+        for (int e = 0; e < G; ++e) issue_one(st, buf, e);
     };
 
     f32x4 acc[TM][TN];
@@ -440,7 +477,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int r16 = lane & 15, q = lane >> 4;
-    const int nk = p.K / KB;
+    const int nk = p.K / (KB * U);                // host guarantees K % (KB*U) == 0
 
 #pragma unroll
     for (int s_ = 0; s_ < STAGES - 1; ++s_)
@@ -448,39 +485,79 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     if (nk >= STAGES - 1) wait_vmcnt<(STAGES - 2) * G>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 
-    int cur = 0, nxt = STAGES - 1;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + STAGES - 1 < nk;
-        if (more) issue(kt + STAGES - 1, nxt);
-        const char* sa = lds + cur * STAGE;
+    // Software pipeline (one wave per SIMD has nobody else to hide LDS latency behind):
+    // the fragments of MFMA group g+1 are read while group g multiplies, and the LAST group
+    // of a stage multiplies after the stage barrier, under the first reads of the next stage.
+    constexpr int NG = 2 * U;                     // MFMA groups per stage (two 64-byte halves per K tile)
+    Frag fa[2][TM], fb[2][TN];
+    auto read_group = [&](int buf, int g, int set) {
+        const char* sa = lds + buf * STAGE + (g >> 1) * TILE;
         const char* sb = sa + A_BYTES;
+        const int c = 4 * (g & 1) + q;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int c = 4 * kk + q;
-            Frag fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm * WTM + i * 16 + r16;
-                fa[i] = *reinterpret_cast<const Frag*>(sa + row * 128 + ((c ^ (row & 7)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = wn * WTN + j * 16 + r16;
-                fb[j] = *reinterpret_cast<const Frag*>(sb + row * 128 + ((c ^ (row & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], fb[j], fa[i]);
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm * WTM + i * 16 + r16;
+            fa[set][i] = *reinterpret_cast<const Frag*>(sa + row * 128 + ((c ^ (row & 7)) << 4));
         }
-        // tile kt+1 must have landed (own DMAs), then everyone's; the barrier also
-        // retires every wave's reads of `cur` before it is refilled next iteration
-        if (more) wait_vmcnt<(STAGES - 2) * G>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = wn * WTN + j * 16 + r16;
+            fb[set][j] = *reinterpret_cast<const Frag*>(sb + row * 128 + ((c ^ (row & 7)) << 4));
+        }
+    };
+    auto mma_group = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], fb[set][j], fa[set][i]);
+    };
+
+    int cur = 0, nxt = STAGES - 1;
+    PROBE_DECL
+    PROBE_STAMP(pr_start)
+    read_group(0, 0, 0);
+    // The loop body is branch-free: trips past the last prefetch re-fetch the final stage into a
+    // buffer nobody reads again, so the vmcnt bookkeeping is the same every trip.
+    for (int kt = 0; kt < nk; ++kt) {
+        PROBE_STAMP(pr_i0)
+        const int pf = min(kt + STAGES - 1, nk - 1);      // stage to prefetch (clamped)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
+                read_group(cur, g + 1, (g + 1) & 1);
+            } else {
+                // stage kt+1 must have landed (own DMAs), then everyone's; the barrier also retires
+                // every wave's reads of `cur` (all of them are in registers by now) before its refill
+                PROBE_STAMP(pr_i1)
+                // in flight at this point: stages kt+2 .. kt+S-2 whole, plus the shares of stage
+                // kt+S-1 already issued by groups 0 .. NG-2 of this trip
+                wait_vmcnt<(STAGES - 3) * G + dma_before_last_group(G, NG)>();
+                PROBE_STAMP(pr_i2)
+                __builtin_amdgcn_s_barrier();
+                PROBE_STAMP(pr_i3)
+                PROBE_ADD(pr_a, pr_i1, pr_i0) PROBE_ADD(pr_b, pr_i2, pr_i1) PROBE_ADD(pr_c, pr_i3, pr_i2)
+                read_group(cur + 1 == STAGES ? 0 : cur + 1, 0, (g + 1) & 1);
+            }
+#pragma unroll
+            for (int e = 0; e < G; ++e)
+                if (e * NG / G == g) issue_one(pf, nxt, e);
+            mma_group(g & 1);
+        }
         cur = cur + 1 == STAGES ? 0 : cur + 1;
         nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
     }
+    wait_vmcnt<0>();                              // no LDS-DMA may outlive the workgroup's LDS allocation
+    PROBE_STAMP(pr_end)
     gemm_epilogue<T, TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wm, wn, r16, q);
+#ifdef ST_PROBE
+    {
+        PROBE_STAMP(pr_fin)
+        if (p.probe && lane == 0) {
+            unsigned long long* o = p.probe + ((size_t)blockIdx.x * NW + wave) * 8;
+            o[0] = pr_a; o[1] = pr_b; o[2] = pr_c; o[3] = pr_end - pr_start; o[4] = pr_fin - pr_end; o[5] = pr_start; o[6] = pr_fin; o[7] = nk;
+        }
+    }
+#endif
 }
 
 template <typename K>
@@ -488,52 +565,109 @@ static void allow_big_lds(K kernel, size_t bytes) {
     if (bytes > 64 * 1024) hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV>
-static void launch_dma(const GemmArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)STAGES * (BM + BN) * 128;
-    const int tiles_m = cdiv(a.M, BM);
-    if (a.epi & ST_EPI_GEGLU) {
-        auto kfn = gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, CONV, true>;
-        static bool once = (allow_big_lds(kfn, lds), true);
-        (void)once;
-        hipLaunchKernelGGL(kfn, dim3(tiles_m * cdiv(a.N, BN / 2)), dim3(WGM * WGN * 64), lds, st, a);
-    } else {
-        auto kfn = gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, CONV, false>;
-        static bool once = (allow_big_lds(kfn, lds), true);
-        (void)once;
-        hipLaunchKernelGGL(kfn, dim3(tiles_m * cdiv(a.N, BN)), dim3(WGM * WGN * 64), lds, st, a);
-    }
-}
-
 template <typename T, int BM, int BN, int WGM, int WGN, bool CONV>
 static void launch_cfg(const GemmArgs& a, hipStream_t st) {
     const size_t lds = 2 * (size_t)(BM + BN) * 128;
     const int tiles_m = cdiv(a.M, BM);
-    if (a.epi & ST_EPI_GEGLU) {
-        const int tiles_n = cdiv(a.N, BN / 2);
-        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WGM, WGN, CONV, true>), dim3(tiles_m * tiles_n), dim3(WGM * WGN * 64), lds, st, a);
-    } else {
-        const int tiles_n = cdiv(a.N, BN);
-        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WGM, WGN, CONV, false>), dim3(tiles_m * tiles_n), dim3(WGM * WGN * 64), lds, st, a);
+    if constexpr (!CONV) {
+        if (a.epi & ST_EPI_GEGLU) {
+            hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WGM, WGN, CONV, true>), dim3(tiles_m * cdiv(a.N, BN / 2)),
+                               dim3(WGM * WGN * 64), lds, st, a);
+            return;
+        }
     }
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WGM, WGN, CONV, false>), dim3(tiles_m * cdiv(a.N, BN)), dim3(WGM * WGN * 64), lds, st, a);
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV>
+static void launch_dma(const GemmArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)STAGES * U * (BM + BN) * 128;
+    const int tiles_m = cdiv(a.M, BM);
+    if constexpr (!CONV) {
+        if (a.epi & ST_EPI_GEGLU) {
+            auto kfn = gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, U, CONV, true>;
+            static bool once = (allow_big_lds(kfn, lds), true);
+            (void)once;
+            hipLaunchKernelGGL(kfn, dim3(tiles_m * cdiv(a.N, BN / 2)), dim3(WGM * WGN * 64), lds, st, a);
+            return;
+        }
+    }
+    auto kfn = gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, U, CONV, false>;
+    static bool once = (allow_big_lds(kfn, lds), true);
+    (void)once;
+    hipLaunchKernelGGL(kfn, dim3(tiles_m * cdiv(a.N, BN)), dim3(WGM * WGN * 64), lds, st, a);
+}
+
+// Tile configurations of the LDS-DMA kernel.  ST_GEMM_FORCE=<id> (developer knob)
+// overrides the heuristic for A/B runs.
+enum { CFG_64x64_S4 = 0, CFG_64x64_S8 = 1, CFG_64x64_S4_U2 = 2, CFG_128x64_S4 = 3, CFG_128x64_S3_U2 = 4,
+       CFG_128x128_S3 = 5, CFG_64x64_S3 = 6, CFG_64x64_W8 = 7, CFG_128x64_W8 = 8, CFG_128x128_W8 = 9,
+       CFG_64x128_W8 = 10, CFG_COUNT };
+
+static int forced_cfg() {
+    static int v = [] { const char* e = getenv("ST_GEMM_FORCE"); return e ? atoi(e) : -1; }();
+    return v;
 }
 
 template <typename T, bool CONV>
 static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
-    // pick the largest tile that still gives every CU (256) a block
     const long n_eff = (a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N;
     auto tiles = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(n_eff, bn); };
     constexpr int KB = 128 / (int)sizeof(T);
-    const bool dma = (a.K % KB == 0);            // whole 128-byte K steps: LDS-DMA pipeline
-    if (tiles(128, 128) >= 240) {
-        if (dma) launch_dma<T, 128, 128, 2, 2, 3, CONV>(a, st); else launch_cfg<T, 128, 128, 2, 2, CONV>(a, st);
-    } else if (tiles(128, 64) >= 200) {
-        if (dma) launch_dma<T, 128, 64, 2, 2, 4, CONV>(a, st); else launch_cfg<T, 128, 64, 2, 2, CONV>(a, st);
-    } else {
-        if (dma) launch_dma<T, 64, 64, 2, 2, 4, CONV>(a, st); else launch_cfg<T, 64, 64, 2, 2, CONV>(a, st);
+    const char* who = CONV ? "conv2d" : "linear";
+    if (a.K % KB != 0) {                         // ragged K: register-staged kernel
+        if (tiles(128, 128) >= 240) launch_cfg<T, 128, 128, 2, 2, CONV>(a, st);
+        else if (tiles(128, 64) >= 200) launch_cfg<T, 128, 64, 2, 2, CONV>(a, st);
+        else launch_cfg<T, 64, 64, 2, 2, CONV>(a, st);
+        return st_check_launch(who);
     }
-    return st_check_launch(CONV ? "conv2d" : "linear");
+    if constexpr (sizeof(T) == 4) {              // strict fp32 mode: one configuration, speed is not the point
+        launch_dma<T, 64, 64, 2, 2, 4, 1, CONV>(a, st);
+        return st_check_launch(who);
+    } else {
+        const bool even2 = (a.K % (2 * KB) == 0);
+        // 8-wave blocks (two waves per SIMD hide the LDS/DMA latencies of the K loop); the tile is
+        // chosen by a small cost model fitted to MI355X measurements (tools/op_bench.py):
+        // one block per CU at a time, a K step costs max(address-unit time of its DMA bytes at
+        // 64 B/clk, MFMA time) + a fixed sync overhead, and a partly filled last round costs a full one.
+        struct Cand { int cfg, bm, bn; };
+        static const Cand cands[] = {{CFG_128x128_W8, 128, 128}, {CFG_64x128_W8, 64, 128}, {CFG_128x64_W8, 128, 64},
+                                     {CFG_64x64_W8, 64, 64}};
+        int cfg = CFG_64x64_W8;
+        double best = 1e30;
+        for (const Cand& c : cands) {
+            const long blocks = tiles(c.bm, c.bn);
+            const double rounds = (double)((blocks + 255) / 256);
+            const double ta = 2.0 * (c.bm + c.bn), mf = c.bm * c.bn / 32.0;
+            const double cost = rounds * ((ta > mf ? ta : mf) + 150.0 + (CONV ? 0.5 * c.bm : 0.0));
+            if (cost < best) { best = cost; cfg = c.cfg; }
+        }
+        const int f = forced_cfg();
+        if (f >= 0 && f < CFG_COUNT) {
+            const bool u2 = (f == CFG_64x64_S4_U2 || f == CFG_128x64_S3_U2);
+            if (!u2 || even2) cfg = f;
+        }
+        switch (cfg) {
+            case CFG_64x64_S4: launch_dma<T, 64, 64, 2, 2, 4, 1, CONV>(a, st); break;
+            case CFG_64x64_S8: launch_dma<T, 64, 64, 2, 2, 8, 1, CONV>(a, st); break;
+            case CFG_64x64_S4_U2: launch_dma<T, 64, 64, 2, 2, 4, 2, CONV>(a, st); break;
+            case CFG_128x64_S4: launch_dma<T, 128, 64, 2, 2, 4, 1, CONV>(a, st); break;
+            case CFG_128x64_S3_U2: launch_dma<T, 128, 64, 2, 2, 3, 2, CONV>(a, st); break;
+            case CFG_128x128_S3: launch_dma<T, 128, 128, 2, 2, 3, 1, CONV>(a, st); break;
+            case CFG_64x64_S3: launch_dma<T, 64, 64, 2, 2, 3, 1, CONV>(a, st); break;
+            case CFG_64x64_W8: launch_dma<T, 64, 64, 4, 2, 4, 1, CONV>(a, st); break;
+            case CFG_128x64_W8: launch_dma<T, 128, 64, 4, 2, 4, 1, CONV>(a, st); break;
+            case CFG_64x128_W8: launch_dma<T, 64, 128, 2, 4, 4, 1, CONV>(a, st); break;
+            default: launch_dma<T, 128, 128, 2, 4, 3, 1, CONV>(a, st); break;
+        }
+        return st_check_launch(who);
+    }
 }
+
+#ifdef ST_PROBE
+static unsigned long long* g_probe = nullptr;
+extern "C" void st_debug_set_probe(void* p) { g_probe = (unsigned long long*)p; }
+#endif
 
 static int check_epilogue(const char* who, const GemmArgs& a) {
     ST_REQUIRE(!(a.epi & ST_EPI_BIAS) || a.bias, "%s: ST_EPI_BIAS without bias pointer", who);
@@ -556,52 +690,87 @@ extern "C" int st_linear(const void* x, const void* W, const void* bias, const v
     GemmArgs a = {};
     a.A = x; a.W = W; a.bias = bias; a.residual = residual; a.rowbias = rowbias; a.C = y;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.rows_per_batch = rows_per_batch; a.epi = epilogue;
+#ifdef ST_PROBE
+    a.probe = g_probe;
+#endif
     if (int e = check_epilogue("linear", a)) return e;
     hipStream_t st = (hipStream_t)stream;
     return dtype == ST_BF16 ? gemm_dispatch<bf16, false>(a, st) : gemm_dispatch<float, false>(a, st);
 }
 
-// ---- direct conv for thin inputs (conv_in: Cin = 4) ------------------------------
-// One thread per (pixel, 4 output channels); K = R*S*Cin is tiny so this is a
-// bandwidth-trivial kernel.
-template <typename T>
+// ---- direct conv for thin inputs (conv_in: Cin = 4, K = R*S*Cin = 36) ---------------------
+// Weights sit in LDS as fp32 [K][Cout]; a thread owns one output pixel and a strip of 16 output
+// channels at a time: its K input values stay in registers, weight reads are wave-wide broadcasts
+// (all lanes of a wave work on the same channel strip).
+template <typename T, int KMAX>
 __global__ __launch_bounds__(256) void conv_thin_kernel(const GemmArgs p, int R) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const int n4 = p.N / 4;
-    if (idx >= (long)p.M * n4) return;
-    const int m = (int)(idx / n4), co = (int)(idx - (long)m * n4) * 4;
-    const int hw = p.Hout * p.Wout;
-    const int img = m / hw, rem = m - img * hw;
-    const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+    extern __shared__ __attribute__((aligned(16))) float wsm[];       // [K][Cout]
     const T* x = (const T*)p.A;
     const T* w = (const T*)p.W;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < R; ++r) {
-        int iy = oy * p.stride - p.pad + r;
-        if (iy < 0 || iy >= (p.ups ? 2 * p.Hin : p.Hin)) continue;
-        if (p.ups) iy >>= 1;
-        for (int s = 0; s < p.S; ++s) {
-            int ix = ox * p.stride - p.pad + s;
-            if (ix < 0 || ix >= (p.ups ? 2 * p.Win : p.Win)) continue;
-            if (p.ups) ix >>= 1;
-            const T* xp = x + (((size_t)img * p.Hin + iy) * p.Win + ix) * p.Cin;
-            const int kb = (r * p.S + s) * p.Cin;
-            for (int c = 0; c < p.Cin; ++c) {
-                const float xv = Elem<T>::to_f(xp[c]);
+    const int K = p.K, N = p.N;
+    for (int i = threadIdx.x; i < K * N; i += 256) {
+        const int n = i / K, k = i - n * K;
+        wsm[k * N + n] = Elem<T>::to_f(w[i]);
+    }
+    __syncthreads();
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const bool live = m < p.M;
+    const int mm = live ? m : 0;
+    const int hw = p.Hout * p.Wout;
+    const int img = mm / hw, rem = mm - img * hw;
+    const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+    float xin[KMAX];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] += xv * Elem<T>::to_f(w[(size_t)(co + e) * p.K + kb + c]);
+    for (int k = 0; k < KMAX; ++k) xin[k] = 0.f;
+    {
+        int k = 0;
+        for (int r = 0; r < R; ++r)
+            for (int s_ = 0; s_ < p.S; ++s_) {
+                int iy = oy * p.stride - p.pad + r, ix = ox * p.stride - p.pad + s_;
+                const int He = p.ups ? 2 * p.Hin : p.Hin, We = p.ups ? 2 * p.Win : p.Win;
+                const bool ok = iy >= 0 && ix >= 0 && iy < He && ix < We;
+                if (p.ups) { iy >>= 1; ix >>= 1; }
+                const T* xp = x + (((size_t)img * p.Hin + (ok ? iy : 0)) * p.Win + (ok ? ix : 0)) * p.Cin;
+                for (int c = 0; c < p.Cin; ++c, ++k) {
+                    const float v = ok ? Elem<T>::to_f(xp[c]) : 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < KMAX; ++kk) if (kk == k) xin[kk] = v;     // keep xin[] in registers
+                }
+            }
+    }
+    for (int n0 = 0; n0 < N; n0 += 16) {
+        float acc[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k < K) {
+                const float xv = xin[k];
+                const float* wr = wsm + k * N + n0;
+#pragma unroll
+                for (int e = 0; e < 16; e += 4) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + e);
+                    acc[e] += xv * w4[0]; acc[e + 1] += xv * w4[1]; acc[e + 2] += xv * w4[2]; acc[e + 3] += xv * w4[3];
+                }
             }
         }
+        if (!live) continue;
+#pragma unroll
+        for (int e0 = 0; e0 < 16; e0 += 4) {
+            const int co = n0 + e0;
+            if (co >= N) break;
+            float v[4] = {acc[e0], acc[e0 + 1], acc[e0 + 2], acc[e0 + 3]};
+            if (p.epi & ST_EPI_BIAS)
+                for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f(((const T*)p.bias)[co + e]);
+            if (p.epi & ST_EPI_SILU)
+                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+            if (p.epi & ST_EPI_ROWBIAS)
+                for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f(((const T*)p.rowbias)[(size_t)(m / p.rows_per_batch) * N + co + e]);
+            if (p.epi & ST_EPI_RESIDUAL)
+                for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f(((const T*)p.residual)[(size_t)m * p.ldr + co + e]);
+            Out4<T>::store((T*)p.C + (size_t)m * p.ldc + co, v);
+        }
     }
-    if (p.epi & ST_EPI_BIAS)
-        for (int e = 0; e < 4; ++e) acc[e] += Elem<T>::to_f(((const T*)p.bias)[co + e]);
-    if (p.epi & ST_EPI_SILU)
-        for (int e = 0; e < 4; ++e) acc[e] = silu_f(acc[e]);
-    if (p.epi & ST_EPI_ROWBIAS)
-        for (int e = 0; e < 4; ++e) acc[e] += Elem<T>::to_f(((const T*)p.rowbias)[(size_t)(m / p.rows_per_batch) * p.N + co + e]);
-    if (p.epi & ST_EPI_RESIDUAL)
-        for (int e = 0; e < 4; ++e) acc[e] += Elem<T>::to_f(((const T*)p.residual)[(size_t)m * p.ldr + co + e]);
-    Out4<T>::store((T*)p.C + (size_t)m * p.ldc + co, acc);
 }
 
 extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const void* residual, const void* rowbias, void* y,
@@ -629,12 +798,13 @@ extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const v
         ST_REQUIRE(((uintptr_t)x | (uintptr_t)W | (uintptr_t)y) % 16 == 0, "conv2d: pointers must be 16-byte aligned");
         return dtype == ST_BF16 ? gemm_dispatch<bf16, true>(a, st) : gemm_dispatch<float, true>(a, st);
     }
-    // thin-input path
-    const long work = (long)a.M * (Cout / 4);
-    ST_REQUIRE(work / 256 < 2147483647L, "conv2d: too large for thin path");
+    // thin-input path: K = R*S*Cin small enough to keep one pixel's inputs in registers
+    ST_REQUIRE(a.K <= 64 && Cout % 16 == 0, "conv2d: Cin=%d is neither a multiple of %d (implicit GEMM) nor thin (R*S*Cin <= 64, Cout %% 16 == 0)", Cin, kb);
+    const size_t lds = (size_t)a.K * Cout * sizeof(float);
+    ST_REQUIRE(lds <= 64 * 1024, "conv2d(thin): weights do not fit LDS");
     if (dtype == ST_BF16)
-        hipLaunchKernelGGL(conv_thin_kernel<bf16>, dim3(cdiv(work, 256)), dim3(256), 0, st, a, R);
+        hipLaunchKernelGGL((conv_thin_kernel<bf16, 64>), dim3(cdiv(a.M, 256)), dim3(256), lds, st, a, R);
     else
-        hipLaunchKernelGGL(conv_thin_kernel<float>, dim3(cdiv(work, 256)), dim3(256), 0, st, a, R);
+        hipLaunchKernelGGL((conv_thin_kernel<float, 64>), dim3(cdiv(a.M, 256)), dim3(256), lds, st, a, R);
     return st_check_launch("conv2d(thin)");
 }

@@ -16,8 +16,8 @@ import torch
 from torch import fx, nn
 
 from . import _C
-from .optimizers import (fuse_attention, fuse_geglu, fuse_geglu_into_linear, fuse_residual_adds, fuse_temb_add,
-                         fuse_timesteps, keep_channels_last, make_dynamic_graphed_callable, remove_dropout,
+from .optimizers import (fuse_attention, fuse_geglu, fuse_geglu_into_linear, fuse_residual_adds, fuse_shared_input_linears,
+                         fuse_temb_add, fuse_timesteps, split_context, keep_channels_last, make_dynamic_graphed_callable, remove_dropout,
                          replace_conv, replace_group_norm, replace_group_norm_activation, replace_layer_norm,
                          replace_linear, replace_linear_activ)
 
@@ -41,6 +41,7 @@ def replace_backend(gm: fx.GraphModule, fuse: bool = True) -> fx.GraphModule:
         stats["geglu_in_gemm"] = fuse_geglu_into_linear(gm)
         stats["temb_rowbias"] = fuse_temb_add(gm)
         stats["residual_adds"] = fuse_residual_adds(gm)
+        stats["shared_input_gemms"] = fuse_shared_input_linears(gm)
     stats["channels_last_views"] = keep_channels_last(gm)
     gm.graph.eliminate_dead_code()
     gm.graph.lint()
@@ -66,9 +67,43 @@ def optimize_model(model: nn.Module, cuda_graph: bool = True, fuse: bool = True)
     _C.load()                                  # fail now, loudly, if the HIP library is missing
     model = model.eval().to(memory_format=torch.channels_last)      # conv weights -> (Cout,R,S,Cin) strides
     gm = replace_backend(fx.symbolic_trace(model), fuse=fuse)
+    if fuse:
+        _install_context_split(gm)
     if cuda_graph:
         gm.forward = make_dynamic_graphed_callable(gm.forward)
     return gm
+
+
+def _install_context_split(gm: fx.GraphModule) -> None:
+    """Hoist the text-context projections (step-invariant) out of the per-step graph.
+
+    `gm(sample, timesteps, encoder_hidden_states, added_cond_kwargs)` keeps working and stays
+    stateless (it evaluates the context part on every call).  Loops that reuse one prompt call
+    `ctx = gm.precompute_context(ehs)` once and `gm.forward_with_context(sample, t, ctx, cond)`
+    per step (stabletriton_amd/pipeline.py)."""
+    names = [n.target for n in gm.graph.nodes if n.op == "placeholder"]
+    if "encoder_hidden_states" not in names:
+        return
+    context_module = split_context(gm, "encoder_hidden_states")
+    if context_module is None:
+        return
+    gm.rewrite_stats["context_outputs"] = len(
+        [n for n in context_module.graph.nodes if n.op == "output"][0].args[0])
+    gm.context_module = context_module
+    core = gm.forward                     # generated: (sample, timesteps, ehs, context_cache, added_cond_kwargs, **kw)
+
+    def precompute_context(encoder_hidden_states):
+        return context_module(encoder_hidden_states)
+
+    def forward_with_context(sample, timesteps, context_cache, added_cond_kwargs, **kwargs):
+        return core(sample, timesteps, None, context_cache, added_cond_kwargs, **kwargs)
+
+    def forward(sample, timesteps, encoder_hidden_states, added_cond_kwargs, **kwargs):
+        return core(sample, timesteps, None, context_module(encoder_hidden_states), added_cond_kwargs, **kwargs)
+
+    gm.precompute_context = precompute_context
+    gm.forward_with_context = forward_with_context
+    gm.forward = forward
 
 
 compile = optimize_model

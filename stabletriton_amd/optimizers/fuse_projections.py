@@ -1,0 +1,113 @@
+"""Graph-level GEMM consolidation (additions; cf. the reference's unused fused
+Q/K/V projection kernel, kernels/attention_proj.py:53-155):
+
+* `fuse_shared_input_linears`: plain bias-free linear_wrapper calls that read the
+  same tensor (to_q/to_k/to_v of self-attention, to_k/to_v of cross-attention,
+  unet_pt.py:122-132) become one `linear_cat_wrapper` GEMM; consumers get
+  column slices (the attention kernel takes strided q/k/v).
+* `split_context`: everything that depends only on `encoder_hidden_states`
+  (the 77-token text context: 140 K/V projections, step-invariant - SURVEY.md 8a
+  row L) moves into a separate context GraphModule, evaluated once per prompt.
+"""
+from __future__ import annotations
+
+import operator
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import fx, nn
+
+from .wrappers import linear_cat_wrapper, linear_wrapper
+
+
+def fuse_shared_input_linears(gm: fx.GraphModule) -> int:
+    groups: Dict[fx.Node, List[fx.Node]] = {}
+    for n in gm.graph.nodes:
+        if n.op == "call_function" and n.target is linear_wrapper and n.args[2] is False and isinstance(n.args[0], fx.Node):
+            lin = gm.get_submodule(n.args[1].target)
+            if isinstance(lin, nn.Linear) and lin.bias is None:
+                groups.setdefault(n.args[0], []).append(n)
+    fused = 0
+    for src, nodes in groups.items():
+        if len(nodes) < 2:
+            continue
+        first = nodes[0]
+        mods = [gm.get_submodule(n.args[1].target) for n in nodes]
+        if len({m.in_features for m in mods}) != 1 or len({m.weight.dtype for m in mods}) != 1:
+            continue
+        with gm.graph.inserting_before(first):
+            attrs = tuple(gm.graph.get_attr(n.args[1].target) for n in nodes)
+            cat = gm.graph.call_function(linear_cat_wrapper, (src, attrs))
+            off = 0
+            for n, m in zip(nodes, mods):
+                sl = gm.graph.call_function(operator.getitem, (cat, (Ellipsis, slice(off, off + m.out_features))))
+                n.replace_all_uses_with(sl)
+                off += m.out_features
+        for n in nodes:
+            gm.graph.erase_node(n)
+        fused += 1
+    if fused:
+        gm.graph.eliminate_dead_code()
+        gm.graph.lint()
+        gm.recompile()
+    return fused
+
+
+def split_context(gm: fx.GraphModule, context_arg: str = "encoder_hidden_states") -> Optional[fx.GraphModule]:
+    """Move the sub-graph that depends only on `context_arg` into its own GraphModule.
+
+    Returns the context module (ctx(encoder_hidden_states) -> tuple of tensors) or None if
+    nothing could be hoisted.  `gm` gains a placeholder `context_cache` right after
+    `context_arg`; its original placeholder stays (unused) so positions do not shift.
+    """
+    nodes = list(gm.graph.nodes)
+    ctx_ph = next((n for n in nodes if n.op == "placeholder" and n.target == context_arg), None)
+    if ctx_ph is None:
+        return None
+    inside = {ctx_ph}
+    region: List[fx.Node] = []
+    for n in nodes:
+        if n.op in ("placeholder", "output", "get_attr"):
+            continue
+        ins = n.all_input_nodes
+        if ins and all((i in inside) or i.op == "get_attr" for i in ins) and any(i in inside for i in ins):
+            inside.add(n)
+            region.append(n)
+    if not region:
+        return None
+    region_set = set(region)
+    frontier = [n for n in region if any(u not in region_set for u in n.users)]
+    if not frontier:
+        return None
+
+    # ---- build the context graph -------------------------------------------------------------
+    cg = fx.Graph()
+    env: Dict[fx.Node, fx.Node] = {ctx_ph: cg.placeholder(context_arg)}
+
+    def remap(x):
+        if x in env:
+            return env[x]
+        assert x.op == "get_attr", f"unexpected external dependency {x.format_node()}"
+        env[x] = cg.get_attr(x.target)
+        return env[x]
+
+    for n in region:
+        env[n] = cg.node_copy(n, remap)
+    cg.output(tuple(env[n] for n in frontier))
+    context_module = fx.GraphModule(gm, cg, class_name="ContextModule")
+
+    # ---- rewire the main graph ---------------------------------------------------------------
+    with gm.graph.inserting_after(ctx_ph):
+        cache = gm.graph.placeholder("context_cache")
+    first_user = next(n for n in gm.graph.nodes if n.op not in ("placeholder", "get_attr"))
+    with gm.graph.inserting_before(first_user):
+        for i, n in enumerate(frontier):
+            gi = gm.graph.call_function(operator.getitem, (cache, i))
+            n.replace_all_uses_with(gi)
+    for n in reversed(region):
+        if len(n.users) == 0:
+            gm.graph.erase_node(n)
+    gm.graph.eliminate_dead_code()
+    gm.graph.lint()
+    gm.recompile()
+    return context_module

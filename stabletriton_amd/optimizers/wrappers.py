@@ -81,3 +81,35 @@ for _name in ("attention_wrapper", "geglu_triton", "group_norm_wrapper", "layer_
               "linear_wrapper_functional", "timestep_wrapper", "conv2d_wrapper", "linear_geglu_wrapper",
               "linear_residual_wrapper"):
     torch.fx.wrap(_name)
+
+
+# ---- fused projections sharing one input (q|k|v of self-attention, k|v of cross-attention) ----
+_cat_weights = {}
+
+
+def _cat_weight(linears):
+    """Row-concatenated weight (and bias) of several nn.Linear with the same in_features; rebuilt
+    whenever one of the source parameters changes (weight swaps / LoRA merges stay visible)."""
+    key = tuple(id(l) for l in linears)
+    stamp = tuple((l.weight.data_ptr(), l.weight._version, l.weight.dtype,
+                   None if l.bias is None else (l.bias.data_ptr(), l.bias._version)) for l in linears)
+    hit = _cat_weights.get(key)
+    if hit is None or hit[0] != stamp:
+        w = torch.cat([l.weight.detach() for l in linears], dim=0).contiguous()
+        if all(l.bias is None for l in linears):
+            b = None
+        else:
+            b = torch.cat([l.bias.detach() if l.bias is not None else
+                           torch.zeros(l.out_features, dtype=l.weight.dtype, device=l.weight.device) for l in linears])
+        hit = (stamp, w, b)
+        _cat_weights[key] = hit
+    return hit[1], hit[2]
+
+
+def linear_cat_wrapper(v: torch.Tensor, linears) -> torch.Tensor:
+    """[lin_0(v) | lin_1(v) | ...] along the last dimension, as ONE GEMM."""
+    w, b = _cat_weight(tuple(linears))
+    return ops.linear(v, w, b)
+
+
+torch.fx.wrap("linear_cat_wrapper")

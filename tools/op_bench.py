@@ -12,17 +12,24 @@ dev = torch.device("cuda:0")
 dt = torch.bfloat16
 
 
-def timeit(fn, iters=50, warm=5):
+def timeit(fn, iters=20, warm=3):
+    """GPU time per call in us: `iters` calls captured in one hipGraph, replayed (no host launch cost)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        fn()
+    for _ in range(5):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3      # us
+    return e0.elapsed_time(e1) / (5 * iters) * 1e3
 
 
 def rnd(*shape):
@@ -57,7 +64,7 @@ def conv():
         x = rnd(1, Cin, H, H).contiguous(memory_format=cl)
         w = (rnd(Cout, Cin, k, k) * (Cin * k * k) ** -0.5).contiguous(memory_format=cl)
         b = rnd(Cout)
-        us = timeit(lambda: ops.conv2d(x, w, b, st, k // 2, upsample2x=bool(ups)), iters=20)
+        us = timeit(lambda: ops.conv2d(x, w, b, st, k // 2, upsample2x=bool(ups)))
         Ho = (H * (2 if ups else 1) + 2 * (k // 2) - k) // st + 1
         fl = 2.0 * Ho * Ho * Cout * Cin * k * k
         tot += us * cnt
