@@ -150,10 +150,18 @@ def replace_pattern(gm: fx.GraphModule, pattern: Union[Callable, nn.Module], rep
     """
     matches = SubgraphMatcher(pattern, module_filter).match(gm)
     order = {n: i for i, n in enumerate(gm.graph.nodes)}
+    replaced: Dict[fx.Node, fx.Node] = {}
     for m in matches:
+        # a wildcard of this match may have bound the anchor of an earlier match (chained patterns):
+        # hand the replacement the node that now carries that value
+        for name, val in list(m.bindings.items()):
+            while isinstance(val, fx.Node) and val in replaced:
+                val = replaced[val]
+            m.bindings[name] = val
         with gm.graph.inserting_before(m.anchor):
             new = replacement(gm.graph, m)
         m.anchor.replace_all_uses_with(new)
+        replaced[m.anchor] = new
         for n in sorted(m.interior(), key=order.__getitem__, reverse=True):
             if len(n.users) == 0:
                 gm.graph.erase_node(n)

@@ -1,0 +1,91 @@
+"""Pin the CPU oracle against the vectors recorded from the REFERENCE itself
+(oracle/make_golden.py imported /root/reference/.../unet_pt.py and stored its outputs)."""
+import pytest
+import torch
+
+from oracle import unet_oracle as orc
+from stabletriton_amd import synth
+from stabletriton_amd import unet as U
+from stabletriton_amd.scheduler import euler_discrete_tables
+from stabletriton_amd.unet import SDXL_BASE, UNet2DConditionModel
+from tests.util import golden
+
+F2_STRIDE = 31
+
+
+def _sub(t):
+    return t.flatten()[::F2_STRIDE] if t.numel() > 20000 else t
+
+
+def _sd(prefix, shapes):
+    return {k: synth.param_tensor(f"{prefix}.{k}", s, 0) for k, s in shapes.items()}
+
+
+def _shapes(mod):
+    return {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+
+
+def test_f2_ops_match_reference_bitwise():
+    g = golden("f2_ops")
+    seed = 1234
+
+    def check(name, out):
+        ref = torch.from_numpy(g[name])
+        got = _sub(out).reshape(ref.shape)
+        assert torch.equal(got, ref), f"{name}: max diff {float((got - ref).abs().max()):.3e}"
+
+    for c in (640, 1280):
+        x = synth.normal(f"f2.attn_self{c}.x", (1, 256, c), seed)
+        sd = {"a." + k: v for k, v in _sd(f"f2.attn_self{c}", _shapes(U.Attention(c, 64))).items()}
+        check(f"attn_self{c}", orc.attention(sd, "a", x))
+        ctx = synth.normal(f"f2.attn_cross{c}.ctx", (1, 77, 2048), seed)
+        sd = {"a." + k: v for k, v in _sd(f"f2.attn_cross{c}", _shapes(U.Attention(c, 64, 2048))).items()}
+        check(f"attn_cross{c}", orc.attention(sd, "a", x, ctx))
+    for cin, cout in ((320, 320), (960, 320)):
+        sd = {"r." + k: v for k, v in _sd(f"f2.res{cin}_{cout}", _shapes(U.ResBlock(cin, cout, 1280, 32))).items()}
+        x = synth.normal(f"f2.res{cin}_{cout}.x", (1, cin, 16, 16), seed)
+        temb = synth.normal(f"f2.res{cin}_{cout}.temb", (1, 1280), seed)
+        check(f"res{cin}_{cout}", orc.resnet_block(sd, "r", x, temb))
+    sd = {"g." + k: v for k, v in _sd("f2.geglu", _shapes(U.GEGLU(640, 2560))).items()}
+    check("geglu", orc.geglu(orc.linear(sd, "g.proj", synth.normal("f2.geglu.x", (1, 64, 640), seed))))
+    sd = {"t." + k: v for k, v in _sd("f2.xfmr", _shapes(U.SpatialTransformer(640, 1, 64, 2048, 32))).items()}
+    check("xfmr", orc.spatial_transformer(sd, "t", synth.normal("f2.xfmr.x", (1, 640, 16, 16), seed),
+                                          synth.normal("f2.xfmr.ctx", (1, 77, 2048), seed)))
+    tt = torch.tensor([999.0, 500.0, 1.0, 1024.0, 0.0])
+    check("timesteps320", orc.timestep_features(tt, 320))
+    check("timesteps256", orc.timestep_features(tt, 256))
+    for c, eps in ((320, 1e-5), (640, 1e-6), (960, 1e-5), (1280, 1e-6), (1920, 1e-5), (2560, 1e-5)):
+        sd = {"n.weight": synth.param_tensor(f"f2.gn{c}.weight", (c,), 0), "n.bias": synth.param_tensor(f"f2.gn{c}.bias", (c,), 0)}
+        check(f"gn{c}", orc.group_norm(sd, "n", synth.normal(f"f2.gn{c}.x", (1, c, 8, 8), seed), eps))
+
+
+@pytest.fixture(scope="module")
+def sdxl_state_dict():
+    with torch.device("meta"):
+        m = UNet2DConditionModel(SDXL_BASE)
+    return synth.state_dict_for({k: tuple(v.shape) for k, v in m.state_dict().items()}, 0)
+
+
+@pytest.mark.slow
+def test_f1_unet_step_matches_reference(sdxl_state_dict):
+    """BASELINE config #1 (one eager CPU fp32 step at 512x512): oracle == reference output."""
+    ref = torch.from_numpy(golden("f1_unet_step_latent64")["out"])
+    x = synth.denoise_inputs(1, 64, 1234)
+    with torch.no_grad():
+        out = orc.unet_forward(sdxl_state_dict, x["latent"], torch.tensor(999.0), x["encoder_hidden_states"],
+                               x["text_embeds"], x["time_ids"])
+    assert torch.equal(out, ref), f"max diff {float((out - ref).abs().max()):.3e}"
+
+
+@pytest.mark.slow
+def test_f3_first_step_matches_reference_trace(sdxl_state_dict):
+    """The stored 50-step trajectory starts with the same epsilon the oracle predicts
+    (the full loop is replayed on the GPU by tests/test_unet_gpu.py)."""
+    g = golden("f3_euler50_latent64")
+    tables = euler_discrete_tables(50)
+    x = synth.denoise_inputs(1, 64, 1234)
+    lat = x["latent"] * tables.init_noise_sigma
+    with torch.no_grad():
+        eps = orc.unet_forward(sdxl_state_dict, lat * float(tables.in_scale()[0]), torch.tensor(float(tables.timesteps[0])),
+                               x["encoder_hidden_states"], x["text_embeds"], x["time_ids"])
+    assert abs(float(eps.abs().mean()) - float(g["eps_abs_mean"][0])) < 1e-6
