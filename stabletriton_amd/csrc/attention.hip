@@ -16,6 +16,24 @@
 // fp32 kernel ("strict" parity mode): plain FMA online softmax, one query row
 // per thread.
 #include "common.h"
+#include <stdlib.h>
+
+#ifdef ST_PROBE
+static unsigned long long* g_att_probe = nullptr;
+extern "C" void st_debug_set_att_probe(void* p) { g_att_probe = (unsigned long long*)p; }
+__device__ __forceinline__ unsigned long long att_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define AP_STAMP(v) unsigned long long v = att_now();
+#define AP_ADD(a, t1, t0) a += (t1) - (t0);
+#else
+#define AP_STAMP(v)
+#define AP_ADD(a, t1, t0)
+#endif
 
 static constexpr int ATT_D = 64;
 static constexpr int ATT_KV = 64;          // keys per tile
@@ -25,18 +43,29 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 typedef __attribute__((address_space(3))) const char lds_cchar;
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(lds_cchar*)p; }
 
-// four transposed 4x16 block reads (ds_read_b64_tr_b16) issued back to back, one wait
-__device__ __forceinline__ void lds_read_tr16_x4(const void* p0, const void* p1, const void* p2, const void* p3,
-                                                 u32x2& r0, u32x2& r1, u32x2& r2, u32x2& r3) {
-    asm volatile(
-        "ds_read_b64_tr_b16 %0, %4\n\t"
-        "ds_read_b64_tr_b16 %1, %5\n\t"
-        "ds_read_b64_tr_b16 %2, %6\n\t"
-        "ds_read_b64_tr_b16 %3, %7\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-        : "v"(lds_addr(p0)), "v"(lds_addr(p1)), "v"(lds_addr(p2)), "v"(lds_addr(p3))
-        : "memory");
+// All sixteen transposed 4x16 block reads (ds_read_b64_tr_b16) of one 64-key V tile: two lane base
+// addresses (d-block 0 / 1), the (k-step, key-half) position is an immediate offset.  Issued without
+// a wait so the softmax VALU work runs under the LDS latency; v_tile_wait() retires them and pins
+// every destination register behind the wait (cdna guide 5.7 form ii).
+struct VTile { u32x2 r[4][2][2]; };      // [k-step s][d-block][key-half n]
+
+__device__ __forceinline__ void v_tile_issue(VTile& v, unsigned base0, unsigned base1) {
+#define TR(dst, base, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #off : "=v"(dst) : "v"(base))
+    TR(v.r[0][0][0], base0, 0);    TR(v.r[0][0][1], base0, 1024); TR(v.r[0][1][0], base1, 0);    TR(v.r[0][1][1], base1, 1024);
+    TR(v.r[1][0][0], base0, 2048); TR(v.r[1][0][1], base0, 3072); TR(v.r[1][1][0], base1, 2048); TR(v.r[1][1][1], base1, 3072);
+    TR(v.r[2][0][0], base0, 4096); TR(v.r[2][0][1], base0, 5120); TR(v.r[2][1][0], base1, 4096); TR(v.r[2][1][1], base1, 5120);
+    TR(v.r[3][0][0], base0, 6144); TR(v.r[3][0][1], base0, 7168); TR(v.r[3][1][0], base1, 6144); TR(v.r[3][1][1], base1, 7168);
+#undef TR
+}
+
+__device__ __forceinline__ void v_tile_wait(VTile& v) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(v.r[0][0][0]), "+v"(v.r[0][0][1]), "+v"(v.r[0][1][0]), "+v"(v.r[0][1][1]),
+                   "+v"(v.r[1][0][0]), "+v"(v.r[1][0][1]), "+v"(v.r[1][1][0]), "+v"(v.r[1][1][1]),
+                   "+v"(v.r[2][0][0]), "+v"(v.r[2][0][1]), "+v"(v.r[2][1][0]), "+v"(v.r[2][1][1]),
+                   "+v"(v.r[3][0][0]), "+v"(v.r[3][0][1]), "+v"(v.r[3][1][0]), "+v"(v.r[3][1][1])
+                 :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 __device__ __forceinline__ int swz_k(int row) { return (row >> 1) & 7; }
@@ -45,7 +74,8 @@ __device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 1) << 2; }
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                             const bf16* __restrict__ V, bf16* __restrict__ O,
-                                                            int T, int S, long ldq, long ldk, long ldv, long ldo, float scale_log2e) {
+                                                            int T, int S, long ldq, long ldk, long ldv, long ldo, float scale_log2e,
+                                                            unsigned long long* probe) {
     constexpr int NT = NW * 64;
     constexpr int TILE_B = ATT_KV * 128;                 // bytes of one K (or V) tile image
     constexpr int IT = (ATT_KV * 8) / NT;                // 16-byte chunks per thread per image
@@ -101,23 +131,43 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restri
     store_tile(0);
     __syncthreads();
 
+#ifdef ST_PROBE
+    unsigned long long pa = 0, pb_ = 0, pc = 0, pd = 0;
+#endif
     for (int kt = 0; kt < nkt; ++kt) {
+        AP_STAMP(t0)
         const int cur = kt & 1;
         if (kt + 1 < nkt) load_tile(kt + 1);
         const char* kb = lds + cur * 2 * TILE_B;
         const char* vb = kb + TILE_B;
 
-        // ---- S^T = K Q^T for 64 keys x 32 queries ----
-        f32x16 s0 = {0}, s1 = {0};
+        // ---- S^T = K Q^T for 64 keys x 32 queries: all eight K fragments are read up front ----
+        bf16x8 kf0[4], kf1[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int c = 2 * ks + h;
             const int ra = r32, rb = 32 + r32;
-            bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kb + ra * 128 + ((c ^ swz_k(ra)) << 4));
-            bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kb + rb * 128 + ((c ^ swz_k(rb)) << 4));
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ks], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ks], s1, 0, 0, 0);
+            kf0[ks] = *reinterpret_cast<const bf16x8*>(kb + ra * 128 + ((c ^ swz_k(ra)) << 4));
+            kf1[ks] = *reinterpret_cast<const bf16x8*>(kb + rb * 128 + ((c ^ swz_k(rb)) << 4));
         }
+        f32x16 s0 = {0}, s1 = {0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], s1, 0, 0, 0);
+        }
+        // V^T fragments for the whole tile start now and land under the softmax arithmetic.
+        // Lane (4q'+p' of its 16-lane group) addresses row q' of each 4-key block; the row's
+        // swizzle term depends only on q' (the block bases 16s + 8n + 4h are multiples of 4).
+        VTile vt;
+        {
+            const int q4 = (lane & 15) >> 2;
+            const int key = 4 * h + q4;
+            const int ch0 = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+            const unsigned row = lds_addr(vb) + key * 128 + 8 * (lane & 1);
+            v_tile_issue(vt, row + ((ch0 ^ swz_v(key)) << 4), row + (((ch0 + 4) ^ swz_v(key)) << 4));
+        }
+        AP_STAMP(t1)
         // mask the tail keys (only the last tile can have any)
         if ((kt + 1) * ATT_KV > S) {
             const int kbase = kt * ATT_KV + 4 * h;
@@ -136,8 +186,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restri
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m, mx * scale_log2e);
-        const float alpha = fast_exp2(m - m_new);
-        m = m_new;
         float rs = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -145,34 +193,42 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restri
             s1[r] = fast_exp2(fmaf(s1[r], scale_log2e, -m_new));
             rs += s0[r] + s1[r];
         }
-        l = l * alpha + rs;
+        // rescale only when some row's running max moved (exact: alpha == 1 otherwise)
+        if (__any(m_new != m)) {
+            const float alpha = fast_exp2(m - m_new);
+            l *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            m = m_new;
+        }
+        l += rs;
 
+        AP_STAMP(t2)
         // ---- O^T += V^T P^T ; k-step s covers keys 16s .. 16s+15 of the tile ----
+        v_tile_wait(vt);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             bf16x8 pb;
 #pragma unroll
             for (int j = 0; j < 8; ++j) pb[j] = (bf16)((s < 2) ? s0[8 * (s & 1) + j] : s1[8 * (s & 1) + j]);
-            const int q4 = (lane & 15) >> 2;
-            const int key0 = 16 * s + 4 * h + q4, key1 = key0 + 8;
-            const int sub = 8 * (lane & 1);
-            const int ch0 = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1), ch1 = ch0 + 4;
-            const char* row0 = vb + key0 * 128 + sub;
-            const char* row1 = vb + key1 * 128 + sub;
-            u32x2 lo0, hi0, lo1, hi1;
-            lds_read_tr16_x4(row0 + ((ch0 ^ swz_v(key0)) << 4), row1 + ((ch0 ^ swz_v(key1)) << 4),
-                             row0 + ((ch1 ^ swz_v(key0)) << 4), row1 + ((ch1 ^ swz_v(key1)) << 4), lo0, hi0, lo1, hi1);
-            u32x4 w0 = {lo0[0], lo0[1], hi0[0], hi0[1]};
-            u32x4 w1 = {lo1[0], lo1[1], hi1[0], hi1[1]};
+            u32x4 w0 = {vt.r[s][0][0][0], vt.r[s][0][0][1], vt.r[s][0][1][0], vt.r[s][0][1][1]};
+            u32x4 w1 = {vt.r[s][1][0][0], vt.r[s][1][0][1], vt.r[s][1][1][0], vt.r[s][1][1][1]};
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), pb, o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1), pb, o1, 0, 0, 0);
         }
 
+        AP_STAMP(t3)
         if (kt + 1 < nkt) store_tile(cur ^ 1);
         __syncthreads();
+        AP_STAMP(t4)
+        AP_ADD(pa, t1, t0) AP_ADD(pb_, t2, t1) AP_ADD(pc, t3, t2) AP_ADD(pd, t4, t3)
     }
+#ifdef ST_PROBE
+    if (probe && lane == 0) {
+        unsigned long long* o = probe + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW * 8 + wave * 8;
+        o[0] = pa; o[1] = pb_; o[2] = pc; o[3] = pd; o[4] = nkt;
+    }
+#endif
 
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
@@ -261,6 +317,12 @@ __global__ __launch_bounds__(128) void attn_f32_kernel(const float* __restrict__
     }
 }
 
+#ifdef ST_PROBE
+#define ATT_PROBE_ARG g_att_probe
+#else
+#define ATT_PROBE_ARG nullptr
+#endif
+
 extern "C" int st_attention(const void* q, const void* k, const void* v, void* out, int B, int T, int S, int H, int D,
                             long ldq, long ldk, long ldv, long ldo, float scale, int dtype, void* stream) {
     ST_REQUIRE(q && k && v && out, "attention: null pointer");
@@ -273,14 +335,25 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ST_BF16) {
         const float c = scale * 1.4426950408889634f;
-        // 4 waves (128 rows) per block unless that leaves CUs idle
-        const long blocks4 = (long)cdiv(T, 128) * H * B;
-        if (blocks4 >= 256)
+        // waves (32 query rows each) per block: fewer rows per block = more blocks to spread over
+        // the 256 CUs and to co-schedule (MFMA of one wave under the softmax VALU of another)
+        static const int force_nw = [] { const char* e = getenv("ST_ATT_NW"); return e ? atoi(e) : 0; }();
+        // measured (tools/op_bench.py): the loop is latency-bound, so the K/V staging shared by more
+        // waves wins over more blocks; 8 waves once that still leaves >= 128 blocks, else 4
+        int nw = ((long)cdiv(T, 256) * H * B >= 128 && S > 256) ? 8 : 4;
+        if (force_nw == 1 || force_nw == 2 || force_nw == 4 || force_nw == 8) nw = force_nw;
+        if (nw == 8)
+            hipLaunchKernelGGL(attn_bf16_kernel<8>, dim3(cdiv(T, 256), H, B), dim3(512), 0, st, (const bf16*)q, (const bf16*)k,
+                               (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c, ATT_PROBE_ARG);
+        else if (nw == 4)
             hipLaunchKernelGGL(attn_bf16_kernel<4>, dim3(cdiv(T, 128), H, B), dim3(256), 0, st, (const bf16*)q, (const bf16*)k,
-                               (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c);
-        else
+                               (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c, ATT_PROBE_ARG);
+        else if (nw == 2)
             hipLaunchKernelGGL(attn_bf16_kernel<2>, dim3(cdiv(T, 64), H, B), dim3(128), 0, st, (const bf16*)q, (const bf16*)k,
-                               (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c);
+                               (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c, ATT_PROBE_ARG);
+        else
+            hipLaunchKernelGGL(attn_bf16_kernel<1>, dim3(cdiv(T, 32), H, B), dim3(64), 0, st, (const bf16*)q, (const bf16*)k,
+                               (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c, ATT_PROBE_ARG);
     } else if (dtype == ST_F32) {
         hipLaunchKernelGGL(attn_f32_kernel, dim3(cdiv(T, 128), H, B), dim3(128), 0, st, (const float*)q, (const float*)k,
                            (const float*)v, (float*)out, T, S, ldq, ldk, ldv, ldo, scale);

@@ -602,7 +602,7 @@ static void launch_dma(const GemmArgs& a, hipStream_t st) {
 // overrides the heuristic for A/B runs.
 enum { CFG_64x64_S4 = 0, CFG_64x64_S8 = 1, CFG_64x64_S4_U2 = 2, CFG_128x64_S4 = 3, CFG_128x64_S3_U2 = 4,
        CFG_128x128_S3 = 5, CFG_64x64_S3 = 6, CFG_64x64_W8 = 7, CFG_128x64_W8 = 8, CFG_128x128_W8 = 9,
-       CFG_64x128_W8 = 10, CFG_COUNT };
+       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_COUNT };
 
 static int forced_cfg() {
     static int v = [] { const char* e = getenv("ST_GEMM_FORCE"); return e ? atoi(e) : -1; }();
@@ -644,7 +644,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
         }
         const int f = forced_cfg();
         if (f >= 0 && f < CFG_COUNT) {
-            const bool u2 = (f == CFG_64x64_S4_U2 || f == CFG_128x64_S3_U2);
+            const bool u2 = (f == CFG_64x64_S4_U2 || f == CFG_128x64_S3_U2 || f == CFG_64x128_W8_U2 || f == CFG_128x64_W8_U2 || f == CFG_64x64_W8_U2);
             if (!u2 || even2) cfg = f;
         }
         switch (cfg) {
@@ -658,6 +658,13 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             case CFG_64x64_W8: launch_dma<T, 64, 64, 4, 2, 4, 1, CONV>(a, st); break;
             case CFG_128x64_W8: launch_dma<T, 128, 64, 4, 2, 4, 1, CONV>(a, st); break;
             case CFG_64x128_W8: launch_dma<T, 64, 128, 2, 4, 4, 1, CONV>(a, st); break;
+            case CFG_64x128_W8_S6: launch_dma<T, 64, 128, 2, 4, 6, 1, CONV>(a, st); break;
+            case CFG_128x64_W8_S6: launch_dma<T, 128, 64, 4, 2, 6, 1, CONV>(a, st); break;
+            case CFG_128x128_W8_S4: launch_dma<T, 128, 128, 2, 4, 4, 1, CONV>(a, st); break;
+            case CFG_64x64_W8_S8: launch_dma<T, 64, 64, 4, 2, 8, 1, CONV>(a, st); break;
+            case CFG_64x128_W8_U2: launch_dma<T, 64, 128, 2, 4, 3, 2, CONV>(a, st); break;
+            case CFG_128x64_W8_U2: launch_dma<T, 128, 64, 4, 2, 3, 2, CONV>(a, st); break;
+            case CFG_64x64_W8_U2: launch_dma<T, 64, 64, 4, 2, 4, 2, CONV>(a, st); break;
             default: launch_dma<T, 128, 128, 2, 4, 3, 1, CONV>(a, st); break;
         }
         return st_check_launch(who);

@@ -42,9 +42,18 @@ def linear():
               (4096, 640, 640, 70, 0), (4096, 640, 5120 // 2, 10, 1), (4096, 2560, 640, 10, 0),
               (77, 2048, 1280, 120, 0), (77, 2048, 640, 20, 0), (1, 1280, 1280, 9, 0), (1024, 1280, 3840, 0, 0)]
     tot = 0.0
+    cold = os.environ.get("COLD", "1") == "1"
     for M, K, N, cnt, geglu in shapes:
-        x, w, b = rnd(M, K), rnd((2 * N if geglu else N), K) * K ** -0.5, rnd(2 * N if geglu else N)
-        us = timeit(lambda: ops.linear(x, w, b, geglu=bool(geglu)))
+        x, b = rnd(M, K), rnd(2 * N if geglu else N)
+        nrows = 2 * N if geglu else N
+        ncopy = max(1, min(64, int(600e6 // (nrows * K * 2)))) if cold else 1     # > 256 MiB of weights: no cache reuse
+        ws = [rnd(nrows, K) * K ** -0.5 for _ in range(ncopy)]
+        it = [0]
+
+        def call():
+            it[0] += 1
+            return ops.linear(x, ws[it[0] % ncopy], b, geglu=bool(geglu))
+        us = timeit(call, iters=max(20, ncopy))
         fl = 2.0 * M * K * (2 * N if geglu else N)
         tot += us * cnt
         print(f"linear M={M:5d} K={K:5d} N={N:5d} geglu={geglu}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s  x{cnt} = {us * cnt / 1e3:6.2f} ms")
