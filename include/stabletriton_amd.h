@@ -71,11 +71,14 @@ int st_geglu(const void* state, const void* gate, void* out, int rows, int F,
  * kernels/linear.py:173-222).  W is (N,K) row-major exactly as nn.Linear
  * stores it.  lda/ldc/ldr are row strides in elements.  With ST_EPI_GEGLU,
  * W has 2N rows and y has N columns.  rows_per_batch is only read with
- * ST_EPI_ROWBIAS (rowbias is (M/rows_per_batch, N) contiguous). */
+ * ST_EPI_ROWBIAS (rowbias is (M/rows_per_batch, N) contiguous).
+ * `workspace` (may be NULL) is caller-owned scratch of `workspace_bytes` bytes: when
+ * present, long-K problems with few output tiles are split over K into fp32 slabs
+ * there and reduced in a fixed order by a second launch (bit-reproducible). */
 int st_linear(const void* x, const void* W, const void* bias, const void* residual,
               const void* rowbias, void* y, int M, int N, int K,
               long lda, long ldc, long ldr, int rows_per_batch,
-              int epilogue, int dtype, void* stream);
+              int epilogue, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Fused attention core: out = softmax(q k^T * scale) v per head, no mask.
  * Replaces attention_wrapper (optimizers/replace_attention.py:60-68); inputs
@@ -92,11 +95,11 @@ int st_attention(const void* q, const void* k, const void* v, void* out,
  * to cuDNN (optimizations.txt:5).  `upsample2x` folds a nearest 2x upsample of
  * the input into the gather (unet_pt.py:264-266).  Epilogue flags as for
  * st_linear; rowbias is (N_batch, Cout) (the time-embedding projection,
- * unet_pt.py:82-83), residual is NHWC (N,Hout,Wout,Cout). */
+ * unet_pt.py:82-83), residual is NHWC (N,Hout,Wout,Cout).  workspace: as st_linear. */
 int st_conv2d(const void* x, const void* W, const void* bias, const void* residual,
               const void* rowbias, void* y, int N, int Hin, int Win, int Cin,
               int Cout, int R, int S, int stride, int pad, int upsample2x,
-              int epilogue, int dtype, void* stream);
+              int epilogue, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Euler-discrete update of the fp32 latent and preparation of the next UNet
  * input (restated diffusers EulerDiscreteScheduler, see

@@ -23,6 +23,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
 
 
 def lib_path() -> str:
+    # ST_LIB_VARIANT=<dir under lib/> selects an alternative build (developer A/B runs only)
+    variant = os.environ.get("ST_LIB_VARIANT")
+    if variant:
+        return os.path.join(LIBDIR, variant, LIBNAME)
     return os.path.join(LIBDIR, LIBNAME)
 
 

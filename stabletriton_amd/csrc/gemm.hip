@@ -13,6 +13,7 @@
 // one row and the epilogue stores 8/16 contiguous bytes per lane.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct GemmArgs {
     const void* A; const void* W; const void* bias; const void* residual; const void* rowbias; void* C;
@@ -22,6 +23,9 @@ struct GemmArgs {
     int epi;
     // implicit-GEMM conv geometry (unused for dense)
     int Hin, Win, Cin, Hout, Wout, S, stride, pad, ups;
+    int splitk;                  // K slices (1 = none); slices write fp32 slabs to `partial`, a second pass reduces
+    float* partial;
+    size_t partial_bytes;
     unsigned long long* probe;   // diagnostic builds only (-DST_PROBE): per-wave phase cycle sums
 };
 
@@ -68,16 +72,73 @@ template <> struct Out4<float> {
     }
 };
 
-// ---- shared epilogue: lane (r16, q) holds rows m = .. + r16, columns n = .. + 4q .. 4q+3 ----
-template <typename T, int TM, int TN, int WTM, int WTN, bool GEGLU>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
-                                              int r16, int q) {
+// ---- shared epilogue ---------------------------------------------------------------------------
+// One output row m, 4 consecutive columns n..n+3: v = accumulators (value half), g = gate half (GEGLU).
+template <typename T, bool GEGLU>
+__device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n, float (&v)[4], const float (&g_in)[4]) {
     T* __restrict__ Cp = (T*)p.C;
     const T* __restrict__ bias = (const T*)p.bias;
     const T* __restrict__ Rp = (const T*)p.residual;
     const T* __restrict__ RBp = (const T*)p.rowbias;
+    const bool full = (n + 3 < p.N);
+    if (p.epi & ST_EPI_BIAS) {
+        if (full) { float b4[4]; Out4<T>::load(bias + n, b4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += b4[e];
+        } else {
+            for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(bias[n + e]);
+        }
+    }
+    if (GEGLU) {
+        float g[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = g_in[e];
+        if (p.epi & ST_EPI_BIAS) {
+            if (full) { float b4[4]; Out4<T>::load(bias + p.N + n, b4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] += b4[e];
+            } else {
+                for (int e = 0; e < 4 && n + e < p.N; ++e) g[e] += Elem<T>::to_f(bias[p.N + n + e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_f(g[e]);
+    }
+    if (p.epi & ST_EPI_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+    }
+    if (p.epi & ST_EPI_ROWBIAS) {
+        const T* rb = RBp + (size_t)(m / p.rows_per_batch) * p.N + n;
+        if (full) { float b4[4]; Out4<T>::load(rb, b4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += b4[e];
+        } else {
+            for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(rb[e]);
+        }
+    }
+    if (p.epi & ST_EPI_RESIDUAL) {
+        const T* rr = Rp + (size_t)m * p.ldr + n;
+        if (full) { float b4[4]; Out4<T>::load(rr, b4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += b4[e];
+        } else {
+            for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(rr[e]);
+        }
+    }
+    T* dst = Cp + (size_t)m * p.ldc + n;
+    if (full) Out4<T>::store(dst, v);
+    else for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = Elem<T>::from_f(v[e]);
+}
+
+// lane (r16, q) holds rows m = .. + r16, columns n = .. + 4q .. 4q+3 of every 16x16 tile.
+// With split-K (p.splitk > 1) the raw fp32 sums go to the partial slab of this K slice instead.
+template <typename T, int TM, int TN, int WTM, int WTN, bool GEGLU>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                              int r16, int q, int split = 0) {
     constexpr int TNO = GEGLU ? TN / 2 : TN;
     constexpr int WTNO = GEGLU ? WTN / 2 : WTN;
+    const int ncols = GEGLU ? 2 * p.N : p.N;          // columns of one partial slab
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * WTM + i * 16 + r16;
@@ -86,60 +147,52 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
         for (int j = 0; j < TNO; ++j) {
             const int n = n0 + wn * WTNO + j * 16 + 4 * q;
             if (n >= p.N) continue;
-            float v[4];
+            float v[4], g[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
-            const bool full = (n + 3 < p.N);
-            if (p.epi & ST_EPI_BIAS) {
-                if (full) { float b4[4]; Out4<T>::load(bias + n, b4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += b4[e];
-                } else {
-                    for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(bias[n + e]);
-                }
-            }
             if (GEGLU) {
-                float g[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = acc[i][j + TN / 2][e];
-                if (p.epi & ST_EPI_BIAS) {
-                    if (full) { float b4[4]; Out4<T>::load(bias + p.N + n, b4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) g[e] += b4[e];
-                    } else {
-                        for (int e = 0; e < 4 && n + e < p.N; ++e) g[e] += Elem<T>::to_f(bias[p.N + n + e]);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_f(g[e]);
+                for (int e = 0; e < 4; ++e) g[e] = acc[i][j + (GEGLU ? TN / 2 : 0)][e];
             }
-            if (p.epi & ST_EPI_SILU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-            }
-            if (p.epi & ST_EPI_ROWBIAS) {
-                const T* rb = RBp + (size_t)(m / p.rows_per_batch) * p.N + n;
-                if (full) { float b4[4]; Out4<T>::load(rb, b4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += b4[e];
+            if (p.splitk > 1) {
+                float* slab = p.partial + ((size_t)split * p.M + m) * ncols;
+                if (n + 3 < p.N) {
+                    Out4<float>::store(slab + n, v);
+                    if (GEGLU) Out4<float>::store(slab + p.N + n, g);
                 } else {
-                    for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(rb[e]);
+                    for (int e = 0; e < 4 && n + e < p.N; ++e) { slab[n + e] = v[e]; if (GEGLU) slab[p.N + n + e] = g[e]; }
                 }
+            } else {
+                epilogue_store4<T, GEGLU>(p, m, n, v, g);
             }
-            if (p.epi & ST_EPI_RESIDUAL) {
-                const T* rr = Rp + (size_t)m * p.ldr + n;
-                if (full) { float b4[4]; Out4<T>::load(rr, b4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += b4[e];
-                } else {
-                    for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(rr[e]);
-                }
-            }
-            T* dst = Cp + (size_t)m * p.ldc + n;
-            if (full) Out4<T>::store(dst, v);
-            else for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = Elem<T>::from_f(v[e]);
         }
     }
+}
+
+// split-K second pass: sum the K-slice slabs in a fixed order, then the normal epilogue.
+template <typename T, bool GEGLU>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
+    const int n4 = (p.N + 3) / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)p.M * n4) return;
+    const int m = (int)(idx / n4), n = (int)(idx - (long)m * n4) * 4;
+    const int ncols = GEGLU ? 2 * p.N : p.N;
+    float v[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool full = n + 3 < p.N;
+    for (int s_ = 0; s_ < p.splitk; ++s_) {
+        const float* slab = p.partial + ((size_t)s_ * p.M + m) * ncols;
+        if (full) {
+            float t[4]; Out4<float>::load(slab + n, t);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += t[e];
+            if (GEGLU) { Out4<float>::load(slab + p.N + n, t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] += t[e]; }
+        } else {
+            for (int e = 0; e < 4 && n + e < p.N; ++e) { v[e] += slab[n + e]; if (GEGLU) g[e] += slab[p.N + n + e]; }
+        }
+    }
+    epilogue_store4<T, GEGLU>(p, m, n, v, g);
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, bool CONV, bool GEGLU>
@@ -330,6 +383,12 @@ constexpr int dma_before_last_group(int G, int NG) {
     return n;
 }
 
+constexpr int dma_in_group(int G, int NG, int g) {
+    int n = 0;
+    for (int e = 0; e < G; ++e) n += (e * NG / G == g) ? 1 : 0;
+    return n;
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -363,7 +422,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     constexpr int G = (A_IT + B_IT) * U;                         // DMA instructions per wave per stage
     constexpr int A_BYTES = BM * 128, TILE = (BM + BN) * 128, STAGE = TILE * U;   // a stage = U consecutive K tiles
     static_assert(!GEGLU || (TN % 2 == 0), "GEGLU pairs value/gate n-tiles inside one wave");
-    static_assert(STAGES >= 3, "the last DMA share of a stage is issued after the barrier: needs >= 3 buffers");
     static_assert((STAGES - 2) * G <= 63, "vmcnt immediate");
     typedef typename Mma<T>::Frag Frag;
 
@@ -378,9 +436,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
     const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const int tile_n = wg / tiles_m, tile_m = wg - tile_n * tiles_m;
-    const int m0 = tile_m * BM;
     constexpr int BNO = GEGLU ? BN / 2 : BN;
+    // split-K: slice-major block order, so the blocks that run together share one K range
+    const int ntile = nblk / p.splitk;
+    const int split = wg / ntile, tw = wg - split * ntile;
+    const int tile_n = tw / tiles_m, tile_m = tw - tile_n * tiles_m;
+    const int m0 = tile_m * BM;
     const int n0 = tile_n * BNO;
 
     const T* __restrict__ Ap = (const T*)p.A;
@@ -433,13 +494,17 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         b_adv[i] = ok ? KB : 0;
     }
 
+    // K range of this block in stages (host guarantees K % (KB*U) == 0); split-K slices are balanced
+    const int nk_all = p.K / (KB * U);
+    const int nk_lo = (int)((long)split * nk_all / p.splitk), nk_hi = (int)((long)(split + 1) * nk_all / p.splitk);
+    const int kbase = nk_lo * U;
     // DMA list of a stage: for each of its U tiles, A_IT activation pieces then B_IT weight pieces.
     // `issue_range` emits entries [lo, hi) so the loop can spread them between MFMA groups
     // (back-to-back DMAs serialise in the address unit while the matrix pipe idles).
     constexpr int PER_TILE = A_IT + B_IT;
     auto issue_one = [&](int st, int buf, int e) {
         const int u = e / PER_TILE, i = e - u * PER_TILE;
-        const int kt = st * U + u;
+        const int kt = kbase + st * U + u;
         char* base = lds + buf * STAGE + u * TILE;
         if (i < A_IT) {
             const T* src;
@@ -477,7 +542,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int r16 = lane & 15, q = lane >> 4;
-    const int nk = p.K / (KB * U);                // host guarantees K % (KB*U) == 0
+    const int nk = nk_hi - nk_lo;
 
 #pragma unroll
     for (int s_ = 0; s_ < STAGES - 1; ++s_)
@@ -489,6 +554,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     // the fragments of MFMA group g+1 are read while group g multiplies, and the LAST group
     // of a stage multiplies after the stage barrier, under the first reads of the next stage.
     constexpr int NG = 2 * U;                     // MFMA groups per stage (two 64-byte halves per K tile)
+    // with only two buffers the whole prefetch must be issued before the stage barrier (group 0)
+    constexpr bool EARLY = (STAGES == 2);
     Frag fa[2][TM], fb[2][TN];
     auto read_group = [&](int buf, int g, int set) {
         const char* sa = lds + buf * STAGE + (g >> 1) * TILE;
@@ -521,9 +588,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     for (int kt = 0; kt < nk; ++kt) {
         PROBE_STAMP(pr_i0)
         const int pf = min(kt + STAGES - 1, nk - 1);      // stage to prefetch (clamped)
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) {
+        auto group = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g + 1 < NG) {
                 read_group(cur, g + 1, (g + 1) & 1);
             } else {
                 // stage kt+1 must have landed (own DMAs), then everyone's; the barrier also retires
@@ -531,24 +598,48 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
                 PROBE_STAMP(pr_i1)
                 // in flight at this point: stages kt+2 .. kt+S-2 whole, plus the shares of stage
                 // kt+S-1 already issued by groups 0 .. NG-2 of this trip
-                wait_vmcnt<(STAGES - 3) * G + dma_before_last_group(G, NG)>();
+                wait_vmcnt<EARLY ? 0 : (STAGES - 3) * G + dma_before_last_group(G, NG)>();
                 PROBE_STAMP(pr_i2)
                 __builtin_amdgcn_s_barrier();
                 PROBE_STAMP(pr_i3)
                 PROBE_ADD(pr_a, pr_i1, pr_i0) PROBE_ADD(pr_b, pr_i2, pr_i1) PROBE_ADD(pr_c, pr_i3, pr_i2)
+                __builtin_amdgcn_sched_barrier(0);
                 read_group(cur + 1 == STAGES ? 0 : cur + 1, 0, (g + 1) & 1);
             }
+            constexpr int n_dma = EARLY ? (g == 0 ? G : 0) : dma_in_group(G, NG, g);
 #pragma unroll
             for (int e = 0; e < G; ++e)
-                if (e * NG / G == g) issue_one(pf, nxt, e);
+                if ((EARLY ? 0 : e * NG / G) == g) issue_one(pf, nxt, e);
             mma_group(g & 1);
+            // pin the emitted order of this group: fragment reads of the NEXT group first, then this
+            // group's DMA share, then this group's MFMAs (hipcc otherwise sinks the reads to just
+            // before their use and exposes the LDS latency in front of every MFMA cluster)
+#ifndef ST_NO_PIN
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            if constexpr (n_dma > 0) __builtin_amdgcn_sched_group_barrier(0x020, n_dma, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * (sizeof(T) == 4 ? 4 : 1), 0);
+            __builtin_amdgcn_sched_barrier(0);
+#else
+            (void)n_dma;
+#endif
+        };
+        group(std::integral_constant<int, 0>{});
+        group(std::integral_constant<int, 1>{});
+        if constexpr (NG > 2) {
+            group(std::integral_constant<int, 2>{});
+            group(std::integral_constant<int, 3>{});
         }
+        // the prefetched first fragments of the next stage have had a whole MFMA group to land: retire
+        // them here so the compiler enters the next trip with an empty LDS scoreboard (exact waits)
+#ifndef ST_NO_PIN
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+#endif
         cur = cur + 1 == STAGES ? 0 : cur + 1;
         nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
     }
     wait_vmcnt<0>();                              // no LDS-DMA may outlive the workgroup's LDS allocation
     PROBE_STAMP(pr_end)
-    gemm_epilogue<T, TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wm, wn, r16, q);
+    gemm_epilogue<T, TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wm, wn, r16, q, split);
 #ifdef ST_PROBE
     {
         PROBE_STAMP(pr_fin)
@@ -583,26 +674,30 @@ template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool 
 static void launch_dma(const GemmArgs& a, hipStream_t st) {
     const size_t lds = (size_t)STAGES * U * (BM + BN) * 128;
     const int tiles_m = cdiv(a.M, BM);
+    const int sk = a.splitk > 1 ? a.splitk : 1;
+    const int red_blocks = cdiv((long)a.M * ((a.N + 3) / 4), 256);
     if constexpr (!CONV) {
         if (a.epi & ST_EPI_GEGLU) {
             auto kfn = gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, U, CONV, true>;
             static bool once = (allow_big_lds(kfn, lds), true);
             (void)once;
-            hipLaunchKernelGGL(kfn, dim3(tiles_m * cdiv(a.N, BN / 2)), dim3(WGM * WGN * 64), lds, st, a);
+            hipLaunchKernelGGL(kfn, dim3(tiles_m * cdiv(a.N, BN / 2) * sk), dim3(WGM * WGN * 64), lds, st, a);
+            if (sk > 1) hipLaunchKernelGGL((splitk_reduce_kernel<T, true>), dim3(red_blocks), dim3(256), 0, st, a);
             return;
         }
     }
     auto kfn = gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, U, CONV, false>;
     static bool once = (allow_big_lds(kfn, lds), true);
     (void)once;
-    hipLaunchKernelGGL(kfn, dim3(tiles_m * cdiv(a.N, BN)), dim3(WGM * WGN * 64), lds, st, a);
+    hipLaunchKernelGGL(kfn, dim3(tiles_m * cdiv(a.N, BN) * sk), dim3(WGM * WGN * 64), lds, st, a);
+    if (sk > 1) hipLaunchKernelGGL((splitk_reduce_kernel<T, false>), dim3(red_blocks), dim3(256), 0, st, a);
 }
 
 // Tile configurations of the LDS-DMA kernel.  ST_GEMM_FORCE=<id> (developer knob)
 // overrides the heuristic for A/B runs.
 enum { CFG_64x64_S4 = 0, CFG_64x64_S8 = 1, CFG_64x64_S4_U2 = 2, CFG_128x64_S4 = 3, CFG_128x64_S3_U2 = 4,
        CFG_128x128_S3 = 5, CFG_64x64_S3 = 6, CFG_64x64_W8 = 7, CFG_128x64_W8 = 8, CFG_128x128_W8 = 9,
-       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_COUNT };
+       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_COUNT };
 
 static int forced_cfg() {
     static int v = [] { const char* e = getenv("ST_GEMM_FORCE"); return e ? atoi(e) : -1; }();
@@ -642,30 +737,52 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             const double cost = rounds * ((ta > mf ? ta : mf) + 150.0 + (CONV ? 0.5 * c.bm : 0.0));
             if (cost < best) { best = cost; cfg = c.cfg; }
         }
+        // split-K: long-K problems with too few output tiles to fill the chip (ff-out, the 32x32 / 64x64
+        // resnet convs) run the 256x128 tile over K slices; fp32 slabs go to the caller's workspace and a
+        // second pass reduces them in a fixed order (deterministic) and applies the epilogue.
+        GemmArgs b = a;
+        const int nk = a.K / KB;
+        const long ncols = (a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N;
+        static const int force_sk = [] { const char* e = getenv("ST_GEMM_SPLITK"); return e ? atoi(e) : -1; }();
+        int sk = 1;
+        if (a.partial && force_sk != 0) {
+            const long t = tiles(256, 128);
+            if (t <= 100 && nk >= 120) {        // measured: pays from K ~ 8k up (the wide resnet convs)
+                sk = (int)(256 / t);
+                if (sk > nk / 8) sk = nk / 8;
+            }
+            if (force_sk > 1) sk = force_sk;
+            while (sk > 1 && (size_t)sk * a.M * ncols * sizeof(float) > a.partial_bytes) --sk;
+            if (sk > nk) sk = nk;
+            if (sk > 1) { cfg = CFG_256x128_W8; b.splitk = sk; }
+        }
         const int f = forced_cfg();
         if (f >= 0 && f < CFG_COUNT) {
-            const bool u2 = (f == CFG_64x64_S4_U2 || f == CFG_128x64_S3_U2 || f == CFG_64x128_W8_U2 || f == CFG_128x64_W8_U2 || f == CFG_64x64_W8_U2);
+            const bool u2 = (f == CFG_64x64_S4_U2 || f == CFG_128x64_S3_U2 || f == CFG_64x128_W8_U2 || f == CFG_128x64_W8_U2 ||
+                             f == CFG_64x64_W8_U2);
             if (!u2 || even2) cfg = f;
         }
         switch (cfg) {
-            case CFG_64x64_S4: launch_dma<T, 64, 64, 2, 2, 4, 1, CONV>(a, st); break;
-            case CFG_64x64_S8: launch_dma<T, 64, 64, 2, 2, 8, 1, CONV>(a, st); break;
-            case CFG_64x64_S4_U2: launch_dma<T, 64, 64, 2, 2, 4, 2, CONV>(a, st); break;
-            case CFG_128x64_S4: launch_dma<T, 128, 64, 2, 2, 4, 1, CONV>(a, st); break;
-            case CFG_128x64_S3_U2: launch_dma<T, 128, 64, 2, 2, 3, 2, CONV>(a, st); break;
-            case CFG_128x128_S3: launch_dma<T, 128, 128, 2, 2, 3, 1, CONV>(a, st); break;
-            case CFG_64x64_S3: launch_dma<T, 64, 64, 2, 2, 3, 1, CONV>(a, st); break;
-            case CFG_64x64_W8: launch_dma<T, 64, 64, 4, 2, 4, 1, CONV>(a, st); break;
-            case CFG_128x64_W8: launch_dma<T, 128, 64, 4, 2, 4, 1, CONV>(a, st); break;
-            case CFG_64x128_W8: launch_dma<T, 64, 128, 2, 4, 4, 1, CONV>(a, st); break;
-            case CFG_64x128_W8_S6: launch_dma<T, 64, 128, 2, 4, 6, 1, CONV>(a, st); break;
-            case CFG_128x64_W8_S6: launch_dma<T, 128, 64, 4, 2, 6, 1, CONV>(a, st); break;
-            case CFG_128x128_W8_S4: launch_dma<T, 128, 128, 2, 4, 4, 1, CONV>(a, st); break;
-            case CFG_64x64_W8_S8: launch_dma<T, 64, 64, 4, 2, 8, 1, CONV>(a, st); break;
-            case CFG_64x128_W8_U2: launch_dma<T, 64, 128, 2, 4, 3, 2, CONV>(a, st); break;
-            case CFG_128x64_W8_U2: launch_dma<T, 128, 64, 4, 2, 3, 2, CONV>(a, st); break;
-            case CFG_64x64_W8_U2: launch_dma<T, 64, 64, 4, 2, 4, 2, CONV>(a, st); break;
-            default: launch_dma<T, 128, 128, 2, 4, 3, 1, CONV>(a, st); break;
+            case CFG_64x64_S4: launch_dma<T, 64, 64, 2, 2, 4, 1, CONV>(b, st); break;
+            case CFG_64x64_S8: launch_dma<T, 64, 64, 2, 2, 8, 1, CONV>(b, st); break;
+            case CFG_64x64_S4_U2: launch_dma<T, 64, 64, 2, 2, 4, 2, CONV>(b, st); break;
+            case CFG_128x64_S4: launch_dma<T, 128, 64, 2, 2, 4, 1, CONV>(b, st); break;
+            case CFG_128x64_S3_U2: launch_dma<T, 128, 64, 2, 2, 3, 2, CONV>(b, st); break;
+            case CFG_128x128_S3: launch_dma<T, 128, 128, 2, 2, 3, 1, CONV>(b, st); break;
+            case CFG_64x64_S3: launch_dma<T, 64, 64, 2, 2, 3, 1, CONV>(b, st); break;
+            case CFG_64x64_W8: launch_dma<T, 64, 64, 4, 2, 4, 1, CONV>(b, st); break;
+            case CFG_128x64_W8: launch_dma<T, 128, 64, 4, 2, 4, 1, CONV>(b, st); break;
+            case CFG_64x128_W8: launch_dma<T, 64, 128, 2, 4, 4, 1, CONV>(b, st); break;
+            case CFG_64x128_W8_S6: launch_dma<T, 64, 128, 2, 4, 6, 1, CONV>(b, st); break;
+            case CFG_128x64_W8_S6: launch_dma<T, 128, 64, 4, 2, 6, 1, CONV>(b, st); break;
+            case CFG_128x128_W8_S4: launch_dma<T, 128, 128, 2, 4, 4, 1, CONV>(b, st); break;
+            case CFG_64x64_W8_S8: launch_dma<T, 64, 64, 4, 2, 8, 1, CONV>(b, st); break;
+            case CFG_64x128_W8_U2: launch_dma<T, 64, 128, 2, 4, 3, 2, CONV>(b, st); break;
+            case CFG_128x64_W8_U2: launch_dma<T, 128, 64, 4, 2, 3, 2, CONV>(b, st); break;
+            case CFG_64x64_W8_U2: launch_dma<T, 64, 64, 4, 2, 4, 2, CONV>(b, st); break;
+            case CFG_256x256_W8: launch_dma<T, 256, 256, 2, 4, 2, 1, CONV>(b, st); break;
+            case CFG_256x128_W8: launch_dma<T, 256, 128, 4, 2, 3, 1, CONV>(b, st); break;
+            default: launch_dma<T, 128, 128, 2, 4, 3, 1, CONV>(b, st); break;
         }
         return st_check_launch(who);
     }
@@ -686,7 +803,7 @@ static int check_epilogue(const char* who, const GemmArgs& a) {
 
 extern "C" int st_linear(const void* x, const void* W, const void* bias, const void* residual, const void* rowbias, void* y,
                          int M, int N, int K, long lda, long ldc, long ldr, int rows_per_batch, int epilogue, int dtype,
-                         void* stream) {
+                         void* workspace, size_t workspace_bytes, void* stream) {
     ST_REQUIRE(x && W && y, "linear: null pointer");
     ST_REQUIRE(M > 0 && N > 0 && K > 0, "linear: bad shape M=%d N=%d K=%d", M, N, K);
     const int vec = dtype == ST_BF16 ? 8 : 4;
@@ -697,6 +814,7 @@ extern "C" int st_linear(const void* x, const void* W, const void* bias, const v
     GemmArgs a = {};
     a.A = x; a.W = W; a.bias = bias; a.residual = residual; a.rowbias = rowbias; a.C = y;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.rows_per_batch = rows_per_batch; a.epi = epilogue;
+    a.splitk = 1; a.partial = (float*)workspace; a.partial_bytes = workspace ? workspace_bytes : 0;
 #ifdef ST_PROBE
     a.probe = g_probe;
 #endif
@@ -782,7 +900,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GemmArgs p, int R)
 
 extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const void* residual, const void* rowbias, void* y,
                          int N, int Hin, int Win, int Cin, int Cout, int R, int S, int stride, int pad, int upsample2x,
-                         int epilogue, int dtype, void* stream) {
+                         int epilogue, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     ST_REQUIRE(x && W && y, "conv2d: null pointer");
     ST_REQUIRE(N > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0,
                "conv2d: bad geometry");
@@ -798,6 +916,7 @@ extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const v
     ST_REQUIRE(a.Hout > 0 && a.Wout > 0, "conv2d: empty output");
     a.M = N * a.Hout * a.Wout; a.N = Cout; a.K = R * S * Cin;
     a.lda = 0; a.ldc = Cout; a.ldr = Cout; a.rows_per_batch = a.Hout * a.Wout; a.epi = epilogue;
+    a.splitk = 1; a.partial = (float*)workspace; a.partial_bytes = workspace ? workspace_bytes : 0;
     if (int e = check_epilogue("conv2d", a)) return e;
     hipStream_t st = (hipStream_t)stream;
     const int kb = dtype == ST_BF16 ? 64 : 32;

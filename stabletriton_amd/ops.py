@@ -48,6 +48,21 @@ def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     return ws
 
 
+# split-K scratch for st_linear / st_conv2d: one fixed-size slab per device, allocated once and
+# never replaced (captured graphs keep its address); problems that would need more run unsplit.
+GEMM_WORKSPACE_BYTES = 192 << 20
+_gemm_ws = {}
+
+
+def _gemm_workspace(device: torch.device) -> torch.Tensor:
+    key = (device.type, device.index)
+    ws = _gemm_ws.get(key)
+    if ws is None:
+        ws = torch.empty(GEMM_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        _gemm_ws[key] = ws
+    return ws
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -162,9 +177,10 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
             raise BackendError("linear: residual must match the output shape and dtype")
         residual, _, ldr = _rows2d(residual)
         epi |= _C.EPI_RESIDUAL
+    gws = _gemm_workspace(x.device)
     _C.check(_timed("linear", 2.0 * M * w.shape[0] * K, float((M * K + w.numel() + M * N) * x.element_size()),
                     lib.st_linear, x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
-                           lda, N, ldr, 0, epi, _C.dtype_code(x.dtype), _C.stream_ptr()), "linear")
+                           lda, N, ldr, 0, epi, _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(), _C.stream_ptr()), "linear")
     return out
 
 
@@ -234,10 +250,11 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
         if not residual.is_contiguous(memory_format=torch.channels_last):
             residual = residual.contiguous(memory_format=torch.channels_last)
         epi |= _C.EPI_RESIDUAL
+    gws = _gemm_workspace(x.device)
     _C.check(_timed("conv2d", 2.0 * N * Ho * Wo * Cout * R * S * Cin,
                     float((x.numel() + w.numel() + out.numel()) * x.element_size()), lib.st_conv2d, x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(rowbias), out.data_ptr(),
                            N, H, W, Cin, Cout, R, S, stride, padding, int(upsample2x), epi,
-                           _C.dtype_code(x.dtype), _C.stream_ptr()), "conv2d")
+                           _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(), _C.stream_ptr()), "conv2d")
     return out
 
 
