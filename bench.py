@@ -108,9 +108,13 @@ def main():
     ap.add_argument("--mode", choices=["auto", "loop", "step", "eager"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-census", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a same-device rehearsal)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
-    rank, world, local = parallel.init_from_env("nccl")
+    rank, world, local = parallel.init_from_env(args.backend)
+    if args.same_device:
+        local = 0
     assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
