@@ -72,6 +72,16 @@ def census(loop):
     return fam
 
 
+def measured_traffic(name):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json), or None."""
+    try:
+        import glob
+        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+        return json.load(open(latest)).get(f"{name}_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def roofline_of(name, f):
     sec = f["ms"] * 1e-3
     if BOUND[name] == "mfma":
@@ -79,7 +89,7 @@ def roofline_of(name, f):
     else:
         ach, peak, unit = f["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s"
     return {"kernel": KERNEL[name], "op": name, "bound": BOUND[name], "achieved": round(ach, 2), "peak": peak, "unit": unit,
-            "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": f["launches"],
+            "frac": round(ach / peak, 4), "traffic": measured_traffic(name), "launches_per_step": f["launches"],
             "avg_launch_us": round(f["ms"] * 1e3 / f["launches"], 2), "ms_per_step": round(f["ms"], 3)}
 
 

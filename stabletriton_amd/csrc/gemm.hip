@@ -697,7 +697,7 @@ static void launch_dma(const GemmArgs& a, hipStream_t st) {
 // overrides the heuristic for A/B runs.
 enum { CFG_64x64_S4 = 0, CFG_64x64_S8 = 1, CFG_64x64_S4_U2 = 2, CFG_128x64_S4 = 3, CFG_128x64_S3_U2 = 4,
        CFG_128x128_S3 = 5, CFG_64x64_S3 = 6, CFG_64x64_W8 = 7, CFG_128x64_W8 = 8, CFG_128x128_W8 = 9,
-       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_COUNT };
+       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_COUNT };
 
 static int forced_cfg() {
     static int v = [] { const char* e = getenv("ST_GEMM_FORCE"); return e ? atoi(e) : -1; }();
@@ -782,6 +782,9 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             case CFG_64x64_W8_U2: launch_dma<T, 64, 64, 4, 2, 4, 2, CONV>(b, st); break;
             case CFG_256x256_W8: launch_dma<T, 256, 256, 2, 4, 2, 1, CONV>(b, st); break;
             case CFG_256x128_W8: launch_dma<T, 256, 128, 4, 2, 3, 1, CONV>(b, st); break;
+            case CFG_128x128_W8_S2: launch_dma<T, 128, 128, 2, 4, 2, 1, CONV>(b, st); break;
+            case CFG_128x64_W8_S3: launch_dma<T, 128, 64, 4, 2, 3, 1, CONV>(b, st); break;
+            case CFG_64x128_W8_S3: launch_dma<T, 64, 128, 2, 4, 3, 1, CONV>(b, st); break;
             default: launch_dma<T, 128, 128, 2, 4, 3, 1, CONV>(b, st); break;
         }
         return st_check_launch(who);
