@@ -74,11 +74,28 @@ int st_geglu(const void* state, const void* gate, void* out, int rows, int F,
  * ST_EPI_ROWBIAS (rowbias is (M/rows_per_batch, N) contiguous).
  * `workspace` (may be NULL) is caller-owned scratch of `workspace_bytes` bytes: when
  * present, long-K problems with few output tiles are split over K into fp32 slabs
- * there and reduced in a fixed order by a second launch (bit-reproducible). */
+ * there and reduced in a fixed order by a second launch (bit-reproducible).
+ * `row_stats` (may be NULL): device buffer of M * row_stats_capacity float2; when given, the
+ * kernel also writes, per output row and per N tile, (sum, sum of squares) of the values it
+ * stored - the LayerNorm partials st_ln_linear consumes; the number of tiles actually used is
+ * returned through the HOST pointer `row_stats_chunks` (0 = none written). */
 int st_linear(const void* x, const void* W, const void* bias, const void* residual,
               const void* rowbias, void* y, int M, int N, int K,
               long lda, long ldc, long ldr, int rows_per_batch,
-              int epilogue, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+              int epilogue, int dtype, void* workspace, size_t workspace_bytes,
+              float* row_stats, int row_stats_capacity, int* row_stats_chunks, void* stream);
+
+/* LayerNorm folded into the Linear (or GEGLU projection) that consumes it - the pair
+ * layer_norm_wrapper -> linear_wrapper of the reference graph (replace_layernorm.py:17-24,
+ * replace_linear.py:20-34; unet_pt.py:192-208) as ONE launch:
+ *   y = rstd_m * (x W'^T - mean_m * c) + d,   W' = W * diag(gamma)  (rows of `Wg`, dtype),
+ *   c[n] = sum_k W'[n][k],  d[n] = sum_k beta[k] W[n][k] + bias[n]   (fp32, host-prepared),
+ * mean_m / rstd_m = LayerNorm statistics of row m of x, summed from the `row_stats`
+ * partials (M x row_stats_chunks float2) the GEMM that produced x emitted (st_linear).
+ * With ST_EPI_GEGLU, Wg has 2N rows and c, d 2N entries. */
+int st_ln_linear(const void* x, const float* row_stats, int row_stats_chunks, const void* Wg,
+                 const float* c, const float* d, void* y, int M, int N, int K, long lda,
+                 long ldc, float eps, int epilogue, int dtype, void* stream);
 
 /* Fused attention core: out = softmax(q k^T * scale) v per head, no mask.
  * Replaces attention_wrapper (optimizers/replace_attention.py:60-68); inputs

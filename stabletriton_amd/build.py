@@ -19,7 +19,10 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIBNAME = "libstabletriton_amd.so"
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wno-unused-result"]
+# -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one unified register file), so the
+# softmax / epilogue VALU code reads them without v_accvgpr_read/write copies.
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wno-unused-result",
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def lib_path() -> str:

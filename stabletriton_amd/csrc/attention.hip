@@ -71,17 +71,29 @@ __device__ __forceinline__ void v_tile_wait(VTile& v) {
 __device__ __forceinline__ int swz_k(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 1) << 2; }
 
+typedef __attribute__((address_space(3))) void att_lds_void_t;
+typedef __attribute__((address_space(1))) const void att_gbl_cvoid_t;
+__device__ __attribute__((aligned(16))) unsigned int g_att_zero16[4] = {0u, 0u, 0u, 0u};
+
+// Pipeline per 64-key tile t (one barrier per tile, three LDS tile buffers filled by LDS-DMA):
+//   wait DMA(t+1) -> barrier -> issue DMA(t+2) -> read V(t) and K(t+1) fragments
+//   -> S_next = K(t+1) Q^T (MFMA, asynchronous) -> softmax of S_cur on the VALU (runs under those MFMAs)
+//   -> O^T += V(t)^T P^T -> S_cur = S_next.
+// The buffer refilled in trip t held tile t-1, whose last reads (V fragments of trip t-1) are in
+// registers before any wave reaches this trip's barrier; the DMA is issued after that barrier.
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                             const bf16* __restrict__ V, bf16* __restrict__ O,
                                                             int T, int S, long ldq, long ldk, long ldv, long ldo, float scale_log2e,
                                                             unsigned long long* probe) {
-    constexpr int NT = NW * 64;
     constexpr int TILE_B = ATT_KV * 128;                 // bytes of one K (or V) tile image
-    constexpr int IT = (ATT_KV * 8) / NT;                // 16-byte chunks per thread per image
-    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_B];   // [buf][K|V]
+    constexpr int BUF_B = 2 * TILE_B;                    // K image + V image
+    constexpr int PIECES = 16 / NW > 0 ? 16 / NW : 1;    // 1-KiB DMA pieces per wave per tile (8 K + 8 V pieces)
+    static_assert(16 % NW == 0, "waves must divide the 16 DMA pieces of a tile");
+    __shared__ __attribute__((aligned(16))) char lds[3 * BUF_B];
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t_ = threadIdx.x, lane = t_ & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t_ >> 6);
     const int r32 = lane & 31, h = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
     const int q0 = (blockIdx.x * NW + wave) * 32;
@@ -90,6 +102,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restri
     const bf16* Qb = Q + (size_t)b * T * ldq + (size_t)head * ATT_D;
     const bf16* Kb = K + (size_t)b * S * ldk + (size_t)head * ATT_D;
     const bf16* Vb = V + (size_t)b * S * ldv + (size_t)head * ATT_D;
+    const bf16* zeros = reinterpret_cast<const bf16*>(g_att_zero16);
 
     // Q^T fragments: lane (q = r32, h) holds d = 16ks + 8h .. +7
     bf16x8 qf[4];
@@ -97,29 +110,36 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restri
     for (int ks = 0; ks < 4; ++ks)
         qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (size_t)qrow * ldq + 16 * ks + 8 * h);
 
-    // staging slots
-    int st_row[IT], st_c[IT];
+    // ---- LDS-DMA of one tile: piece p = wave*PIECES + i; p < 8 -> K row block p, else V row block p-8.
+    // The LDS image is lane-linear, so the chunk swizzle goes on the per-lane SOURCE address.
+    const int lr = lane >> 3, pc = lane & 7;
+    auto dma_tile = [&](int kt, int buf) {
 #pragma unroll
-    for (int i = 0; i < IT; ++i) { const int id = t + i * NT; st_row[i] = id >> 3; st_c[i] = id & 7; }
-    u32x4 kreg[IT], vreg[IT];
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int key = kt * ATT_KV + st_row[i];
-            const bool ok = key < S;
-            kreg[i] = ok ? *reinterpret_cast<const u32x4*>(Kb + (size_t)key * ldk + st_c[i] * 8) : zero4;
-            vreg[i] = ok ? *reinterpret_cast<const u32x4*>(Vb + (size_t)key * ldv + st_c[i] * 8) : zero4;
+        for (int i = 0; i < PIECES; ++i) {
+            const int pce = wave * PIECES + i;
+            const int isv = pce >> 3, rb = pce & 7;
+            const int row = rb * 8 + lr;
+            const int key = kt * ATT_KV + row;
+            const int c = pc ^ (isv ? swz_v(row) : swz_k(row));
+            const bf16* src = isv ? Vb + (size_t)key * ldv + c * 8 : Kb + (size_t)key * ldk + c * 8;
+            if (key >= S) src = zeros;
+            __builtin_amdgcn_global_load_lds((att_gbl_cvoid_t*)src, (att_lds_void_t*)(lds + buf * BUF_B + isv * TILE_B + rb * 1024), 16, 0, 0);
         }
     };
-    auto store_tile = [&](int buf) {
-        char* kb = lds + buf * 2 * TILE_B;
-        char* vb = kb + TILE_B;
+    auto qk_tile = [&](int buf, f32x16& s0, f32x16& s1) {
+        const char* kb = lds + buf * BUF_B;
+        bf16x8 kf0[4], kf1[4];
 #pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int row = st_row[i];
-            *reinterpret_cast<u32x4*>(kb + row * 128 + ((st_c[i] ^ swz_k(row)) << 4)) = kreg[i];
-            *reinterpret_cast<u32x4*>(vb + row * 128 + ((st_c[i] ^ swz_v(row)) << 4)) = vreg[i];
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = 2 * ks + h;
+            const int ra = r32, rb_ = 32 + r32;
+            kf0[ks] = *reinterpret_cast<const bf16x8*>(kb + ra * 128 + ((c ^ swz_k(ra)) << 4));
+            kf1[ks] = *reinterpret_cast<const bf16x8*>(kb + rb_ * 128 + ((c ^ swz_k(rb_)) << 4));
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], s1, 0, 0, 0);
         }
     };
 
@@ -127,38 +147,27 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restri
     float m = -1e30f, l = 0.f;
     const int nkt = (S + ATT_KV - 1) / ATT_KV;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    dma_tile(0, 0);
+    if (nkt > 1) dma_tile(1, 1);
+    if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x16 s0 = {0}, s1 = {0};
+    qk_tile(0, s0, s1);
 
 #ifdef ST_PROBE
-    unsigned long long pa = 0, pb_ = 0, pc = 0, pd = 0;
+    unsigned long long pa = 0, pb_ = 0, pc_ = 0, pd = 0;
 #endif
+    int cur = 0;                                   // buffer of tile kt
     for (int kt = 0; kt < nkt; ++kt) {
         AP_STAMP(t0)
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);
-        const char* kb = lds + cur * 2 * TILE_B;
-        const char* vb = kb + TILE_B;
-
-        // ---- S^T = K Q^T for 64 keys x 32 queries: all eight K fragments are read up front ----
-        bf16x8 kf0[4], kf1[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int c = 2 * ks + h;
-            const int ra = r32, rb = 32 + r32;
-            kf0[ks] = *reinterpret_cast<const bf16x8*>(kb + ra * 128 + ((c ^ swz_k(ra)) << 4));
-            kf1[ks] = *reinterpret_cast<const bf16x8*>(kb + rb * 128 + ((c ^ swz_k(rb)) << 4));
-        }
-        f32x16 s0 = {0}, s1 = {0};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], s1, 0, 0, 0);
-        }
-        // V^T fragments for the whole tile start now and land under the softmax arithmetic.
-        // Lane (4q'+p' of its 16-lane group) addresses row q' of each 4-key block; the row's
-        // swizzle term depends only on q' (the block bases 16s + 8n + 4h are multiples of 4).
+        const int nb = cur == 2 ? 0 : cur + 1;     // buffer of tile kt+1
+        const int fb = nb == 2 ? 0 : nb + 1;       // buffer to refill with tile kt+2 (held tile kt-1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // own pieces of tile kt+1 have landed
+        __builtin_amdgcn_s_barrier();                              // ... and everyone's; tile kt-1 is dead
+        if (kt + 2 < nkt) dma_tile(kt + 2, fb);
+        // V^T fragments of this tile: sixteen transposed reads, retired after the softmax arithmetic
+        const char* vb = lds + cur * BUF_B + TILE_B;
         VTile vt;
         {
             const int q4 = (lane & 15) >> 2;
@@ -167,6 +176,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restri
             const unsigned row = lds_addr(vb) + key * 128 + 8 * (lane & 1);
             v_tile_issue(vt, row + ((ch0 ^ swz_v(key)) << 4), row + (((ch0 + 4) ^ swz_v(key)) << 4));
         }
+        // scores of the NEXT tile go to the matrix pipe now and run under this tile's softmax
+        f32x16 n0 = {0}, n1 = {0};
+        if (kt + 1 < nkt) qk_tile(nb, n0, n1);
         AP_STAMP(t1)
         // mask the tail keys (only the last tile can have any)
         if ((kt + 1) * ATT_KV > S) {
@@ -202,31 +214,29 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restri
             m = m_new;
         }
         l += rs;
-
         AP_STAMP(t2)
         // ---- O^T += V^T P^T ; k-step s covers keys 16s .. 16s+15 of the tile ----
         v_tile_wait(vt);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s_ = 0; s_ < 4; ++s_) {
             bf16x8 pb;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pb[j] = (bf16)((s < 2) ? s0[8 * (s & 1) + j] : s1[8 * (s & 1) + j]);
-            u32x4 w0 = {vt.r[s][0][0][0], vt.r[s][0][0][1], vt.r[s][0][1][0], vt.r[s][0][1][1]};
-            u32x4 w1 = {vt.r[s][1][0][0], vt.r[s][1][0][1], vt.r[s][1][1][0], vt.r[s][1][1][1]};
+            for (int j = 0; j < 8; ++j) pb[j] = (bf16)((s_ < 2) ? s0[8 * (s_ & 1) + j] : s1[8 * (s_ & 1) + j]);
+            u32x4 w0 = {vt.r[s_][0][0][0], vt.r[s_][0][0][1], vt.r[s_][0][1][0], vt.r[s_][0][1][1]};
+            u32x4 w1 = {vt.r[s_][1][0][0], vt.r[s_][1][0][1], vt.r[s_][1][1][0], vt.r[s_][1][1][1]};
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), pb, o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1), pb, o1, 0, 0, 0);
         }
-
         AP_STAMP(t3)
-        if (kt + 1 < nkt) store_tile(cur ^ 1);
-        __syncthreads();
-        AP_STAMP(t4)
-        AP_ADD(pa, t1, t0) AP_ADD(pb_, t2, t1) AP_ADD(pc, t3, t2) AP_ADD(pd, t4, t3)
+        s0 = n0; s1 = n1;
+        cur = nb;
+        AP_ADD(pa, t1, t0) AP_ADD(pb_, t2, t1) AP_ADD(pc_, t3, t2)
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef ST_PROBE
     if (probe && lane == 0) {
         unsigned long long* o = probe + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW * 8 + wave * 8;
-        o[0] = pa; o[1] = pb_; o[2] = pc; o[3] = pd; o[4] = nkt;
+        o[0] = pa; o[1] = pb_; o[2] = pc_; o[3] = pd; o[4] = nkt;
     }
 #endif
 
@@ -236,11 +246,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restri
         bf16* orow = O + (size_t)b * T * ldo + (size_t)(q0 + r32) * ldo + (size_t)head * ATT_D;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            bf16x4 a, c;
+            bf16x4 a_, c_;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { a[e] = (bf16)(o0[4 * g + e] * inv); c[e] = (bf16)(o1[4 * g + e] * inv); }
-            *reinterpret_cast<bf16x4*>(orow + 8 * g + 4 * h) = a;
-            *reinterpret_cast<bf16x4*>(orow + 32 + 8 * g + 4 * h) = c;
+            for (int e = 0; e < 4; ++e) { a_[e] = (bf16)(o0[4 * g + e] * inv); c_[e] = (bf16)(o1[4 * g + e] * inv); }
+            *reinterpret_cast<bf16x4*>(orow + 8 * g + 4 * h) = a_;
+            *reinterpret_cast<bf16x4*>(orow + 32 + 8 * g + 4 * h) = c_;
         }
     }
 }

@@ -23,6 +23,13 @@ struct GemmArgs {
     int epi;
     // implicit-GEMM conv geometry (unused for dense)
     int Hin, Win, Cin, Hout, Wout, S, stride, pad, ups;
+    // LayerNorm folded into the GEMM (st_ln_linear): W already carries gamma; ln_c[n] = sum_k W'[n][k],
+    // ln_d[n] = sum_k beta[k] W[n][k] (+ bias); y = rstd_m * (acc - mean_m * c_n) + d_n; the row statistics
+    // come from the GEMM that produced x (it emits per-tile partial sums of the values it stores)
+    const float* ln_c; const float* ln_d; float ln_eps;
+    const float* ln_stats; int ln_chunks;     // per-row (sum, sum of squares) partials written by the producer GEMM
+    float* row_stats; int stats_chunks;       // producer side: emit those partials, one float2 per (row, N tile)
+    int stats_capacity; int* stats_chunks_out; // host-side plumbing of the chunk count
     int splitk;                  // K slices (1 = none); slices write fp32 slabs to `partial`, a second pass reduces
     float* partial;
     size_t partial_bytes;
@@ -75,12 +82,34 @@ template <> struct Out4<float> {
 // ---- shared epilogue ---------------------------------------------------------------------------
 // One output row m, 4 consecutive columns n..n+3: v = accumulators (value half), g = gate half (GEGLU).
 template <typename T, bool GEGLU>
-__device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n, float (&v)[4], const float (&g_in)[4]) {
+__device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n, float (&v)[4], const float (&g_in)[4],
+                                                float ln_mean = 0.f, float ln_rstd = 0.f) {
     T* __restrict__ Cp = (T*)p.C;
     const T* __restrict__ bias = (const T*)p.bias;
     const T* __restrict__ Rp = (const T*)p.residual;
     const T* __restrict__ RBp = (const T*)p.rowbias;
     const bool full = (n + 3 < p.N);
+    float g[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = g_in[e];
+    if (p.ln_c) {                                      // folded LayerNorm: rank-1 correction per row / column
+        if (full) {
+            float c4[4], d4[4];
+            Out4<float>::load(p.ln_c + n, c4); Out4<float>::load(p.ln_d + n, d4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ln_rstd * (v[e] - ln_mean * c4[e]) + d4[e];
+            if (GEGLU) {
+                Out4<float>::load(p.ln_c + p.N + n, c4); Out4<float>::load(p.ln_d + p.N + n, d4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = ln_rstd * (g[e] - ln_mean * c4[e]) + d4[e];
+            }
+        } else {
+            for (int e = 0; e < 4 && n + e < p.N; ++e) {
+                v[e] = ln_rstd * (v[e] - ln_mean * p.ln_c[n + e]) + p.ln_d[n + e];
+                if (GEGLU) g[e] = ln_rstd * (g[e] - ln_mean * p.ln_c[p.N + n + e]) + p.ln_d[p.N + n + e];
+            }
+        }
+    }
     if (p.epi & ST_EPI_BIAS) {
         if (full) { float b4[4]; Out4<T>::load(bias + n, b4);
 #pragma unroll
@@ -90,9 +119,6 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n,
         }
     }
     if (GEGLU) {
-        float g[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] = g_in[e];
         if (p.epi & ST_EPI_BIAS) {
             if (full) { float b4[4]; Out4<T>::load(bias + p.N + n, b4);
 #pragma unroll
@@ -129,13 +155,19 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n,
     T* dst = Cp + (size_t)m * p.ldc + n;
     if (full) Out4<T>::store(dst, v);
     else for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = Elem<T>::from_f(v[e]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (n + e < p.N) ? Elem<T>::to_f(Elem<T>::from_f(v[e])) : 0.f;   // what was stored
 }
 
 // lane (r16, q) holds rows m = .. + r16, columns n = .. + 4q .. 4q+3 of every 16x16 tile.
 // With split-K (p.splitk > 1) the raw fp32 sums go to the partial slab of this K slice instead.
-template <typename T, int TM, int TN, int WTM, int WTN, bool GEGLU>
+template <typename T, int TM, int TN, int WTM, int WTN, bool GEGLU, int WGM_ = 0, int WGN_ = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
-                                              int r16, int q, int split = 0) {
+                                              int r16, int q, int split = 0, const float* row_mean = nullptr,
+                                              const float* row_rstd = nullptr, char* lds_scratch = nullptr, int tile_n = 0) {
+    float rs1[TM], rs2[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { rs1[i] = 0.f; rs2[i] = 0.f; }
     constexpr int TNO = GEGLU ? TN / 2 : TN;
     constexpr int WTNO = GEGLU ? WTN / 2 : WTN;
     const int ncols = GEGLU ? 2 * p.N : p.N;          // columns of one partial slab
@@ -163,7 +195,32 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                     for (int e = 0; e < 4 && n + e < p.N; ++e) { slab[n + e] = v[e]; if (GEGLU) slab[p.N + n + e] = g[e]; }
                 }
             } else {
-                epilogue_store4<T, GEGLU>(p, m, n, v, g);
+                epilogue_store4<T, GEGLU>(p, m, n, v, g, row_mean ? row_mean[i] : 0.f, row_rstd ? row_rstd[i] : 0.f);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { rs1[i] += v[e]; rs2[i] = fmaf(v[e], v[e], rs2[i]); }
+            }
+        }
+    }
+    if constexpr (WGN_ > 0) {
+        // LayerNorm partials of the rows this block just stored (consumed by the next st_ln_linear):
+        // lane sums -> the four q lanes -> the WGN waves of this tile row (through LDS) -> one float2
+        // per (row, N tile).  Fixed order throughout: bit-reproducible.
+        if (p.row_stats) {
+            float2* sm = reinterpret_cast<float2*>(lds_scratch);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float a1 = rs1[i], a2 = rs2[i];
+                a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
+                a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+                if (q == 0) sm[(wm * WTM + i * 16 + r16) * WGN_ + wn] = make_float2(a1, a2);
+            }
+            __syncthreads();
+            for (int row = threadIdx.x; row < WGM_ * WTM; row += WGM_ * WGN_ * 64) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WGN_; ++w) { const float2 t = sm[row * WGN_ + w]; a1 += t.x; a2 += t.y; }
+                if (m0 + row < p.M)
+                    reinterpret_cast<float2*>(p.row_stats)[(size_t)(m0 + row) * p.stats_chunks + tile_n] = make_float2(a1, a2);
             }
         }
     }
@@ -410,7 +467,7 @@ __device__ __forceinline__ unsigned long long probe_now() {
 #define PROBE_ADD(acc, t1, t0)
 #endif
 
-template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV, bool GEGLU>
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV, bool GEGLU, bool LNF = false>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs p) {
     constexpr int NW = WGM * WGN;
     constexpr int VEC = 16 / (int)sizeof(T);
@@ -639,7 +696,26 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     }
     wait_vmcnt<0>();                              // no LDS-DMA may outlive the workgroup's LDS allocation
     PROBE_STAMP(pr_end)
-    gemm_epilogue<T, TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wm, wn, r16, q, split);
+    if constexpr (LNF) {
+        // LayerNorm statistics of this lane's rows from the producer's per-tile partials: the four q
+        // lanes of a row each sum every fourth partial, then a two-step butterfly (fixed order)
+        float mean[TM], rstd[TM];
+        const float2* st2 = reinterpret_cast<const float2*>(p.ln_stats);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + r16;
+            float a1 = 0.f, a2 = 0.f;
+            if (m < p.M)
+                for (int c = q; c < p.ln_chunks; c += 4) { const float2 t = st2[(size_t)m * p.ln_chunks + c]; a1 += t.x; a2 += t.y; }
+            a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
+            a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+            mean[i] = a1 / (float)p.K;
+            rstd[i] = rsqrtf(fmaxf(a2 / (float)p.K - mean[i] * mean[i], 0.f) + p.ln_eps);
+        }
+        gemm_epilogue<T, TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wm, wn, r16, q, split, mean, rstd);
+    } else {
+        gemm_epilogue<T, TM, TN, WTM, WTN, GEGLU, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n);
+    }
 #ifdef ST_PROBE
     {
         PROBE_STAMP(pr_fin)
@@ -670,27 +746,29 @@ static void launch_cfg(const GemmArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WGM, WGN, CONV, false>), dim3(tiles_m * cdiv(a.N, BN)), dim3(WGM * WGN * 64), lds, st, a);
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV>
-static void launch_dma(const GemmArgs& a, hipStream_t st) {
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV, bool GEGLU, bool LNF>
+static void launch_dma_one(const GemmArgs& a, hipStream_t st, int tiles_n) {
     const size_t lds = (size_t)STAGES * U * (BM + BN) * 128;
-    const int tiles_m = cdiv(a.M, BM);
     const int sk = a.splitk > 1 ? a.splitk : 1;
-    const int red_blocks = cdiv((long)a.M * ((a.N + 3) / 4), 256);
-    if constexpr (!CONV) {
-        if (a.epi & ST_EPI_GEGLU) {
-            auto kfn = gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, U, CONV, true>;
-            static bool once = (allow_big_lds(kfn, lds), true);
-            (void)once;
-            hipLaunchKernelGGL(kfn, dim3(tiles_m * cdiv(a.N, BN / 2) * sk), dim3(WGM * WGN * 64), lds, st, a);
-            if (sk > 1) hipLaunchKernelGGL((splitk_reduce_kernel<T, true>), dim3(red_blocks), dim3(256), 0, st, a);
-            return;
-        }
-    }
-    auto kfn = gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, U, CONV, false>;
+    auto kfn = gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, U, CONV, GEGLU, LNF>;
     static bool once = (allow_big_lds(kfn, lds), true);
     (void)once;
-    hipLaunchKernelGGL(kfn, dim3(tiles_m * cdiv(a.N, BN) * sk), dim3(WGM * WGN * 64), lds, st, a);
-    if (sk > 1) hipLaunchKernelGGL((splitk_reduce_kernel<T, false>), dim3(red_blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(kfn, dim3(cdiv(a.M, BM) * tiles_n * sk), dim3(WGM * WGN * 64), lds, st, a);
+    if (sk > 1) hipLaunchKernelGGL((splitk_reduce_kernel<T, GEGLU>), dim3(cdiv((long)a.M * ((a.N + 3) / 4), 256)), dim3(256), 0, st, a);
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV>
+static void launch_dma(const GemmArgs& a, hipStream_t st) {
+    if constexpr (!CONV) {
+        const bool geglu = a.epi & ST_EPI_GEGLU;
+        if (a.ln_c) {          // LayerNorm-folded variants (never split over K: the row statistics need all of K)
+            if (geglu) launch_dma_one<T, BM, BN, WGM, WGN, STAGES, U, false, true, true>(a, st, cdiv(a.N, BN / 2));
+            else launch_dma_one<T, BM, BN, WGM, WGN, STAGES, U, false, false, true>(a, st, cdiv(a.N, BN));
+            return;
+        }
+        if (geglu) { launch_dma_one<T, BM, BN, WGM, WGN, STAGES, U, false, true, false>(a, st, cdiv(a.N, BN / 2)); return; }
+    }
+    launch_dma_one<T, BM, BN, WGM, WGN, STAGES, U, CONV, false, false>(a, st, cdiv(a.N, BN));
 }
 
 // Tile configurations of the LDS-DMA kernel.  ST_GEMM_FORCE=<id> (developer knob)
@@ -698,6 +776,16 @@ static void launch_dma(const GemmArgs& a, hipStream_t st) {
 enum { CFG_64x64_S4 = 0, CFG_64x64_S8 = 1, CFG_64x64_S4_U2 = 2, CFG_128x64_S4 = 3, CFG_128x64_S3_U2 = 4,
        CFG_128x128_S3 = 5, CFG_64x64_S3 = 6, CFG_64x64_W8 = 7, CFG_128x64_W8 = 8, CFG_128x128_W8 = 9,
        CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_COUNT };
+
+static int cfg_bn(int cfg) {
+    switch (cfg) {
+        case CFG_64x64_S4: case CFG_64x64_S8: case CFG_64x64_S4_U2: case CFG_128x64_S4: case CFG_128x64_S3_U2: case CFG_64x64_S3:
+        case CFG_64x64_W8: case CFG_128x64_W8: case CFG_128x64_W8_S6: case CFG_64x64_W8_S8: case CFG_128x64_W8_U2:
+        case CFG_64x64_W8_U2: case CFG_128x64_W8_S3: return 64;
+        case CFG_256x256_W8: return 256;
+        default: return 128;
+    }
+}
 
 static int forced_cfg() {
     static int v = [] { const char* e = getenv("ST_GEMM_FORCE"); return e ? atoi(e) : -1; }();
@@ -710,14 +798,18 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
     auto tiles = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(n_eff, bn); };
     constexpr int KB = 128 / (int)sizeof(T);
     const char* who = CONV ? "conv2d" : "linear";
-    if (a.K % KB != 0) {                         // ragged K: register-staged kernel
+    if (a.K % KB != 0) {                         // ragged K: register-staged kernel (no LayerNorm partials)
+        if (a.stats_chunks_out) *a.stats_chunks_out = 0;
         if (tiles(128, 128) >= 240) launch_cfg<T, 128, 128, 2, 2, CONV>(a, st);
         else if (tiles(128, 64) >= 200) launch_cfg<T, 128, 64, 2, 2, CONV>(a, st);
         else launch_cfg<T, 64, 64, 2, 2, CONV>(a, st);
         return st_check_launch(who);
     }
     if constexpr (sizeof(T) == 4) {              // strict fp32 mode: one configuration, speed is not the point
-        launch_dma<T, 64, 64, 2, 2, 4, 1, CONV>(a, st);
+        GemmArgs b = a;
+        b.stats_chunks = cdiv(a.N, 64);
+        if (a.stats_chunks_out) *a.stats_chunks_out = a.row_stats ? b.stats_chunks : 0;
+        launch_dma<T, 64, 64, 2, 2, 4, 1, CONV>(b, st);
         return st_check_launch(who);
     } else {
         const bool even2 = (a.K % (2 * KB) == 0);
@@ -745,7 +837,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
         const long ncols = (a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N;
         static const int force_sk = [] { const char* e = getenv("ST_GEMM_SPLITK"); return e ? atoi(e) : -1; }();
         int sk = 1;
-        if (a.partial && force_sk != 0) {
+        if (a.partial && force_sk != 0 && !a.ln_c && !a.row_stats) {
             const long t = tiles(256, 128);
             if (t <= 100 && nk >= 120) {        // measured: pays from K ~ 8k up (the wide resnet convs)
                 sk = (int)(256 / t);
@@ -762,7 +854,15 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
                              f == CFG_64x64_W8_U2);
             if (!u2 || even2) cfg = f;
         }
+        b.stats_chunks = cdiv(a.N, cfg_bn(cfg));
+        if (a.row_stats && b.stats_chunks > a.stats_capacity) return st_fail("%s: row_stats buffer holds %d chunks, %d needed", who, a.stats_capacity, b.stats_chunks);
+        if (a.stats_chunks_out) *a.stats_chunks_out = a.row_stats ? b.stats_chunks : 0;
         switch (cfg) {
+            case CFG_64x64_W8: launch_dma<T, 64, 64, 4, 2, 4, 1, CONV>(b, st); break;
+            case CFG_128x64_W8: launch_dma<T, 128, 64, 4, 2, 4, 1, CONV>(b, st); break;
+            case CFG_64x128_W8: launch_dma<T, 64, 128, 2, 4, 4, 1, CONV>(b, st); break;
+            case CFG_256x128_W8: launch_dma<T, 256, 128, 4, 2, 3, 1, CONV>(b, st); break;
+#ifdef ST_DEV_CONFIGS       // tile/pipeline variants kept for A/B sweeps (tools/op_bench.py with ST_GEMM_FORCE)
             case CFG_64x64_S4: launch_dma<T, 64, 64, 2, 2, 4, 1, CONV>(b, st); break;
             case CFG_64x64_S8: launch_dma<T, 64, 64, 2, 2, 8, 1, CONV>(b, st); break;
             case CFG_64x64_S4_U2: launch_dma<T, 64, 64, 2, 2, 4, 2, CONV>(b, st); break;
@@ -770,9 +870,6 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             case CFG_128x64_S3_U2: launch_dma<T, 128, 64, 2, 2, 3, 2, CONV>(b, st); break;
             case CFG_128x128_S3: launch_dma<T, 128, 128, 2, 2, 3, 1, CONV>(b, st); break;
             case CFG_64x64_S3: launch_dma<T, 64, 64, 2, 2, 3, 1, CONV>(b, st); break;
-            case CFG_64x64_W8: launch_dma<T, 64, 64, 4, 2, 4, 1, CONV>(b, st); break;
-            case CFG_128x64_W8: launch_dma<T, 128, 64, 4, 2, 4, 1, CONV>(b, st); break;
-            case CFG_64x128_W8: launch_dma<T, 64, 128, 2, 4, 4, 1, CONV>(b, st); break;
             case CFG_64x128_W8_S6: launch_dma<T, 64, 128, 2, 4, 6, 1, CONV>(b, st); break;
             case CFG_128x64_W8_S6: launch_dma<T, 128, 64, 4, 2, 6, 1, CONV>(b, st); break;
             case CFG_128x128_W8_S4: launch_dma<T, 128, 128, 2, 4, 4, 1, CONV>(b, st); break;
@@ -781,11 +878,11 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             case CFG_128x64_W8_U2: launch_dma<T, 128, 64, 4, 2, 3, 2, CONV>(b, st); break;
             case CFG_64x64_W8_U2: launch_dma<T, 64, 64, 4, 2, 4, 2, CONV>(b, st); break;
             case CFG_256x256_W8: launch_dma<T, 256, 256, 2, 4, 2, 1, CONV>(b, st); break;
-            case CFG_256x128_W8: launch_dma<T, 256, 128, 4, 2, 3, 1, CONV>(b, st); break;
             case CFG_128x128_W8_S2: launch_dma<T, 128, 128, 2, 4, 2, 1, CONV>(b, st); break;
             case CFG_128x64_W8_S3: launch_dma<T, 128, 64, 4, 2, 3, 1, CONV>(b, st); break;
             case CFG_64x128_W8_S3: launch_dma<T, 64, 128, 2, 4, 3, 1, CONV>(b, st); break;
-            default: launch_dma<T, 128, 128, 2, 4, 3, 1, CONV>(b, st); break;
+#endif
+            default: launch_dma<T, 128, 128, 2, 4, 3, 1, CONV>(b, st); break;      // CFG_128x128_W8
         }
         return st_check_launch(who);
     }
@@ -806,7 +903,8 @@ static int check_epilogue(const char* who, const GemmArgs& a) {
 
 extern "C" int st_linear(const void* x, const void* W, const void* bias, const void* residual, const void* rowbias, void* y,
                          int M, int N, int K, long lda, long ldc, long ldr, int rows_per_batch, int epilogue, int dtype,
-                         void* workspace, size_t workspace_bytes, void* stream) {
+                         void* workspace, size_t workspace_bytes, float* row_stats, int row_stats_capacity,
+                         int* row_stats_chunks, void* stream) {
     ST_REQUIRE(x && W && y, "linear: null pointer");
     ST_REQUIRE(M > 0 && N > 0 && K > 0, "linear: bad shape M=%d N=%d K=%d", M, N, K);
     const int vec = dtype == ST_BF16 ? 8 : 4;
@@ -818,10 +916,32 @@ extern "C" int st_linear(const void* x, const void* W, const void* bias, const v
     a.A = x; a.W = W; a.bias = bias; a.residual = residual; a.rowbias = rowbias; a.C = y;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.rows_per_batch = rows_per_batch; a.epi = epilogue;
     a.splitk = 1; a.partial = (float*)workspace; a.partial_bytes = workspace ? workspace_bytes : 0;
+    ST_REQUIRE(!row_stats || !(epilogue & ST_EPI_GEGLU), "linear: row_stats with GEGLU is not supported");
+    a.row_stats = row_stats; a.stats_capacity = row_stats_capacity; a.stats_chunks_out = row_stats_chunks;
 #ifdef ST_PROBE
     a.probe = g_probe;
 #endif
     if (int e = check_epilogue("linear", a)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == ST_BF16 ? gemm_dispatch<bf16, false>(a, st) : gemm_dispatch<float, false>(a, st);
+}
+
+// LayerNorm folded into the following Linear (or GEGLU projection): see GemmArgs::ln_c.
+extern "C" int st_ln_linear(const void* x, const float* row_stats, int row_stats_chunks, const void* Wg, const float* c,
+                            const float* d, void* y, int M, int N, int K, long lda, long ldc, float eps, int epilogue,
+                            int dtype, void* stream) {
+    ST_REQUIRE(x && Wg && c && d && y && row_stats, "ln_linear: null pointer");
+    ST_REQUIRE(row_stats_chunks > 0, "ln_linear: the producer emitted no row statistics");
+    ST_REQUIRE(M > 0 && N > 0 && K > 0, "ln_linear: bad shape M=%d N=%d K=%d", M, N, K);
+    ST_REQUIRE(dtype == ST_BF16 || dtype == ST_F32, "ln_linear: unsupported dtype %d", dtype);
+    const int kb = dtype == ST_BF16 ? 64 : 32;
+    ST_REQUIRE(K % kb == 0 && lda % (kb / 8) == 0, "ln_linear: K=%d must be a multiple of %d", K, kb);
+    ST_REQUIRE(ldc % 4 == 0, "ln_linear: ldc must be a multiple of 4");
+    ST_REQUIRE((epilogue & ~ST_EPI_GEGLU) == 0, "ln_linear: only the GEGLU epilogue flag is accepted (bias lives in d)");
+    ST_REQUIRE(((uintptr_t)x | (uintptr_t)Wg | (uintptr_t)y) % 16 == 0, "ln_linear: pointers must be 16-byte aligned");
+    GemmArgs a = {};
+    a.A = x; a.W = Wg; a.C = y; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.epi = epilogue;
+    a.ln_c = c; a.ln_d = d; a.ln_eps = eps; a.splitk = 1; a.ln_stats = row_stats; a.ln_chunks = row_stats_chunks;
     hipStream_t st = (hipStream_t)stream;
     return dtype == ST_BF16 ? gemm_dispatch<bf16, false>(a, st) : gemm_dispatch<float, false>(a, st);
 }

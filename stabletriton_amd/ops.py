@@ -147,9 +147,22 @@ def geglu(state: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- linear
+STATS_MAX_CHUNKS = 64      # N tiles a row-statistics buffer can hold (N <= 64 * 64)
+
+
+class RowStats:
+    """LayerNorm partials of a GEMM output: (M, chunks) float2 = per-row (sum, sum of squares) per N tile."""
+    __slots__ = ("buf", "chunks")
+
+    def __init__(self, buf: torch.Tensor, chunks: int):
+        self.buf, self.chunks = buf, chunks
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, silu: bool = False,
-           geglu: bool = False, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """epilogue(x @ weight.T): +bias, then SiLU or GEGLU (weight has 2N rows), then +residual."""
+           geglu: bool = False, residual: Optional[torch.Tensor] = None, emit_stats: bool = False):
+    """epilogue(x @ weight.T): +bias, then SiLU or GEGLU (weight has 2N rows), then +residual.
+    With emit_stats the GEMM also writes the LayerNorm partials of its output rows and the call
+    returns (out, RowStats)."""
     _C.require_device(x, weight, bias, residual)
     lib = _C.load()
     K = x.shape[-1]
@@ -178,10 +191,54 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         residual, _, ldr = _rows2d(residual)
         epi |= _C.EPI_RESIDUAL
     gws = _gemm_workspace(x.device)
+    stats = chunks = None
+    if emit_stats:
+        import ctypes
+        cap = min(STATS_MAX_CHUNKS, (N + 63) // 64)
+        stats = torch.empty((M, cap, 2), dtype=torch.float32, device=x.device)
+        chunks = ctypes.c_int(0)
     _C.check(_timed("linear", 2.0 * M * w.shape[0] * K, float((M * K + w.numel() + M * N) * x.element_size()),
                     lib.st_linear, x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
-                           lda, N, ldr, 0, epi, _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(), _C.stream_ptr()), "linear")
+                    lda, N, ldr, 0, epi, _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(),
+                    _ptr(stats), 0 if stats is None else stats.shape[1],
+                    None if chunks is None else ctypes.byref(chunks), _C.stream_ptr()), "linear")
+    if emit_stats:
+        if chunks.value <= 0:
+            raise BackendError("linear: this shape cannot emit LayerNorm row statistics (K must be a multiple of the K tile)")
+        dense = stats.view(-1)[:M * chunks.value * 2].view(M, chunks.value, 2)      # the kernel packs rows at `chunks` stride
+        return out, RowStats(dense, chunks.value)
     return out
+
+
+def ln_linear(x: torch.Tensor, stats: "RowStats", w_folded: torch.Tensor, c: torch.Tensor, d: torch.Tensor, eps: float, *,
+              geglu: bool = False) -> torch.Tensor:
+    """LayerNorm(x) @ W.T (+bias) as one GEMM on gamma-folded weights with a rank-1 correction
+    (see st_ln_linear in the header); `w_folded`, `c`, `d` come from `fold_layer_norm`, `stats`
+    from the `linear(..., emit_stats=True)` call that produced x."""
+    _C.require_device(x, w_folded, c, d, stats.buf)
+    lib = _C.load()
+    K = x.shape[-1]
+    if w_folded.shape[1] != K or w_folded.dtype != x.dtype or c.dtype != torch.float32 or d.dtype != torch.float32:
+        raise BackendError("ln_linear: folded operands do not match the input")
+    x2, M, lda = _rows2d(x)
+    N = w_folded.shape[0] // 2 if geglu else w_folded.shape[0]
+    out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+    _C.check(_timed("linear", 2.0 * M * w_folded.shape[0] * K, float((M * K + w_folded.numel() + M * N) * x.element_size()),
+                    lib.st_ln_linear, x2.data_ptr(), stats.buf.data_ptr(), stats.chunks, w_folded.data_ptr(),
+                    c.data_ptr(), d.data_ptr(), out.data_ptr(), M, N, K,
+                    lda, N, float(eps), _C.EPI_GEGLU if geglu else 0, _C.dtype_code(x.dtype), _C.stream_ptr()), "ln_linear")
+    return out
+
+
+@torch.no_grad()
+def fold_layer_norm(gamma: torch.Tensor, beta: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+    """(W * diag(gamma) in the weight dtype, c = row sums of that rounded matrix, d = W beta + bias), fp32 c/d."""
+    wf = (weight.float() * gamma.float()[None, :]).to(weight.dtype).contiguous()
+    c = wf.float().sum(dim=1).contiguous()
+    d = weight.float() @ beta.float()
+    if bias is not None:
+        d = d + bias.float()
+    return wf, c, d.contiguous()
 
 
 # ----------------------------------------------------------------------------- attention

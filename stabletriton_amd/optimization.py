@@ -16,7 +16,8 @@ import torch
 from torch import fx, nn
 
 from . import _C
-from .optimizers import (fuse_attention, fuse_geglu, fuse_geglu_into_linear, fuse_residual_adds, fuse_shared_input_linears,
+from .optimizers import (fuse_attention, fuse_geglu, fuse_geglu_into_linear, fuse_layernorm_into_linear, fuse_residual_adds,
+                         fuse_shared_input_linears,
                          fuse_temb_add, fuse_timesteps, split_context, keep_channels_last, make_dynamic_graphed_callable, remove_dropout,
                          replace_conv, replace_group_norm, replace_group_norm_activation, replace_layer_norm,
                          replace_linear, replace_linear_activ)
@@ -42,6 +43,7 @@ def replace_backend(gm: fx.GraphModule, fuse: bool = True) -> fx.GraphModule:
         stats["temb_rowbias"] = fuse_temb_add(gm)
         stats["residual_adds"] = fuse_residual_adds(gm)
         stats["shared_input_gemms"] = fuse_shared_input_linears(gm)
+        stats["layer_norm_in_gemm"] = fuse_layernorm_into_linear(gm)
     stats["channels_last_views"] = keep_channels_last(gm)
     gm.graph.eliminate_dead_code()
     gm.graph.lint()

@@ -17,7 +17,8 @@ from typing import Dict, List, Optional, Tuple
 import torch
 from torch import fx, nn
 
-from .wrappers import linear_cat_wrapper, linear_wrapper
+from .wrappers import (layer_norm_wrapper, linear_cat_wrapper, linear_geglu_wrapper, linear_wrapper,
+                       ln_linear_wrapper)
 
 
 def fuse_shared_input_linears(gm: fx.GraphModule) -> int:
@@ -51,6 +52,65 @@ def fuse_shared_input_linears(gm: fx.GraphModule) -> int:
         gm.graph.lint()
         gm.recompile()
     return fused
+
+
+def fuse_layernorm_into_linear(gm: fx.GraphModule) -> int:
+    """layer_norm_wrapper whose input comes from a GEMM and whose only consumer is a plain /
+    concatenated / GEGLU projection disappears: the producing GEMM also emits per-row (sum, sum of
+    squares) partials of what it stores, gamma is folded into the consumer's weights and the
+    consumer applies mean/rstd as a rank-1 correction in its epilogue (`ln_linear_wrapper`)."""
+    from .wrappers import linear_residual_wrapper
+    count = 0
+    for ln in list(gm.graph.nodes):
+        if not (ln.op == "call_function" and ln.target is layer_norm_wrapper) or len(ln.users) != 1:
+            continue
+        user = next(iter(ln.users))
+        if user.op != "call_function" or user.args[0] is not ln:
+            continue
+        lnmod = gm.get_submodule(ln.args[1].target)
+        if len(lnmod.normalized_shape) != 1:
+            continue
+        if user.target is linear_wrapper and user.args[2] is False and len(user.args) == 3:
+            linears, geglu = (user.args[1],), False
+        elif user.target is linear_cat_wrapper:
+            linears, geglu = tuple(user.args[1]), False
+        elif user.target is linear_geglu_wrapper:
+            linears, geglu = (user.args[1],), True
+        else:
+            continue
+        kdim = lnmod.normalized_shape[0]
+        mods = [gm.get_submodule(a.target) for a in linears]
+        if any(m.in_features != kdim for m in mods) or kdim % 64 != 0:
+            continue
+        # the producer of the LayerNorm input must be one of our GEMMs (it will emit the partials)
+        prod = ln.args[0]
+        if not (isinstance(prod, fx.Node) and prod.op == "call_function"):
+            continue
+        if prod.target is linear_wrapper and prod.args[2] is False and len(prod.args) == 3:
+            pass
+        elif prod.target is linear_residual_wrapper and len(prod.args) == 3:
+            pass
+        else:
+            continue
+        pmod = gm.get_submodule(prod.args[1].target)
+        if pmod.in_features % 64 != 0 or pmod.out_features != kdim:
+            continue
+        prod.args = tuple(prod.args) + (True,)            # emit_stats
+        with gm.graph.inserting_after(prod):
+            st = gm.graph.call_function(operator.getitem, (prod, 1))
+            x0 = gm.graph.call_function(operator.getitem, (prod, 0))
+        prod.replace_all_uses_with(x0, delete_user_cb=lambda u: u is not x0 and u is not st)
+        with gm.graph.inserting_before(user):
+            new = gm.graph.call_function(ln_linear_wrapper, (x0, st, ln.args[1], linears, geglu))
+        user.replace_all_uses_with(new)
+        gm.graph.erase_node(user)
+        gm.graph.erase_node(ln)
+        count += 1
+    if count:
+        gm.graph.eliminate_dead_code()
+        gm.graph.lint()
+        gm.recompile()
+    return count
 
 
 def split_context(gm: fx.GraphModule, context_arg: str = "encoder_hidden_states") -> Optional[fx.GraphModule]:

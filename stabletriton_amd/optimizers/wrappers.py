@@ -46,12 +46,14 @@ def layer_norm_wrapper(v: torch.Tensor, layernorm: nn.LayerNorm) -> torch.Tensor
 
 
 def linear_wrapper_functional(v: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
-                              activation: bool) -> torch.Tensor:
-    return ops.linear(v, weight, bias, silu=activation)
+                              activation: bool, emit_stats: bool = False):
+    return ops.linear(v, weight, bias, silu=activation, emit_stats=emit_stats)
 
 
-def linear_wrapper(v: torch.Tensor, linear: nn.Linear, activation: bool) -> torch.Tensor:
-    return linear_wrapper_functional(v, linear.weight, linear.bias, activation)
+def linear_wrapper(v: torch.Tensor, linear: nn.Linear, activation: bool, emit_stats: bool = False):
+    """`emit_stats` (addition): also return the LayerNorm partials of the output rows, for a
+    following `ln_linear_wrapper`; the result is then the pair (out, stats)."""
+    return linear_wrapper_functional(v, linear.weight, linear.bias, activation, emit_stats)
 
 
 def timestep_wrapper(t: torch.Tensor, dim: int) -> torch.Tensor:
@@ -73,8 +75,8 @@ def linear_geglu_wrapper(v: torch.Tensor, linear: nn.Linear) -> torch.Tensor:
     return ops.linear(v, linear.weight, linear.bias, geglu=True)
 
 
-def linear_residual_wrapper(v: torch.Tensor, linear: nn.Linear, residual: torch.Tensor) -> torch.Tensor:
-    return ops.linear(v, linear.weight, linear.bias, residual=residual)
+def linear_residual_wrapper(v: torch.Tensor, linear: nn.Linear, residual: torch.Tensor, emit_stats: bool = False):
+    return ops.linear(v, linear.weight, linear.bias, residual=residual, emit_stats=emit_stats)
 
 
 for _name in ("attention_wrapper", "geglu_triton", "group_norm_wrapper", "layer_norm_wrapper", "linear_wrapper",
@@ -113,3 +115,36 @@ def linear_cat_wrapper(v: torch.Tensor, linears) -> torch.Tensor:
 
 
 torch.fx.wrap("linear_cat_wrapper")
+
+
+# ---- LayerNorm folded into the projection(s) that consume it ---------------------------------
+_ln_folds = {}
+
+
+def _ln_fold(layernorm: nn.LayerNorm, linears):
+    key = (id(layernorm),) + tuple(id(l) for l in linears)
+    params = [layernorm.weight, layernorm.bias] + [l.weight for l in linears] + [l.bias for l in linears if l.bias is not None]
+    stamp = tuple((t.data_ptr(), t._version, t.dtype) for t in params)
+    hit = _ln_folds.get(key)
+    if hit is None or hit[0] != stamp:
+        with torch.no_grad():
+            w = torch.cat([l.weight.detach() for l in linears], dim=0) if len(linears) > 1 else linears[0].weight.detach()
+            if all(l.bias is None for l in linears):
+                b = None
+            else:
+                b = torch.cat([l.bias.detach().float() if l.bias is not None else
+                               torch.zeros(l.out_features, dtype=torch.float32, device=w.device) for l in linears])
+            hit = (stamp,) + ops.fold_layer_norm(layernorm.weight.detach(), layernorm.bias.detach(), w, b)
+        _ln_folds[key] = hit
+    return hit[1], hit[2], hit[3]
+
+
+def ln_linear_wrapper(v: torch.Tensor, stats, layernorm: nn.LayerNorm, linears, geglu: bool = False) -> torch.Tensor:
+    """linear_i(layernorm(v)) for every linear in `linears`, concatenated on the last dimension
+    (or the GEGLU of the single projection), as ONE GEMM: the LayerNorm never runs as its own
+    kernel.  `stats` are the row partials the GEMM that produced `v` emitted (emit_stats=True)."""
+    wf, c, d = _ln_fold(layernorm, tuple(linears))
+    return ops.ln_linear(v, stats, wf, c, d, layernorm.eps, geglu=geglu)
+
+
+torch.fx.wrap("ln_linear_wrapper")

@@ -58,6 +58,7 @@ def test_pass_counts_match_reference_probe_on_sdxl():
     for k, v in EXPECTED.items():
         assert gm.rewrite_stats[k] == v, (k, gm.rewrite_stats[k], v)
     assert gm.rewrite_stats["geglu_in_gemm"] == 70 and gm.rewrite_stats["temb_rowbias"] == 17
+    assert gm.rewrite_stats["layer_norm_in_gemm"] == 210 and gm.rewrite_stats["shared_input_gemms"] == 71
     _install_context_split(gm)
     assert gm.rewrite_stats["context_outputs"] == 140
     left = [n for n in gm.graph.nodes if n.op == "call_module"]
@@ -72,14 +73,23 @@ def _cpu_backend(monkeypatch):
     monkeypatch.setattr(ops, "layer_norm", lambda x, w, b, eps: F.layer_norm(x, w.shape, w, b, eps))
     monkeypatch.setattr(ops, "geglu", lambda s, g: s * F.gelu(g))
 
-    def linear(x, w, b=None, *, silu=False, geglu=False, residual=None):
+    def linear(x, w, b=None, *, silu=False, geglu=False, residual=None, emit_stats=False):
         y = F.linear(x, w, b)
         if silu:
             y = F.silu(y)
         if geglu:
             y = orc.geglu(y)
-        return y if residual is None else y + residual
+        y = y if residual is None else y + residual
+        return (y, "stats") if emit_stats else y
     monkeypatch.setattr(ops, "linear", linear)
+
+    def ln_linear(x, stats, wf, c, d, eps, *, geglu=False):
+        assert stats == "stats"
+        mean = x.mean(-1, keepdim=True)
+        rstd = (x.var(-1, unbiased=False, keepdim=True) + eps).rsqrt()
+        y = rstd * (F.linear(x, wf) - mean * c) + d
+        return orc.geglu(y) if geglu else y
+    monkeypatch.setattr(ops, "ln_linear", ln_linear)
     monkeypatch.setattr(ops, "attention", lambda q, k, v, h, scale: orc.attention_core(q, k, v, h))
 
     def conv2d(x, w, b, stride, padding, *, upsample2x=False, rowbias=None, residual=None):

@@ -100,6 +100,31 @@ def test_linear_geglu(gpu, dtype, M, K, F_):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K,N,geglu", [(1024, 1280, 3840, False), (100, 640, 640, False), (256, 640, 2560, True),
+                                         (1024, 1280, 5120, True), (77, 128, 64, False), (4096, 640, 1920, False)])
+def test_ln_linear(gpu, dtype, M, K, N, geglu):
+    """LayerNorm folded into the consuming GEMM == LayerNorm followed by Linear (/GEGLU)."""
+    x = rnd("lnl.x", (M, K)) * 1.7 + 0.4                  # rows with a non-zero mean
+    g, be = rnd("lnl.g", (K,)) * 0.2 + 1.0, rnd("lnl.b", (K,)) * 0.2
+    rows = 2 * N if geglu else N
+    w, b = rnd("lnl.w", (rows, K)) * K ** -0.5, rnd("lnl.bias", (rows,))
+    xr, gr, br, wr, bbr = (rounded(t, dtype) for t in (x, g, be, w, b))
+    ref = F.linear(F.layer_norm(xr, (K,), gr, br, 1e-5), wr, bbr)
+    if geglu:
+        ref = orc.geglu(ref)
+    # x itself must come out of a GEMM that emits the row partials: x = x0 @ I + 0 (exact in both dtypes)
+    eye = torch.eye(K)
+    xg, stats = ops.linear(x.to(gpu, dtype), eye.to(gpu, dtype), None, emit_stats=True)
+    assert torch.equal(xg.cpu().float(), xr)
+    s = stats.buf.double().sum(1).cpu()
+    assert torch.allclose(s[:, 0], xr.double().sum(1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[:, 1], (xr.double() ** 2).sum(1), rtol=1e-5, atol=1e-3)
+    wf, c, d = ops.fold_layer_norm(g.to(gpu, dtype), be.to(gpu, dtype), w.to(gpu, dtype), b.to(gpu, dtype))
+    out = ops.ln_linear(xg, stats, wf, c, d, 1e-5, geglu=geglu)
+    assert_close(out, ref, dtype, "ln_linear", factor=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,T,S,H", [(1, 256, 256, 10), (2, 128, 77, 5), (1, 1024, 1024, 20), (1, 100, 33, 2),
                                      (1, 64, 1, 1), (1, 4096, 77, 10)])
 def test_attention(gpu, dtype, B, T, S, H):

@@ -19,5 +19,5 @@ for (T, S, H) in [(4096, 4096, 10), (1024, 1024, 20), (1024, 77, 20)]:
     pr = probe.view(-1, 8).cpu().double()
     u = pr[pr[:, 4] > 0]
     n = u[0, 4].item()
-    print(f"T={T} S={S} H={H}: waves={len(u)} tiles={int(n)} per-tile cycles: loads+QK={u[:,0].mean()/n:.0f} softmax={u[:,1].mean()/n:.0f} "
-          f"PV={u[:,2].mean()/n:.0f} stage+barrier={u[:,3].mean()/n:.0f}")
+    print(f"T={T} S={S} H={H}: waves={len(u)} tiles={int(n)} per-tile cycles: wait+barrier+dma+QKnext={u[:,0].mean()/n:.0f} softmax={u[:,1].mean()/n:.0f} "
+          f"PV={u[:,2].mean()/n:.0f} (unused)={u[:,3].mean()/n:.0f}")

@@ -6,7 +6,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = C.CDLL(os.path.join(root, "stabletriton_amd/lib/probe/libst_probe.so"))
 lib.st_debug_set_probe.argtypes = [C.c_void_p]
 p = C.c_void_p
-lib.st_linear.argtypes = [p, p, p, p, p, p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, p, C.c_size_t, p]
+lib.st_linear.argtypes = [p, p, p, p, p, p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, p, C.c_size_t, p, C.c_int, p, p]
 dev = torch.device("cuda:0")
 for (M, K, N) in [(1024, 1280, 1280), (1024, 5120, 1280), (4096, 640, 640), (1024, 1280, 3840), (77, 2048, 1280), (1, 1280, 1280)]:
     x = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16()
@@ -14,7 +14,7 @@ for (M, K, N) in [(1024, 1280, 1280), (1024, 5120, 1280), (4096, 640, 640), (102
     probe = torch.zeros(4096 * 4 * 8, dtype=torch.int64, device=dev)
     lib.st_debug_set_probe(probe.data_ptr())
     for _ in range(3):
-        lib.st_linear(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), M, N, K, K, N, 0, 0, 0, 1, None, 0, torch.cuda.current_stream().cuda_stream)
+        lib.st_linear(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), M, N, K, K, N, 0, 0, 0, 1, None, 0, None, 0, None, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     pr = probe.view(-1, 8).cpu()
     used = pr[pr[:, 7] > 0].double()

@@ -60,6 +60,22 @@ def linear():
     print(f"linear total per step: {tot / 1e3:.2f} ms")
 
 
+def lnlinear():
+    for M, K, N, geglu in [(1024, 1280, 3840, 0), (1024, 1280, 1280, 0), (1024, 1280, 5120, 1), (4096, 640, 1920, 0), (4096, 640, 2560, 1)]:
+        rows = 2 * N if geglu else N
+        x, w, b, g, be = rnd(M, K), rnd(rows, K) * K ** -0.5, rnd(rows), rnd(K), rnd(K)
+        wf, c, d = ops.fold_layer_norm(g, be, w, b)
+        wp, res = rnd(K, K) * K ** -0.5, rnd(M, K)
+        t_ln = timeit(lambda: ops.layer_norm(x, g, be, 1e-5))
+        t_lin = timeit(lambda: ops.linear(x, w, b, geglu=bool(geglu)))
+        t_p0 = timeit(lambda: ops.linear(x, wp, None, residual=res))
+        t_p1 = timeit(lambda: ops.linear(x, wp, None, residual=res, emit_stats=True))
+        _, st = ops.linear(x, wp, None, residual=res, emit_stats=True)
+        t_f = timeit(lambda: ops.ln_linear(x, st, wf, c, d, 1e-5, geglu=bool(geglu)))
+        print(f"M={M} K={K} N={N} geglu={geglu}: layer_norm {t_ln:6.1f} + linear {t_lin:6.1f} = {t_ln + t_lin:6.1f} us | folded {t_f:6.1f} us"
+              f" + producer stats {t_p1 - t_p0:+5.1f} us (producer {t_p0:5.1f} -> {t_p1:5.1f})")
+
+
 def conv():
     # (Cin, H, Cout, k, stride, ups, count)
     shapes = [(320, 128, 320, 3, 1, 0, 7), (640, 64, 640, 3, 1, 0, 6), (1280, 32, 1280, 3, 1, 0, 10), (2560, 32, 1280, 3, 1, 0, 2),
@@ -112,6 +128,6 @@ def norm():
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
-    for name, fn in (("linear", linear), ("conv", conv), ("attn", attn), ("norm", norm)):
+    for name, fn in (("linear", linear), ("lnlinear", lnlinear), ("conv", conv), ("attn", attn), ("norm", norm)):
         if what in (name, "all"):
             fn()
