@@ -761,12 +761,17 @@ template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool 
 static void launch_dma(const GemmArgs& a, hipStream_t st) {
     if constexpr (!CONV) {
         const bool geglu = a.epi & ST_EPI_GEGLU;
+        constexpr bool PAIRS = ((BN / WGN / 16) % 2 == 0);      // GEGLU pairs value/gate n-tiles inside a wave
         if (a.ln_c) {          // LayerNorm-folded variants (never split over K: the row statistics need all of K)
-            if (geglu) launch_dma_one<T, BM, BN, WGM, WGN, STAGES, U, false, true, true>(a, st, cdiv(a.N, BN / 2));
-            else launch_dma_one<T, BM, BN, WGM, WGN, STAGES, U, false, false, true>(a, st, cdiv(a.N, BN));
+            if constexpr (PAIRS) {
+                if (geglu) { launch_dma_one<T, BM, BN, WGM, WGN, STAGES, U, false, true, true>(a, st, cdiv(a.N, BN / 2)); return; }
+            }
+            launch_dma_one<T, BM, BN, WGM, WGN, STAGES, U, false, false, true>(a, st, cdiv(a.N, BN));
             return;
         }
-        if (geglu) { launch_dma_one<T, BM, BN, WGM, WGN, STAGES, U, false, true, false>(a, st, cdiv(a.N, BN / 2)); return; }
+        if constexpr (PAIRS) {
+            if (geglu) { launch_dma_one<T, BM, BN, WGM, WGN, STAGES, U, false, true, false>(a, st, cdiv(a.N, BN / 2)); return; }
+        }
     }
     launch_dma_one<T, BM, BN, WGM, WGN, STAGES, U, CONV, false, false>(a, st, cdiv(a.N, BN));
 }
@@ -775,14 +780,15 @@ static void launch_dma(const GemmArgs& a, hipStream_t st) {
 // overrides the heuristic for A/B runs.
 enum { CFG_64x64_S4 = 0, CFG_64x64_S8 = 1, CFG_64x64_S4_U2 = 2, CFG_128x64_S4 = 3, CFG_128x64_S3_U2 = 4,
        CFG_128x128_S3 = 5, CFG_64x64_S3 = 6, CFG_64x64_W8 = 7, CFG_128x64_W8 = 8, CFG_128x128_W8 = 9,
-       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_COUNT };
+       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_128x320_W8 = 23, CFG_128x256_W8 = 24, CFG_64x320_W8 = 25, CFG_COUNT };
 
 static int cfg_bn(int cfg) {
     switch (cfg) {
         case CFG_64x64_S4: case CFG_64x64_S8: case CFG_64x64_S4_U2: case CFG_128x64_S4: case CFG_128x64_S3_U2: case CFG_64x64_S3:
         case CFG_64x64_W8: case CFG_128x64_W8: case CFG_128x64_W8_S6: case CFG_64x64_W8_S8: case CFG_128x64_W8_U2:
         case CFG_64x64_W8_U2: case CFG_128x64_W8_S3: return 64;
-        case CFG_256x256_W8: return 256;
+        case CFG_256x256_W8: case CFG_128x256_W8: return 256;
+        case CFG_128x320_W8: case CFG_64x320_W8: return 320;
         default: return 128;
     }
 }
@@ -819,10 +825,11 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
         // 64 B/clk, MFMA time) + a fixed sync overhead, and a partly filled last round costs a full one.
         struct Cand { int cfg, bm, bn; };
         static const Cand cands[] = {{CFG_128x128_W8, 128, 128}, {CFG_64x128_W8, 64, 128}, {CFG_128x64_W8, 128, 64},
-                                     {CFG_64x64_W8, 64, 64}};
+                                     {CFG_64x64_W8, 64, 64}, {CFG_128x320_W8, 128, 320}, {CFG_64x320_W8, 64, 320}};
         int cfg = CFG_64x64_W8;
         double best = 1e30;
         for (const Cand& c : cands) {
+            if ((a.epi & ST_EPI_GEGLU) && c.cfg == CFG_64x320_W8) continue;      // odd n-tiles per wave: no value/gate pairing
             const long blocks = tiles(c.bm, c.bn);
             const double rounds = (double)((blocks + 255) / 256);
             const double ta = 2.0 * (c.bm + c.bn), mf = c.bm * c.bn / 32.0;
@@ -848,6 +855,12 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             if (sk > nk) sk = nk;
             if (sk > 1) { cfg = CFG_256x128_W8; b.splitk = sk; }
         }
+#ifdef ST_DEV_CONFIGS
+        {   // dev knob: override only the small-problem class (fewer than 150 tiles of 128x128)
+            static const int small_cfg = [] { const char* e = getenv("ST_GEMM_SMALL_CFG"); return e ? atoi(e) : -1; }();
+            if (small_cfg >= 0 && small_cfg < CFG_COUNT && tiles(128, 128) < 150 && sk == 1) cfg = small_cfg;
+        }
+#endif
         const int f = forced_cfg();
         if (f >= 0 && f < CFG_COUNT) {
             const bool u2 = (f == CFG_64x64_S4_U2 || f == CFG_128x64_S3_U2 || f == CFG_64x128_W8_U2 || f == CFG_128x64_W8_U2 ||
@@ -862,7 +875,10 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             case CFG_128x64_W8: launch_dma<T, 128, 64, 4, 2, 4, 1, CONV>(b, st); break;
             case CFG_64x128_W8: launch_dma<T, 64, 128, 2, 4, 4, 1, CONV>(b, st); break;
             case CFG_256x128_W8: launch_dma<T, 256, 128, 4, 2, 3, 1, CONV>(b, st); break;
-#ifdef ST_DEV_CONFIGS       // tile/pipeline variants kept for A/B sweeps (tools/op_bench.py with ST_GEMM_FORCE)
+            case CFG_128x320_W8: launch_dma<T, 128, 320, 4, 2, 2, 1, CONV>(b, st); break;
+            case CFG_64x320_W8: launch_dma<T, 64, 320, 2, 4, 3, 1, CONV>(b, st); break;
+#ifdef ST_DEV_CONFIGS
+            case CFG_128x256_W8: launch_dma<T, 128, 256, 4, 2, 3, 1, CONV>(b, st); break;       // tile/pipeline variants kept for A/B sweeps (tools/op_bench.py with ST_GEMM_FORCE)
             case CFG_64x64_S4: launch_dma<T, 64, 64, 2, 2, 4, 1, CONV>(b, st); break;
             case CFG_64x64_S8: launch_dma<T, 64, 64, 2, 2, 8, 1, CONV>(b, st); break;
             case CFG_64x64_S4_U2: launch_dma<T, 64, 64, 2, 2, 4, 2, CONV>(b, st); break;
