@@ -51,22 +51,35 @@ def build_model(dev, dtype, rank, world):
 
 
 def census(loop):
-    """One eager step with HIP events around every operator launch (same stream)."""
+    """One eager step with HIP events around every operator launch (same stream).
+
+    The host needs ~20-40 us of Python per launch, more than most kernels run, so a naive eager
+    pass would time an idle GPU waiting for the host.  The measured step is therefore enqueued
+    behind a spin kernel: by the time the GPU reaches it every launch and event record is already
+    in the queue, kernels run back to back as in the graph, and event deltas are device times."""
     store = []
     loop_mode, loop.mode = loop.mode, "eager"
     ops.set_census(None)
     loop.run_steps(1)                      # warm the eager path
     torch.cuda.synchronize()
+    step0 = int(loop.step.item())
+    torch.cuda._sleep(int(6e8))            # ~0.25 s head start for the host
+    # cost of the event pair itself (nothing launched in between), measured in the same queued regime
+    empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+    for a, b in empty:
+        a.record(); b.record()
     ops.set_census(store)
-    loop.run_steps(1)
-    torch.cuda.synchronize()
+    for i in range(1):
+        loop._step_const((step0 + i) % loop.n_steps)
     ops.set_census(None)
+    torch.cuda.synchronize()
     loop.mode = loop_mode
+    pair_ms = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
     fam = {}
     for name, flops, nbytes, e0, e1 in store:
         f = fam.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
         f["launches"] += 1
-        f["ms"] += e0.elapsed_time(e1)
+        f["ms"] += max(e0.elapsed_time(e1) - pair_ms, 0.0)
         f["flops"] += flops
         f["bytes"] += nbytes
     return fam
