@@ -16,7 +16,7 @@ import torch
 from torch import fx, nn
 
 from . import _C
-from .optimizers import (fuse_attention, fuse_geglu, fuse_geglu_into_linear, fuse_layernorm_into_linear, fuse_residual_adds,
+from .optimizers import (dedupe_pure_calls, fuse_token_residual, fuse_attention, fuse_geglu, fuse_geglu_into_linear, fuse_layernorm_into_linear, fuse_residual_adds,
                          fuse_shared_input_linears,
                          fuse_temb_add, fuse_timesteps, split_context, keep_channels_last, make_dynamic_graphed_callable, remove_dropout,
                          replace_conv, replace_group_norm, replace_group_norm_activation, replace_layer_norm,
@@ -29,6 +29,8 @@ def replace_backend(gm: fx.GraphModule, fuse: bool = True) -> fx.GraphModule:
     product here), replace_conv / epilogue fusions / layout are additions."""
     stats: Dict[str, int] = {}
     stats["dropout"] = remove_dropout(gm)
+    if fuse:
+        stats["deduped_activations"] = dedupe_pure_calls(gm)
     stats["attention"] = fuse_attention(gm)
     stats["geglu"] = fuse_geglu(gm)
     stats["linear_silu"] = replace_linear_activ(gm, nn.SiLU())
@@ -42,6 +44,7 @@ def replace_backend(gm: fx.GraphModule, fuse: bool = True) -> fx.GraphModule:
         stats["geglu_in_gemm"] = fuse_geglu_into_linear(gm)
         stats["temb_rowbias"] = fuse_temb_add(gm)
         stats["residual_adds"] = fuse_residual_adds(gm)
+        stats["token_residuals"] = fuse_token_residual(gm)
         stats["shared_input_gemms"] = fuse_shared_input_linears(gm)
         stats["layer_norm_in_gemm"] = fuse_layernorm_into_linear(gm)
     stats["channels_last_views"] = keep_channels_last(gm)
