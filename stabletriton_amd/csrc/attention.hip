@@ -255,6 +255,190 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restri
     }
 }
 
+// ---- 16-row variant (v_mfma_f32_16x16x32_bf16): one wave owns 16 query rows ----
+// Half the rows per wave doubles the wave count of a launch (the SDXL shapes give only 1.25 waves per
+// SIMD with 32-row waves) and halves the live accumulators (S 16 + O 16 registers), so several waves
+// share a SIMD and one wave's MFMAs run under another's softmax without any software pipelining.
+//   S^T[key][q] = K Q^T : A = K rows (lane: key = l&15, d = 32ks + 8g..), B = Q^T (lane: q = l&15, same d)
+//                         D: lane (q = l&15, g = l>>4) holds keys 16kb + 4g + r
+//   O^T[d][q]  += V^T P^T: B = P^T straight from the S registers of key blocks (2kp, 2kp+1): k-slot
+//                         8g + j <-> key 32kp + 16(j>>2) + 4g + (j&3); A = V^T through two transposed
+//                         4x16 block reads per fragment that follow the same key order.
+__device__ __forceinline__ int swz_k16(int row) { return row & 7; }
+__device__ __forceinline__ int swz_v16(int row) { return ((row >> 1) & 3) << 1; }
+
+struct VTile16 { u32x2 r[2][4][2]; };      // [key pair-block kp][d-block][key-half n]
+
+__device__ __forceinline__ void v16_issue(VTile16& v, unsigned b0, unsigned b1, unsigned b2, unsigned b3) {
+#define TR(dst, base, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #off : "=v"(dst) : "v"(base))
+    TR(v.r[0][0][0], b0, 0);    TR(v.r[0][0][1], b0, 2048); TR(v.r[0][1][0], b1, 0);    TR(v.r[0][1][1], b1, 2048);
+    TR(v.r[0][2][0], b2, 0);    TR(v.r[0][2][1], b2, 2048); TR(v.r[0][3][0], b3, 0);    TR(v.r[0][3][1], b3, 2048);
+    TR(v.r[1][0][0], b0, 4096); TR(v.r[1][0][1], b0, 6144); TR(v.r[1][1][0], b1, 4096); TR(v.r[1][1][1], b1, 6144);
+    TR(v.r[1][2][0], b2, 4096); TR(v.r[1][2][1], b2, 6144); TR(v.r[1][3][0], b3, 4096); TR(v.r[1][3][1], b3, 6144);
+#undef TR
+}
+
+__device__ __forceinline__ void v16_wait(VTile16& v) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(v.r[0][0][0]), "+v"(v.r[0][0][1]), "+v"(v.r[0][1][0]), "+v"(v.r[0][1][1]),
+                   "+v"(v.r[0][2][0]), "+v"(v.r[0][2][1]), "+v"(v.r[0][3][0]), "+v"(v.r[0][3][1]),
+                   "+v"(v.r[1][0][0]), "+v"(v.r[1][0][1]), "+v"(v.r[1][1][0]), "+v"(v.r[1][1][1]),
+                   "+v"(v.r[1][2][0]), "+v"(v.r[1][2][1]), "+v"(v.r[1][3][0]), "+v"(v.r[1][3][1])
+                 :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn16_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                              const bf16* __restrict__ V, bf16* __restrict__ O,
+                                                              int T, int S, long ldq, long ldk, long ldv, long ldo, float scale_log2e) {
+    constexpr int TILE_B = ATT_KV * 128;
+    constexpr int BUF_B = 2 * TILE_B;
+    constexpr int PIECES = 16 / NW;
+    static_assert(NW <= 16 && 16 % NW == 0, "waves must divide the 16 DMA pieces of a tile");
+    __shared__ __attribute__((aligned(16))) char lds[3 * BUF_B];
+
+    const int t_ = threadIdx.x, lane = t_ & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t_ >> 6);
+    const int c16 = lane & 15, g = lane >> 4;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = (blockIdx.x * NW + wave) * 16;
+    const int qrow = min(q0 + c16, T - 1);
+
+    const bf16* Qb = Q + (size_t)b * T * ldq + (size_t)head * ATT_D;
+    const bf16* Kb = K + (size_t)b * S * ldk + (size_t)head * ATT_D;
+    const bf16* Vb = V + (size_t)b * S * ldv + (size_t)head * ATT_D;
+    const bf16* zeros = reinterpret_cast<const bf16*>(g_att_zero16);
+
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (size_t)qrow * ldq + 32 * ks + 8 * g);
+
+    const int lr = lane >> 3, pc = lane & 7;
+    auto dma_tile = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int pce = wave * PIECES + i;
+            const int isv = pce >> 3, rb = pce & 7;
+            const int row = rb * 8 + lr;
+            const int key = kt * ATT_KV + row;
+            const int c = pc ^ (isv ? swz_v16(row) : swz_k16(row));
+            const bf16* src = isv ? Vb + (size_t)key * ldv + c * 8 : Kb + (size_t)key * ldk + c * 8;
+            if (key >= S) src = zeros;
+            __builtin_amdgcn_global_load_lds((att_gbl_cvoid_t*)src, (att_lds_void_t*)(lds + buf * BUF_B + isv * TILE_B + rb * 1024), 16, 0, 0);
+        }
+    };
+
+    // lane-constant LDS offsets of the fragment reads
+    const int k_off0 = c16 * 128 + (((0 + g) ^ swz_k16(c16)) << 4);       // d-step 0; key block kb adds kb*2048
+    const int k_off1 = c16 * 128 + (((4 + g) ^ swz_k16(c16)) << 4);       // d-step 1
+    const int vkey = 4 * g + (c16 >> 2);
+    const int vsw = swz_v16(vkey);
+    const int vrow = vkey * 128 + 8 * (c16 & 1);
+    const int vbit = (c16 & 3) >> 1;
+    const int v_off0 = vrow + (((0 ^ vsw) + vbit) << 4), v_off1 = vrow + (((2 ^ vsw) + vbit) << 4);
+    const int v_off2 = vrow + (((4 ^ vsw) + vbit) << 4), v_off3 = vrow + (((6 ^ vsw) + vbit) << 4);
+
+    f32x4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -1e30f, l = 0.f;
+    const int nkt = (S + ATT_KV - 1) / ATT_KV;
+
+    dma_tile(0, 0);
+    if (nkt > 1) dma_tile(1, 1);
+
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int nb = cur == 2 ? 0 : cur + 1;
+        const int fb = nb == 2 ? 0 : nb + 1;
+        // own pieces of tile kt have landed (tile kt+1 may still be in flight) ...
+        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // ... and everyone's; tile kt-1 is dead
+        if (kt + 2 < nkt) dma_tile(kt + 2, fb);
+
+        const char* kb_ = lds + cur * BUF_B;
+        f32x4 s[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kb_ + kb * 2048 + k_off0);
+            const bf16x8 kc = *reinterpret_cast<const bf16x8*>(kb_ + kb * 2048 + k_off1);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[0], acc, 0, 0, 0);
+            s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc, qf[1], acc, 0, 0, 0);
+        }
+        // V^T fragments: issued now, retired after the softmax arithmetic
+        VTile16 vt;
+        {
+            const unsigned vb = lds_addr(lds + cur * BUF_B + TILE_B);
+            v16_issue(vt, vb + v_off0, vb + v_off1, vb + v_off2, vb + v_off3);
+        }
+        if ((kt + 1) * ATT_KV > S) {
+            const int kbase = kt * ATT_KV + 4 * g;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kbase + 16 * kb + r >= S) s[kb][r] = -INFINITY;
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx * scale_log2e);
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[kb][r] = fast_exp2(fmaf(s[kb][r], scale_log2e, -m_new));
+                rs += s[kb][r];
+            }
+        if (__any(m_new != m)) {
+            const float alpha = fast_exp2(m - m_new);
+            l *= alpha;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[db][r] *= alpha;
+            m = m_new;
+        }
+        l += rs;
+        v16_wait(vt);
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) {
+            bf16x8 pb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { pb[j] = (bf16)s[2 * kp][j]; pb[4 + j] = (bf16)s[2 * kp + 1][j]; }
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                u32x4 w = {vt.r[kp][db][0][0], vt.r[kp][db][0][1], vt.r[kp][db][1][0], vt.r[kp][db][1][1]};
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), pb, o[db], 0, 0, 0);
+            }
+        }
+        cur = nb;
+    }
+
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (q0 + c16 < T) {
+        bf16* orow = O + (size_t)b * T * ldo + (size_t)(q0 + c16) * ldo + (size_t)head * ATT_D;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            bf16x4 a_;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a_[e] = (bf16)(o[db][e] * inv);
+            *reinterpret_cast<bf16x4*>(orow + 16 * db + 4 * g) = a_;
+        }
+    }
+}
+
 // ---- fp32 strict kernel: thread = one query row, keys in tiles of 32 via LDS ----
 __global__ __launch_bounds__(128) void attn_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                        const float* __restrict__ V, float* __restrict__ O, int T, int S,
@@ -352,6 +536,20 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
         // waves wins over more blocks; 8 waves once that still leaves >= 128 blocks, else 4
         int nw = ((long)cdiv(T, 256) * H * B >= 128 && S > 256) ? 8 : 4;
         if (force_nw == 1 || force_nw == 2 || force_nw == 4 || force_nw == 8) nw = force_nw;
+        static const int rows16 = [] { const char* e = getenv("ST_ATT_R16"); return e ? atoi(e) : 0; }();
+        if (rows16 == 16) {
+            hipLaunchKernelGGL(attn16_bf16_kernel<16>, dim3(cdiv(T, 256), H, B), dim3(1024), 0, st, (const bf16*)q, (const bf16*)k,
+                               (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c);
+            return st_check_launch("attention");
+        } else if (rows16 == 8) {
+            hipLaunchKernelGGL(attn16_bf16_kernel<8>, dim3(cdiv(T, 128), H, B), dim3(512), 0, st, (const bf16*)q, (const bf16*)k,
+                               (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c);
+            return st_check_launch("attention");
+        } else if (rows16 == 4) {
+            hipLaunchKernelGGL(attn16_bf16_kernel<4>, dim3(cdiv(T, 64), H, B), dim3(256), 0, st, (const bf16*)q, (const bf16*)k,
+                               (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c);
+            return st_check_launch("attention");
+        }
         if (nw == 8)
             hipLaunchKernelGGL(attn_bf16_kernel<8>, dim3(cdiv(T, 256), H, B), dim3(512), 0, st, (const bf16*)q, (const bf16*)k,
                                (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c, ATT_PROBE_ARG);

@@ -79,12 +79,38 @@ template <> struct Out4<float> {
     }
 };
 
+#ifdef ST_PROBE
+__device__ __forceinline__ unsigned long long probe_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define PROBE_DECL unsigned long long pr_t0 = 0, pr_a = 0, pr_b = 0, pr_c = 0, pr_d = 0, pr_x = 0; (void)pr_x;
+#define PROBE_STAMP(var) unsigned long long var = probe_now();
+#define PROBE_ADD(acc, t1, t0) acc += (t1) - (t0);
+#else
+#define PROBE_DECL
+#define PROBE_STAMP(var)
+#define PROBE_ADD(acc, t1, t0)
+#endif
+
+template <typename T> struct Raw4 { typedef bf16x4 type; };
+template <> struct Raw4<float> { typedef f32x4 type; };
+template <typename T> __device__ __forceinline__ typename Raw4<T>::type ld_raw4(const T* p) {
+    return *reinterpret_cast<const typename Raw4<T>::type*>(p);
+}
+
 // ---- shared epilogue ---------------------------------------------------------------------------
 // One output row m, 4 consecutive columns n..n+3: v = accumulators (value half), g = gate half (GEGLU).
+// epilogue_compute4 does every load and all the arithmetic and leaves the final values in v;
+// epilogue_put4 stores them.  The tile kernels run compute over ALL their tiles before the first
+// store: on gfx950 vmcnt counts stores too, so a load issued after a store waits for that store's
+// write acknowledgement (a microsecond under load) -- interleaved load/store tiles serialise on it.
 template <typename T, bool GEGLU>
-__device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n, float (&v)[4], const float (&g_in)[4],
-                                                float ln_mean = 0.f, float ln_rstd = 0.f) {
-    T* __restrict__ Cp = (T*)p.C;
+__device__ __forceinline__ void epilogue_compute4(const GemmArgs& p, int m, int n, float (&v)[4], const float (&g_in)[4],
+                                                  float ln_mean = 0.f, float ln_rstd = 0.f) {
     const T* __restrict__ bias = (const T*)p.bias;
     const T* __restrict__ Rp = (const T*)p.residual;
     const T* __restrict__ RBp = (const T*)p.rowbias;
@@ -128,7 +154,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n,
             }
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_f(g[e]);
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_for<T>(g[e]);
     }
     if (p.epi & ST_EPI_SILU) {
 #pragma unroll
@@ -152,11 +178,22 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n,
             for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(rr[e]);
         }
     }
-    T* dst = Cp + (size_t)m * p.ldc + n;
-    if (full) Out4<T>::store(dst, v);
-    else for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = Elem<T>::from_f(v[e]);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (n + e < p.N) ? Elem<T>::to_f(Elem<T>::from_f(v[e])) : 0.f;   // what was stored
+    for (int e = 0; e < 4; ++e) v[e] = (n + e < p.N) ? Elem<T>::to_f(Elem<T>::from_f(v[e])) : 0.f;   // what will be stored
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue_put4(const GemmArgs& p, int m, int n, const float (&v)[4]) {
+    T* dst = (T*)p.C + (size_t)m * p.ldc + n;
+    if (n + 3 < p.N) Out4<T>::store(dst, v);
+    else for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = Elem<T>::from_f(v[e]);
+}
+
+template <typename T, bool GEGLU>
+__device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n, float (&v)[4], const float (&g_in)[4],
+                                                float ln_mean = 0.f, float ln_rstd = 0.f) {
+    epilogue_compute4<T, GEGLU>(p, m, n, v, g_in, ln_mean, ln_rstd);
+    epilogue_put4<T>(p, m, n, v);
 }
 
 // lane (r16, q) holds rows m = .. + r16, columns n = .. + 4q .. 4q+3 of every 16x16 tile.
@@ -164,43 +201,148 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n,
 template <typename T, int TM, int TN, int WTM, int WTN, bool GEGLU, int WGM_ = 0, int WGN_ = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
                                               int r16, int q, int split = 0, const float* row_mean = nullptr,
-                                              const float* row_rstd = nullptr, char* lds_scratch = nullptr, int tile_n = 0) {
+                                              const float* row_rstd = nullptr, char* lds_scratch = nullptr, int tile_n = 0,
+                                              unsigned long long* ptimes = nullptr) {
     float rs1[TM], rs2[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) { rs1[i] = 0.f; rs2[i] = 0.f; }
     constexpr int TNO = GEGLU ? TN / 2 : TN;
     constexpr int WTNO = GEGLU ? WTN / 2 : WTN;
     const int ncols = GEGLU ? 2 * p.N : p.N;          // columns of one partial slab
+    if (p.splitk > 1) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WTM + i * 16 + r16;
-        if (m >= p.M) continue;
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + r16;
+            if (m >= p.M) continue;
 #pragma unroll
-        for (int j = 0; j < TNO; ++j) {
-            const int n = n0 + wn * WTNO + j * 16 + 4 * q;
-            if (n >= p.N) continue;
-            float v[4], g[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
-            if (GEGLU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = acc[i][j + (GEGLU ? TN / 2 : 0)][e];
-            }
-            if (p.splitk > 1) {
+            for (int j = 0; j < TNO; ++j) {
+                const int n = n0 + wn * WTNO + j * 16 + 4 * q;
+                if (n >= p.N) continue;
                 float* slab = p.partial + ((size_t)split * p.M + m) * ncols;
                 if (n + 3 < p.N) {
-                    Out4<float>::store(slab + n, v);
-                    if (GEGLU) Out4<float>::store(slab + p.N + n, g);
+                    *reinterpret_cast<f32x4*>(slab + n) = acc[i][j];
+                    if (GEGLU) *reinterpret_cast<f32x4*>(slab + p.N + n) = acc[i][j + (GEGLU ? TN / 2 : 0)];
                 } else {
-                    for (int e = 0; e < 4 && n + e < p.N; ++e) { slab[n + e] = v[e]; if (GEGLU) slab[p.N + n + e] = g[e]; }
+                    for (int e = 0; e < 4 && n + e < p.N; ++e) { slab[n + e] = acc[i][j][e]; if (GEGLU) slab[p.N + n + e] = acc[i][j + (GEGLU ? TN / 2 : 0)][e]; }
                 }
-            } else {
+            }
+        }
+    } else if ((p.N & 3) != 0) {
+        // ragged N: per-tile loads, arithmetic and element stores
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + r16;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TNO; ++j) {
+                const int n = n0 + wn * WTNO + j * 16 + 4 * q;
+                if (n >= p.N) continue;
+                float v[4], g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = acc[i][j][e]; if (GEGLU) g[e] = acc[i][j + (GEGLU ? TN / 2 : 0)][e]; }
                 epilogue_store4<T, GEGLU>(p, m, n, v, g, row_mean ? row_mean[i] : 0.f, row_rstd ? row_rstd[i] : 0.f);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { rs1[i] += v[e]; rs2[i] = fmaf(v[e], v[e], rs2[i]); }
             }
         }
+    } else {
+        // Three passes: every load (unconditional, clamped addresses, so they all go out back to back
+        // and cost ONE round trip), then the arithmetic, then nothing but stores.  On gfx950 vmcnt
+        // counts stores too, so a load behind a store would also wait for that store's acknowledgement.
+        typedef typename Raw4<T>::type R4;
+        const bool has_bias = p.epi & ST_EPI_BIAS, has_res = p.epi & ST_EPI_RESIDUAL, has_rb = p.epi & ST_EPI_ROWBIAS;
+        const bool has_ln = p.ln_c != nullptr, do_silu = p.epi & ST_EPI_SILU;
+        int ncol[TNO], mrow[TM];
+        bool nok[TNO], mok[TM];
+#pragma unroll
+        for (int j = 0; j < TNO; ++j) { const int n = n0 + wn * WTNO + j * 16 + 4 * q; nok[j] = n < p.N; ncol[j] = nok[j] ? n : 0; }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { const int m = m0 + wm * WTM + i * 16 + r16; mok[i] = m < p.M; mrow[i] = mok[i] ? m : 0; }
+        R4 braw[TNO] = {}, graw[TNO] = {};
+        f32x4 cv[TNO] = {}, dv[TNO] = {}, cg[TNO] = {}, dg[TNO] = {};
+        R4 rres[TM][TNO] = {}, rrb[TM][TNO] = {};
+        const T* __restrict__ bias = (const T*)p.bias;
+        if (has_bias) {
+#pragma unroll
+            for (int j = 0; j < TNO; ++j) { braw[j] = ld_raw4<T>(bias + ncol[j]); if (GEGLU) graw[j] = ld_raw4<T>(bias + p.N + ncol[j]); }
+        }
+        if (has_ln) {
+#pragma unroll
+            for (int j = 0; j < TNO; ++j) {
+                cv[j] = *reinterpret_cast<const f32x4*>(p.ln_c + ncol[j]); dv[j] = *reinterpret_cast<const f32x4*>(p.ln_d + ncol[j]);
+                if (GEGLU) { cg[j] = *reinterpret_cast<const f32x4*>(p.ln_c + p.N + ncol[j]); dg[j] = *reinterpret_cast<const f32x4*>(p.ln_d + p.N + ncol[j]); }
+            }
+        }
+        if (has_rb) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TNO; ++j) rrb[i][j] = ld_raw4<T>((const T*)p.rowbias + (size_t)(mrow[i] / p.rows_per_batch) * p.N + ncol[j]);
+        }
+        if (has_res) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TNO; ++j) rres[i][j] = ld_raw4<T>((const T*)p.residual + (size_t)mrow[i] * p.ldr + ncol[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float mean = row_mean ? row_mean[i] : 0.f, rstd = row_rstd ? row_rstd[i] : 0.f;
+#pragma unroll
+            for (int j = 0; j < TNO; ++j) {
+                float v[4], g[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = acc[i][j][e]; g[e] = GEGLU ? acc[i][j + (GEGLU ? TN / 2 : 0)][e] : 0.f; }
+                if (has_ln) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = rstd * (v[e] - mean * cv[j][e]) + dv[j][e];
+                        if (GEGLU) g[e] = rstd * (g[e] - mean * cg[j][e]) + dg[j][e];
+                    }
+                }
+                if (has_bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += Elem<T>::to_f(braw[j][e]); if (GEGLU) g[e] += Elem<T>::to_f(graw[j][e]); }
+                }
+                if (GEGLU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= gelu_for<T>(g[e]);
+                }
+                if (do_silu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                }
+                if (has_rb) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f(rrb[i][j][e]);
+                }
+                if (has_res) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f(rres[i][j][e]);
+                }
+                const bool live = mok[i] && nok[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = live ? Elem<T>::to_f(Elem<T>::from_f(v[e])) : 0.f;      // what is stored
+                    rs1[i] += v[e]; rs2[i] = fmaf(v[e], v[e], rs2[i]); acc[i][j][e] = v[e];
+                }
+            }
+        }
+#ifdef ST_PROBE
+        if (ptimes) ptimes[0] = probe_now();
+#endif
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TNO; ++j)
+                if (mok[i] && nok[j]) {
+                    const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    Out4<T>::store((T*)p.C + (size_t)mrow[i] * p.ldc + ncol[j], v);
+                }
     }
+#ifdef ST_PROBE
+    if (ptimes) ptimes[1] = probe_now();
+#endif
     if constexpr (WGN_ > 0) {
         // LayerNorm partials of the rows this block just stored (consumed by the next st_ln_linear):
         // lane sums -> the four q lanes -> the WGN waves of this tile row (through LDS) -> one float2
@@ -450,22 +592,6 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-#ifdef ST_PROBE
-__device__ __forceinline__ unsigned long long probe_now() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-#define PROBE_DECL unsigned long long pr_t0 = 0, pr_a = 0, pr_b = 0, pr_c = 0, pr_d = 0, pr_x = 0; (void)pr_x;
-#define PROBE_STAMP(var) unsigned long long var = probe_now();
-#define PROBE_ADD(acc, t1, t0) acc += (t1) - (t0);
-#else
-#define PROBE_DECL
-#define PROBE_STAMP(var)
-#define PROBE_ADD(acc, t1, t0)
-#endif
 
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV, bool GEGLU, bool LNF = false>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs p) {
@@ -551,6 +677,40 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         b_adv[i] = ok ? KB : 0;
     }
 
+    // Touch the epilogue's operands now (one dword per 128-byte line, value unused): they are first
+    // read after the K loop, where a miss to HBM would be fully exposed.  These loads are older than
+    // every DMA, so the counted vmcnt waits below retire them for free.
+    // The destination register stays reserved (touch_sink is "used" after the prologue wait that
+    // retires the loads), so a late return cannot land in a register that has been given away.
+    unsigned int touch_sink = 0;
+    if (p.splitk <= 1) {
+        constexpr int NT_ = NW * 64;
+        const int ncols_out = min(BNO, p.N - n0);                      // output columns of this tile
+        auto touch_at = [&](const char* a) {
+            a = (const char*)((uintptr_t)a & ~(uintptr_t)3);
+            asm volatile("global_load_dword %0, %1, off" : "+v"(touch_sink) : "v"(a) : "memory");
+        };
+        auto touch = [&](const void* base, long byte_off, int nbytes) {
+            for (int o = t * 128; o < nbytes; o += NT_ * 128) touch_at((const char*)base + byte_off + o);
+        };
+        if (p.epi & ST_EPI_BIAS) {
+            touch(p.bias, (long)n0 * sizeof(T), ncols_out * (int)sizeof(T));
+            if (GEGLU) touch(p.bias, ((long)p.N + n0) * sizeof(T), ncols_out * (int)sizeof(T));
+        }
+        if (LNF) {
+            touch(p.ln_c, (long)n0 * 4, ncols_out * 4); touch(p.ln_d, (long)n0 * 4, ncols_out * 4);
+            if (GEGLU) { touch(p.ln_c, ((long)p.N + n0) * 4, ncols_out * 4); touch(p.ln_d, ((long)p.N + n0) * 4, ncols_out * 4); }
+        }
+        if (p.epi & ST_EPI_RESIDUAL) {
+            const int lines = (ncols_out * (int)sizeof(T) + 127) / 128;      // per row
+            const int rows = min(BM, p.M - m0);
+            for (int o = t; o < rows * lines; o += NT_) {
+                const int r = o / lines, l = o - r * lines;
+                touch_at((const char*)p.residual + ((size_t)(m0 + r) * p.ldr + n0) * sizeof(T) + l * 128);
+            }
+        }
+    }
+
     // K range of this block in stages (host guarantees K % (KB*U) == 0); split-K slices are balanced
     const int nk_all = p.K / (KB * U);
     const int nk_lo = (int)((long)split * nk_all / p.splitk), nk_hi = (int)((long)(split + 1) * nk_all / p.splitk);
@@ -601,11 +761,48 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     const int r16 = lane & 15, q = lane >> 4;
     const int nk = nk_hi - nk_lo;
 
+    // LayerNorm-folded GEMM: the producer left per-row (sum, sum of squares) partials, one float2 per
+    // (row, producer N tile).  TPR adjacent threads share a row: each loads every TPR-th partial (all
+    // loads unconditional with clamped indices, so they cost one round trip, issued ahead of the
+    // prologue DMA), a fixed-order butterfly adds them, and (mean, rstd) wait in LDS for the epilogue.
+    constexpr int TPR = NW * 64 / BM;
+    constexpr int LN_UNROLL = 8;
+    float2 ln_part[LN_UNROLL];
+    if constexpr (LNF) {
+        static_assert(TPR >= 1 && TPR <= 64 && (TPR & (TPR - 1)) == 0, "threads per row must be a power of two");
+        const float2* st2 = reinterpret_cast<const float2*>(p.ln_stats);
+        const int row = t / TPR, part = t - row * TPR;
+        const int m = min(m0 + row, p.M - 1);
+#pragma unroll
+        for (int k_ = 0; k_ < LN_UNROLL; ++k_) {
+            const int c = part + k_ * TPR;
+            ln_part[k_] = st2[(size_t)m * p.ln_chunks + (c < p.ln_chunks ? c : 0)];
+        }
+    }
 #pragma unroll
     for (int s_ = 0; s_ < STAGES - 1; ++s_)
         if (s_ < nk) issue(s_, s_);
+    if constexpr (LNF) {
+        const float2* st2 = reinterpret_cast<const float2*>(p.ln_stats);
+        const int row = t / TPR, part = t - row * TPR;
+        const int m = min(m0 + row, p.M - 1);
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k_ = 0; k_ < LN_UNROLL; ++k_) {
+            const bool ok = part + k_ * TPR < p.ln_chunks;
+            a1 += ok ? ln_part[k_].x : 0.f; a2 += ok ? ln_part[k_].y : 0.f;
+        }
+        for (int c = part + LN_UNROLL * TPR; c < p.ln_chunks; c += TPR) { const float2 v = st2[(size_t)m * p.ln_chunks + c]; a1 += v.x; a2 += v.y; }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+        const float mean = a1 / (float)p.K;
+        const float rstd = rsqrtf(fmaxf(a2 / (float)p.K - mean * mean, 0.f) + p.ln_eps);
+        if (part == 0) reinterpret_cast<float2*>(lds + STAGES * STAGE)[row] = make_float2(mean, rstd);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // written before the raw barrier below
+    }
     if (nk >= STAGES - 1) wait_vmcnt<(STAGES - 2) * G>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::"v"(touch_sink));            // the touch loads have returned by now
 
     // Software pipeline (one wave per SIMD has nobody else to hide LDS latency behind):
     // the fragments of MFMA group g+1 are read while group g multiplies, and the LAST group
@@ -697,31 +894,29 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     wait_vmcnt<0>();                              // no LDS-DMA may outlive the workgroup's LDS allocation
     PROBE_STAMP(pr_end)
     if constexpr (LNF) {
-        // LayerNorm statistics of this lane's rows from the producer's per-tile partials: the four q
-        // lanes of a row each sum every fourth partial, then a two-step butterfly (fixed order)
         float mean[TM], rstd[TM];
-        const float2* st2 = reinterpret_cast<const float2*>(p.ln_stats);
+        const float2* lnst = reinterpret_cast<const float2*>(lds + STAGES * STAGE);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * WTM + i * 16 + r16;
-            float a1 = 0.f, a2 = 0.f;
-            if (m < p.M)
-                for (int c = q; c < p.ln_chunks; c += 4) { const float2 t = st2[(size_t)m * p.ln_chunks + c]; a1 += t.x; a2 += t.y; }
-            a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
-            a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
-            mean[i] = a1 / (float)p.K;
-            rstd[i] = rsqrtf(fmaxf(a2 / (float)p.K - mean[i] * mean[i], 0.f) + p.ln_eps);
+            const float2 v = lnst[wm * WTM + i * 16 + r16];
+            mean[i] = v.x; rstd[i] = v.y;
         }
         gemm_epilogue<T, TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wm, wn, r16, q, split, mean, rstd);
     } else {
+#ifdef ST_PROBE
+        unsigned long long ept[2] = {0, 0};
+        gemm_epilogue<T, TM, TN, WTM, WTN, GEGLU, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n, ept);
+        pr_x = ept[0] - pr_end; pr_d = ept[1] - ept[0];
+#else
         gemm_epilogue<T, TM, TN, WTM, WTN, GEGLU, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n);
+#endif
     }
 #ifdef ST_PROBE
     {
         PROBE_STAMP(pr_fin)
         if (p.probe && lane == 0) {
             unsigned long long* o = p.probe + ((size_t)blockIdx.x * NW + wave) * 8;
-            o[0] = pr_a; o[1] = pr_b; o[2] = pr_c; o[3] = pr_end - pr_start; o[4] = pr_fin - pr_end; o[5] = pr_start; o[6] = pr_fin; o[7] = nk;
+            o[0] = pr_a; o[1] = pr_b; o[2] = pr_c; o[3] = pr_end - pr_start; o[4] = pr_fin - pr_end; o[5] = pr_x; o[6] = pr_d; o[7] = nk;
         }
     }
 #endif
@@ -748,7 +943,7 @@ static void launch_cfg(const GemmArgs& a, hipStream_t st) {
 
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV, bool GEGLU, bool LNF>
 static void launch_dma_one(const GemmArgs& a, hipStream_t st, int tiles_n) {
-    const size_t lds = (size_t)STAGES * U * (BM + BN) * 128;
+    const size_t lds = (size_t)STAGES * U * (BM + BN) * 128 + (LNF ? (size_t)BM * 8 : 0);      // + LayerNorm (mean, rstd) per row
     const int sk = a.splitk > 1 ? a.splitk : 1;
     auto kfn = gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, U, CONV, GEGLU, LNF>;
     static bool once = (allow_big_lds(kfn, lds), true);

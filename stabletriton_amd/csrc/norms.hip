@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void geglu_kernel(const T* __restrict__ state,
         const int c = (int)(i - r * FV) * VEC;
         Vec16<T> a = load16(state + r * lds_ + c), g = load16(gate + r * ldg + c), o;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) o.set(k, a.get(k) * gelu_erf_f(g.get(k)));
+        for (int k = 0; k < VEC; ++k) o.set(k, a.get(k) * gelu_for<T>(g.get(k)));
         store16(out + r * ldo + c, o);
     }
 }

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Developer helper: build an alternative library under stabletriton_amd/lib/<name>/ with extra -D flags.
+# usage: tools/build_variant.sh <name> [-DFLAG ...]    (ST_LIB_VARIANT=<name> selects it at run time)
+set -e
+name=$1; shift
+root=$(cd "$(dirname "$0")/.." && pwd)
+out=$root/stabletriton_amd/lib/$name
+mkdir -p "$out"
+objs=()
+for f in "$root"/stabletriton_amd/csrc/*.hip; do
+  o=$out/$(basename "${f%.hip}").o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form "$@" -c "$f" -o "$o" &
+  objs+=("$o")
+done
+wait
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -fno-gpu-rdc "${objs[@]}" -o "$out/libstabletriton_amd.so"
+rm -f "${objs[@]}"
+echo "$out/libstabletriton_amd.so"
