@@ -76,12 +76,19 @@ def census(loop):
     loop.mode = loop_mode
     pair_ms = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
     fam = {}
-    for name, flops, nbytes, e0, e1 in store:
+    for name, flops, nbytes, e0, e1, _tag in store:
         f = fam.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
         f["launches"] += 1
         f["ms"] += max(e0.elapsed_time(e1) - pair_ms, 0.0)
         f["flops"] += flops
         f["bytes"] += nbytes
+    if os.environ.get("ST_CENSUS_SHAPES"):           # developer view: time per (operator, shape)
+        rows = {}
+        for name, flops, nbytes, e0, e1, tag in store:
+            r = rows.setdefault((name, tag), [0, 0.0, 0.0])
+            r[0] += 1; r[1] += max(e0.elapsed_time(e1) - pair_ms, 0.0); r[2] += flops
+        for (name, tag), (cnt, ms, fl) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+            print(f"  {ms:7.3f} ms  x{cnt:3d}  {ms / cnt * 1e3:7.1f} us  {fl / max(ms, 1e-9) / 1e9:7.1f} TF/s  {name:16s} {tag}", file=sys.stderr)
     return fam
 
 

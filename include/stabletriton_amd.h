@@ -72,9 +72,12 @@ int st_geglu(const void* state, const void* gate, void* out, int rows, int F,
  * stores it.  lda/ldc/ldr are row strides in elements.  With ST_EPI_GEGLU,
  * W has 2N rows and y has N columns.  rows_per_batch is only read with
  * ST_EPI_ROWBIAS (rowbias is (M/rows_per_batch, N) contiguous).
- * `workspace` (may be NULL) is caller-owned scratch of `workspace_bytes` bytes: when
- * present, long-K problems with few output tiles are split over K into fp32 slabs
- * there and reduced in a fixed order by a second launch (bit-reproducible).
+ * `workspace` (may be NULL) is caller-owned scratch of `workspace_bytes` bytes that the
+ * caller ZEROES ONCE before its first use (hipMemset) and that concurrent launches must
+ * not share: when present, long-K problems with few output tiles are split over K inside
+ * the one launch - every K slice stores an fp32 slab there, and the block of a tile that
+ * finishes last adds the slabs in slice order and applies the epilogue (bit-reproducible).
+ * The first 64 KiB hold per-tile arrival counters, which every call leaves at zero again.
  * `row_stats` (may be NULL): device buffer of M * row_stats_capacity float2; when given, the
  * kernel also writes, per output row and per N tile, (sum, sum of squares) of the values it
  * stored - the LayerNorm partials st_ln_linear consumes; the number of tiles actually used is

@@ -30,9 +30,10 @@ struct GemmArgs {
     const float* ln_stats; int ln_chunks;     // per-row (sum, sum of squares) partials written by the producer GEMM
     float* row_stats; int stats_chunks;       // producer side: emit those partials, one float2 per (row, N tile)
     int stats_capacity; int* stats_chunks_out; // host-side plumbing of the chunk count
-    int splitk;                  // K slices (1 = none); slices write fp32 slabs to `partial`, a second pass reduces
-    float* partial;
+    int splitk;                  // K slices (1 = none): every slice stores an fp32 slab to `partial`; the block of a tile
+    float* partial;              //   that finishes last sums the slabs in slice order and runs the epilogue (in-launch combine)
     size_t partial_bytes;
+    int* tile_counters;          // one arrival counter per output tile (zero between launches)
     unsigned long long* probe;   // diagnostic builds only (-DST_PROBE): per-wave phase cycle sums
 };
 
@@ -197,7 +198,6 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n,
 }
 
 // lane (r16, q) holds rows m = .. + r16, columns n = .. + 4q .. 4q+3 of every 16x16 tile.
-// With split-K (p.splitk > 1) the raw fp32 sums go to the partial slab of this K slice instead.
 template <typename T, int TM, int TN, int WTM, int WTN, bool GEGLU, int WGM_ = 0, int WGN_ = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
                                               int r16, int q, int split = 0, const float* row_mean = nullptr,
@@ -208,26 +208,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
     for (int i = 0; i < TM; ++i) { rs1[i] = 0.f; rs2[i] = 0.f; }
     constexpr int TNO = GEGLU ? TN / 2 : TN;
     constexpr int WTNO = GEGLU ? WTN / 2 : WTN;
-    const int ncols = GEGLU ? 2 * p.N : p.N;          // columns of one partial slab
-    if (p.splitk > 1) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * WTM + i * 16 + r16;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < TNO; ++j) {
-                const int n = n0 + wn * WTNO + j * 16 + 4 * q;
-                if (n >= p.N) continue;
-                float* slab = p.partial + ((size_t)split * p.M + m) * ncols;
-                if (n + 3 < p.N) {
-                    *reinterpret_cast<f32x4*>(slab + n) = acc[i][j];
-                    if (GEGLU) *reinterpret_cast<f32x4*>(slab + p.N + n) = acc[i][j + (GEGLU ? TN / 2 : 0)];
-                } else {
-                    for (int e = 0; e < 4 && n + e < p.N; ++e) { slab[n + e] = acc[i][j][e]; if (GEGLU) slab[p.N + n + e] = acc[i][j + (GEGLU ? TN / 2 : 0)][e]; }
-                }
-            }
-        }
-    } else if ((p.N & 3) != 0) {
+    if ((p.N & 3) != 0) {
         // ragged N: per-tile loads, arithmetic and element stores
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -366,32 +347,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
             }
         }
     }
-}
-
-// split-K second pass: sum the K-slice slabs in a fixed order, then the normal epilogue.
-template <typename T, bool GEGLU>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
-    const int n4 = (p.N + 3) / 4;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)p.M * n4) return;
-    const int m = (int)(idx / n4), n = (int)(idx - (long)m * n4) * 4;
-    const int ncols = GEGLU ? 2 * p.N : p.N;
-    float v[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool full = n + 3 < p.N;
-    for (int s_ = 0; s_ < p.splitk; ++s_) {
-        const float* slab = p.partial + ((size_t)s_ * p.M + m) * ncols;
-        if (full) {
-            float t[4]; Out4<float>::load(slab + n, t);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += t[e];
-            if (GEGLU) { Out4<float>::load(slab + p.N + n, t);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] += t[e]; }
-        } else {
-            for (int e = 0; e < 4 && n + e < p.N; ++e) { v[e] += slab[n + e]; if (GEGLU) g[e] += slab[p.N + n + e]; }
-        }
-    }
-    epilogue_store4<T, GEGLU>(p, m, n, v, g);
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, bool CONV, bool GEGLU>
@@ -620,9 +575,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
     const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     constexpr int BNO = GEGLU ? BN / 2 : BN;
-    // split-K: slice-major block order, so the blocks that run together share one K range
-    const int ntile = nblk / p.splitk;
-    const int split = wg / ntile, tw = wg - split * ntile;
+    // split-K: tile-major block order, so a tile's slices sit next to each other on one XCD, where the
+    // block that sums their slabs reads them fastest
+    const int split = wg % p.splitk, tw = wg / p.splitk;
     const int tile_n = tw / tiles_m, tile_m = tw - tile_n * tiles_m;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BNO;
@@ -683,7 +638,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     // The destination register stays reserved (touch_sink is "used" after the prologue wait that
     // retires the loads), so a late return cannot land in a register that has been given away.
     unsigned int touch_sink = 0;
-    if (p.splitk <= 1) {
+    {
         constexpr int NT_ = NW * 64;
         const int ncols_out = min(BNO, p.N - n0);                      // output columns of this tile
         auto touch_at = [&](const char* a) {
@@ -719,6 +674,23 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     // `issue_range` emits entries [lo, hi) so the loop can spread them between MFMA groups
     // (back-to-back DMAs serialise in the address unit while the matrix pipe idles).
     constexpr int PER_TILE = A_IT + B_IT;
+    // conv: position of the K tile that the next issue fetches, advanced once per stage (no divisions
+    // in the loop; a K tile never straddles a filter tap because Cin is a multiple of the tile)
+    int cs_r = 0, cs_s = 0, cs_c0 = 0;
+    if (CONV) {
+        const int k0 = kbase * KB;
+        const int tap = k0 / p.Cin;
+        cs_c0 = k0 - tap * p.Cin; cs_r = tap / p.S; cs_s = tap - cs_r * p.S;
+    }
+    auto conv_advance = [&](bool go) {              // branch-free: `go` false leaves the position where it is
+        cs_c0 += go ? KB * U : 0;
+        const bool w1 = cs_c0 >= p.Cin;
+        cs_c0 -= w1 ? p.Cin : 0;
+        cs_s += w1 ? 1 : 0;
+        const bool w2 = cs_s == p.S;
+        cs_s = w2 ? 0 : cs_s;
+        cs_r += w2 ? 1 : 0;
+    };
     auto issue_one = [&](int st, int buf, int e) {
         const int u = e / PER_TILE, i = e - u * PER_TILE;
         const int kt = kbase + st * U + u;
@@ -726,9 +698,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         if (i < A_IT) {
             const T* src;
             if (CONV) {
-                const int k0 = kt * KB;
-                const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
-                const int r = tap / p.S, s_ = tap - r * p.S;
+                int r, s_, c0;
+                if constexpr (U == 1) {            // running (tap row, tap column, channel offset) of the stage being fetched
+                    r = cs_r; s_ = cs_s; c0 = cs_c0;
+                } else {
+                    const int k0 = kt * KB;
+                    const int tap = k0 / p.Cin;
+                    c0 = k0 - tap * p.Cin; r = tap / p.S; s_ = tap - r * p.S;
+                }
                 int iy = a_iy[i] + r, ix = a_ix[i] + s_;
                 bool ok;
                 if (p.ups) {
@@ -781,7 +758,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     }
 #pragma unroll
     for (int s_ = 0; s_ < STAGES - 1; ++s_)
-        if (s_ < nk) issue(s_, s_);
+        if (s_ < nk) { issue(s_, s_); if (CONV) conv_advance(s_ < nk - 1); }
     if constexpr (LNF) {
         const float2* st2 = reinterpret_cast<const float2*>(p.ln_stats);
         const int row = t / TPR, part = t - row * TPR;
@@ -890,9 +867,58 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
 #endif
         cur = cur + 1 == STAGES ? 0 : cur + 1;
         nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+        if (CONV) conv_advance(kt + STAGES - 1 < nk - 1);
     }
     wait_vmcnt<0>();                              // no LDS-DMA may outlive the workgroup's LDS allocation
     PROBE_STAMP(pr_end)
+    if (p.splitk > 1) {
+        // In-launch split-K combine (cdna guide, projection GEMM item 2).  Every slice stores its fp32
+        // accumulators as a slab in FRAGMENT order (a wave-instruction writes 1 KiB contiguous), the
+        // block publishes with one agent-scope release and draws a ticket; the block that draws the
+        // last ticket acquires, re-reads ALL slabs in slice order (bit-reproducible whichever block is
+        // last) and runs the epilogue.  Nobody waits on anybody, so there is no spin to hang in.
+        float* slab0 = p.partial + (size_t)tw * p.splitk * (BM * BN);
+        {
+            float* mine = slab0 + (size_t)split * (BM * BN) + (size_t)wave * (TM * TN * 256) + lane * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    // write-through (sc1) store: visible to every XCD once acknowledged, no release fence needed
+                    const float* dst = mine + (i * TN + j) * 256;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(acc[i][j]) : "memory");
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its own stores ...
+        __syncthreads();                                          // ... before the one lane that signals for all
+        int* flag = reinterpret_cast<int*>(lds);
+        if (t == 0) *flag = __hip_atomic_fetch_add(p.tile_counters + tw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != p.splitk - 1) return;
+        if (t == 0) __hip_atomic_store(p.tile_counters + tw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // every slab load is sc1 (bypasses this CU's L1, which other CUs' stores never refresh)
+        for (int sl = 0; sl < p.splitk; ++sl) {
+            const float* src = slab0 + (size_t)sl * (BM * BN) + (size_t)wave * (TM * TN * 256) + lane * 4;
+            f32x4 part[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float* a_ = src + (i * TN + j) * 256;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[i][j]) : "v"(a_) : "memory");
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] += part[i][j];
+        }
+    }
     if constexpr (LNF) {
         float mean[TM], rstd[TM];
         const float2* lnst = reinterpret_cast<const float2*>(lds + STAGES * STAGE);
@@ -949,7 +975,6 @@ static void launch_dma_one(const GemmArgs& a, hipStream_t st, int tiles_n) {
     static bool once = (allow_big_lds(kfn, lds), true);
     (void)once;
     hipLaunchKernelGGL(kfn, dim3(cdiv(a.M, BM) * tiles_n * sk), dim3(WGM * WGN * 64), lds, st, a);
-    if (sk > 1) hipLaunchKernelGGL((splitk_reduce_kernel<T, GEGLU>), dim3(cdiv((long)a.M * ((a.N + 3) / 4), 256)), dim3(256), 0, st, a);
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV>
@@ -988,8 +1013,15 @@ static int cfg_bn(int cfg) {
     }
 }
 
+#ifdef ST_DEV_CONFIGS
+static int g_dbg_cfg = -1, g_dbg_fusek = -1;
+extern "C" void st_debug_force_gemm(int cfg, int fusek) { g_dbg_cfg = cfg; g_dbg_fusek = fusek; }
+#endif
 static int forced_cfg() {
     static int v = [] { const char* e = getenv("ST_GEMM_FORCE"); return e ? atoi(e) : -1; }();
+#ifdef ST_DEV_CONFIGS
+    if (g_dbg_cfg >= 0) return g_dbg_cfg;
+#endif
     return v;
 }
 
@@ -1018,49 +1050,64 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
         // chosen by a small cost model fitted to MI355X measurements (tools/op_bench.py):
         // one block per CU at a time, a K step costs max(address-unit time of its DMA bytes at
         // 64 B/clk, MFMA time) + a fixed sync overhead, and a partly filled last round costs a full one.
-        struct Cand { int cfg, bm, bn; };
-        static const Cand cands[] = {{CFG_128x128_W8, 128, 128}, {CFG_64x128_W8, 64, 128}, {CFG_128x64_W8, 128, 64},
-                                     {CFG_64x64_W8, 64, 64}, {CFG_128x320_W8, 128, 320}, {CFG_64x320_W8, 64, 320}};
-        int cfg = CFG_64x64_W8;
+        // Tile and K split by a small cost model in microseconds, fitted to MI355X measurements
+        // (tools/op_bench.py, tools/fusek_bench.py): one block per CU at a time; a K trip costs a
+        // per-tile constant (set by the L2 -> LDS fill rate of ~70 GB/s per CU more than by the MFMAs);
+        // a partly filled last round costs a full one; a K split adds the in-launch combine
+        // (write-through fp32 slabs: ~2 us + 0.4 us per MB of slab).
+        struct Cand { int cfg, bm, bn; double trip_us; };
+        static const Cand cands[] = {{CFG_128x128_W8, 128, 128, 0.53}, {CFG_64x128_W8, 64, 128, 0.34}, {CFG_128x64_W8, 128, 64, 0.32},
+                                     {CFG_64x64_W8, 64, 64, 0.19}, {CFG_128x320_W8, 128, 320, 1.38}, {CFG_64x320_W8, 64, 320, 0.64},
+                                     {CFG_256x128_W8, 256, 128, 0.72}};
+        static const int sks[] = {1, 2, 3, 4, 6, 8};
+        static const int force_sk = [] { const char* e = getenv("ST_GEMM_SPLITK"); return e ? atoi(e) : -1; }();     // 0/1: never split
+        const int nk = a.K / KB;
+        const long ncols = (a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N;
+        const bool can_split = a.partial && !a.ln_c && force_sk != 0 && force_sk != 1;
+        int cfg = CFG_64x64_W8, sk = 1;
         double best = 1e30;
         for (const Cand& c : cands) {
             if ((a.epi & ST_EPI_GEGLU) && c.cfg == CFG_64x320_W8) continue;      // odd n-tiles per wave: no value/gate pairing
-            const long blocks = tiles(c.bm, c.bn);
-            const double rounds = (double)((blocks + 255) / 256);
-            const double ta = 2.0 * (c.bm + c.bn), mf = c.bm * c.bn / 32.0;
-            const double cost = rounds * ((ta > mf ? ta : mf) + 150.0 + (CONV ? 0.5 * c.bm : 0.0));
-            if (cost < best) { best = cost; cfg = c.cfg; }
-        }
-        // split-K: long-K problems with too few output tiles to fill the chip (ff-out, the 32x32 / 64x64
-        // resnet convs) run the 256x128 tile over K slices; fp32 slabs go to the caller's workspace and a
-        // second pass reduces them in a fixed order (deterministic) and applies the epilogue.
-        GemmArgs b = a;
-        const int nk = a.K / KB;
-        const long ncols = (a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N;
-        static const int force_sk = [] { const char* e = getenv("ST_GEMM_SPLITK"); return e ? atoi(e) : -1; }();
-        int sk = 1;
-        if (a.partial && force_sk != 0 && !a.ln_c && !a.row_stats) {
-            const long t = tiles(256, 128);
-            if (t <= 100 && nk >= 120) {        // measured: pays from K ~ 8k up (the wide resnet convs)
-                sk = (int)(256 / t);
-                if (sk > nk / 8) sk = nk / 8;
+            const long nt = tiles(c.bm, c.bn);
+            const double trip = c.trip_us * (CONV ? 1.6 : 1.0);
+            for (int k_ : sks) {
+                if (k_ > 1 && (!can_split || nk / k_ < 4 || nt > 16384)) break;
+                const double slab_mb = (double)k_ * nt * c.bm * c.bn * 4.0 / 1e6;
+                if (k_ > 1 && slab_mb * 1e6 + 65536 > (double)a.partial_bytes) break;
+                const double rounds = (double)((nt * k_ + 255) / 256);
+                const double cost = rounds * (cdiv(nk, k_) * trip + 3.0) + (k_ > 1 ? 2.1 + 0.4 * slab_mb : 0.0);
+                if (cost < best) { best = cost; cfg = c.cfg; sk = k_; }
             }
-            if (force_sk > 1) sk = force_sk;
-            while (sk > 1 && (size_t)sk * a.M * ncols * sizeof(float) > a.partial_bytes) --sk;
-            if (sk > nk) sk = nk;
-            if (sk > 1) { cfg = CFG_256x128_W8; b.splitk = sk; }
         }
+        GemmArgs b = a;
 #ifdef ST_DEV_CONFIGS
         {   // dev knob: override only the small-problem class (fewer than 150 tiles of 128x128)
             static const int small_cfg = [] { const char* e = getenv("ST_GEMM_SMALL_CFG"); return e ? atoi(e) : -1; }();
             if (small_cfg >= 0 && small_cfg < CFG_COUNT && tiles(128, 128) < 150 && sk == 1) cfg = small_cfg;
         }
 #endif
-        const int f = forced_cfg();
-        if (f >= 0 && f < CFG_COUNT) {
-            const bool u2 = (f == CFG_64x64_S4_U2 || f == CFG_128x64_S3_U2 || f == CFG_64x128_W8_U2 || f == CFG_128x64_W8_U2 ||
-                             f == CFG_64x64_W8_U2);
-            if (!u2 || even2) cfg = f;
+        {   // developer overrides: ST_GEMM_FORCE=<cfg id> (tile), ST_GEMM_FUSEK=<n> (K split with that tile)
+            static const int env_fk = [] { const char* e = getenv("ST_GEMM_FUSEK"); return e ? atoi(e) : -1; }();
+            int force_fk = env_fk;
+#ifdef ST_DEV_CONFIGS
+            if (g_dbg_cfg >= 0) force_fk = g_dbg_fusek;
+#endif
+            const int f = forced_cfg();
+            if (f >= 0 && f < CFG_COUNT) {
+                const bool u2 = (f == CFG_64x64_S4_U2 || f == CFG_128x64_S3_U2 || f == CFG_64x128_W8_U2 || f == CFG_128x64_W8_U2 ||
+                                 f == CFG_64x64_W8_U2);
+                if (!u2 || even2) { cfg = f; sk = (force_fk > 1 && can_split) ? (force_fk > nk ? nk : force_fk) : 1; }
+            }
+        }
+        if (sk > 1) {
+            int bm = 128;
+            if (cfg == CFG_64x64_W8 || cfg == CFG_64x128_W8 || cfg == CFG_64x320_W8) bm = 64;
+            if (cfg == CFG_256x128_W8) bm = 256;
+            const long nt = tiles(bm, cfg_bn(cfg));
+            if (nt <= 16384 && (size_t)sk * nt * bm * cfg_bn(cfg) * 4 + 65536 <= a.partial_bytes) {
+                // workspace layout: 16384 arrival counters (zero between launches), then the fp32 slabs
+                b.splitk = sk; b.tile_counters = (int*)a.partial; b.partial = a.partial + 16384;
+            }
         }
         b.stats_chunks = cdiv(a.N, cfg_bn(cfg));
         if (a.row_stats && b.stats_chunks > a.stats_capacity) return st_fail("%s: row_stats buffer holds %d chunks, %d needed", who, a.stats_capacity, b.stats_chunks);

@@ -28,15 +28,26 @@ def set_census(store) -> None:
     _census = store
 
 
+_tag = None          # shape label of the launch being timed (census runs only)
+
+
 def _timed(family: str, flops: float, nbytes: float, fn, *args) -> int:
+    global _tag
     if _census is None:
         return fn(*args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     status = fn(*args)
     e1.record()
-    _census.append((family, flops, nbytes, e0, e1))
+    _census.append((family, flops, nbytes, e0, e1, _tag))
+    _tag = None
     return status
+
+
+def _label(text: str) -> None:
+    global _tag
+    if _census is not None:
+        _tag = text
 
 
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
@@ -58,7 +69,7 @@ def _gemm_workspace(device: torch.device) -> torch.Tensor:
     key = (device.type, device.index)
     ws = _gemm_ws.get(key)
     if ws is None:
-        ws = torch.empty(GEMM_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        ws = torch.zeros(GEMM_WORKSPACE_BYTES, dtype=torch.uint8, device=device)      # the arrival counters must start at zero
         _gemm_ws[key] = ws
     return ws
 
@@ -102,6 +113,7 @@ def group_norm(x: torch.Tensor, num_groups: int, weight: torch.Tensor, bias: tor
     w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
     b = bias if bias.dtype == x.dtype else bias.to(x.dtype)
     ws = _workspace(x.device, lib.st_group_norm_workspace_bytes(N, Cc, HW, num_groups))
+    _label(f"N={N} C={Cc} HW={HW} silu={int(bool(silu))}")
     _C.check(_timed("group_norm", 0.0, 2.0 * x.numel() * x.element_size(), lib.st_group_norm, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups,
                                float(eps), int(bool(silu)), layout, _C.dtype_code(x.dtype), ws.data_ptr(),
                                _C.stream_ptr()), "group_norm")
@@ -197,6 +209,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         cap = min(STATS_MAX_CHUNKS, (N + 63) // 64)
         stats = torch.empty((M, cap, 2), dtype=torch.float32, device=x.device)
         chunks = ctypes.c_int(0)
+    _label(f"M={M} N={N} K={K} epi={epi}{' stats' if emit_stats else ''}")
     _C.check(_timed("linear", 2.0 * M * w.shape[0] * K, float((M * K + w.numel() + M * N) * x.element_size()),
                     lib.st_linear, x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
                     lda, N, ldr, 0, epi, _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(),
@@ -223,6 +236,7 @@ def ln_linear(x: torch.Tensor, stats: "RowStats", w_folded: torch.Tensor, c: tor
     x2, M, lda = _rows2d(x)
     N = w_folded.shape[0] // 2 if geglu else w_folded.shape[0]
     out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+    _label(f"M={M} N={N} K={K} ln{' geglu' if geglu else ''}")
     _C.check(_timed("linear", 2.0 * M * w_folded.shape[0] * K, float((M * K + w_folded.numel() + M * N) * x.element_size()),
                     lib.st_ln_linear, x2.data_ptr(), stats.buf.data_ptr(), stats.chunks, w_folded.data_ptr(),
                     c.data_ptr(), d.data_ptr(), out.data_ptr(), M, N, K,
@@ -262,6 +276,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int,
     k_, ldk = tok(k)
     v_, ldv = tok(v)
     out = torch.empty((B, T, Cc), dtype=q.dtype, device=q.device)
+    _label(f"B={B} T={T} S={S} H={num_heads}")
     _C.check(_timed("attention_self" if S == T else "attention_cross", 4.0 * B * num_heads * T * S * D,
                     float((2 * q.numel() + k.numel() + v.numel()) * q.element_size()), lib.st_attention, q_.data_ptr(), k_.data_ptr(), v_.data_ptr(), out.data_ptr(), B, T, S, num_heads, D,
                               ldq, ldk, ldv, Cc, float(scale), _C.dtype_code(q.dtype), _C.stream_ptr()), "attention")
@@ -308,6 +323,7 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
             residual = residual.contiguous(memory_format=torch.channels_last)
         epi |= _C.EPI_RESIDUAL
     gws = _gemm_workspace(x.device)
+    _label(f"Cin={Cin} H={H} Cout={Cout} k={R} s={stride} ups={int(upsample2x)} epi={epi}")
     _C.check(_timed("conv2d", 2.0 * N * Ho * Wo * Cout * R * S * Cin,
                     float((x.numel() + w.numel() + out.numel()) * x.element_size()), lib.st_conv2d, x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(rowbias), out.data_ptr(),
                            N, H, W, Cin, Cout, R, S, stride, padding, int(upsample2x), epi,
