@@ -239,76 +239,88 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
         for (int j = 0; j < TNO; ++j) { const int n = n0 + wn * WTNO + j * 16 + 4 * q; nok[j] = n < p.N; ncol[j] = nok[j] ? n : 0; }
 #pragma unroll
         for (int i = 0; i < TM; ++i) { const int m = m0 + wm * WTM + i * 16 + r16; mok[i] = m < p.M; mrow[i] = mok[i] ? m : 0; }
-        R4 braw[TNO] = {}, graw[TNO] = {};
-        f32x4 cv[TNO] = {}, dv[TNO] = {}, cg[TNO] = {}, dg[TNO] = {};
-        R4 rres[TM][TNO] = {}, rrb[TM][TNO] = {};
         const T* __restrict__ bias = (const T*)p.bias;
-        if (has_bias) {
+        // wide wave tiles take the load + arithmetic passes in column chunks of JC tiles (registers)
+        constexpr int JC = TNO <= 5 ? TNO : 5;
+        auto chunk = [&](auto jc) {
+            constexpr int J0 = decltype(jc)::value;
+            constexpr int NJ = (J0 + JC <= TNO) ? JC : TNO - J0;
+            R4 braw[NJ] = {}, graw[NJ] = {};
+            f32x4 cv[NJ] = {}, dv[NJ] = {}, cg[NJ] = {}, dg[NJ] = {};
+            R4 rres[TM][NJ] = {}, rrb[TM][NJ] = {};
+            if (has_bias) {
 #pragma unroll
-            for (int j = 0; j < TNO; ++j) { braw[j] = ld_raw4<T>(bias + ncol[j]); if (GEGLU) graw[j] = ld_raw4<T>(bias + p.N + ncol[j]); }
-        }
-        if (has_ln) {
-#pragma unroll
-            for (int j = 0; j < TNO; ++j) {
-                cv[j] = *reinterpret_cast<const f32x4*>(p.ln_c + ncol[j]); dv[j] = *reinterpret_cast<const f32x4*>(p.ln_d + ncol[j]);
-                if (GEGLU) { cg[j] = *reinterpret_cast<const f32x4*>(p.ln_c + p.N + ncol[j]); dg[j] = *reinterpret_cast<const f32x4*>(p.ln_d + p.N + ncol[j]); }
+                for (int j = 0; j < NJ; ++j) { braw[j] = ld_raw4<T>(bias + ncol[J0 + j]); if (GEGLU) graw[j] = ld_raw4<T>(bias + p.N + ncol[J0 + j]); }
             }
-        }
-        if (has_rb) {
+            if (has_ln) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < NJ; ++j) {
+                    const int n = ncol[J0 + j];
+                    cv[j] = *reinterpret_cast<const f32x4*>(p.ln_c + n); dv[j] = *reinterpret_cast<const f32x4*>(p.ln_d + n);
+                    if (GEGLU) { cg[j] = *reinterpret_cast<const f32x4*>(p.ln_c + p.N + n); dg[j] = *reinterpret_cast<const f32x4*>(p.ln_d + p.N + n); }
+                }
+            }
+            if (has_rb) {
 #pragma unroll
-                for (int j = 0; j < TNO; ++j) rrb[i][j] = ld_raw4<T>((const T*)p.rowbias + (size_t)(mrow[i] / p.rows_per_batch) * p.N + ncol[j]);
-        }
-        if (has_res) {
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                    for (int j = 0; j < NJ; ++j) rrb[i][j] = ld_raw4<T>((const T*)p.rowbias + (size_t)(mrow[i] / p.rows_per_batch) * p.N + ncol[J0 + j]);
+            }
+            if (has_res) {
 #pragma unroll
-                for (int j = 0; j < TNO; ++j) rres[i][j] = ld_raw4<T>((const T*)p.residual + (size_t)mrow[i] * p.ldr + ncol[j]);
-        }
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const float mean = row_mean ? row_mean[i] : 0.f, rstd = row_rstd ? row_rstd[i] : 0.f;
+                    for (int j = 0; j < NJ; ++j) rres[i][j] = ld_raw4<T>((const T*)p.residual + (size_t)mrow[i] * p.ldr + ncol[J0 + j]);
+            }
 #pragma unroll
-            for (int j = 0; j < TNO; ++j) {
-                float v[4], g[4];
+            for (int i = 0; i < TM; ++i) {
+                const float mean = row_mean ? row_mean[i] : 0.f, rstd = row_rstd ? row_rstd[i] : 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = acc[i][j][e]; g[e] = GEGLU ? acc[i][j + (GEGLU ? TN / 2 : 0)][e] : 0.f; }
-                if (has_ln) {
+                for (int j = 0; j < NJ; ++j) {
+                    float v[4], g[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = acc[i][J0 + j][e]; g[e] = GEGLU ? acc[i][J0 + j + (GEGLU ? TN / 2 : 0)][e] : 0.f; }
+                    if (has_ln) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = rstd * (v[e] - mean * cv[j][e]) + dv[j][e];
+                            if (GEGLU) g[e] = rstd * (g[e] - mean * cg[j][e]) + dg[j][e];
+                        }
+                    }
+                    if (has_bias) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += Elem<T>::to_f(braw[j][e]); if (GEGLU) g[e] += Elem<T>::to_f(graw[j][e]); }
+                    }
+                    if (GEGLU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= gelu_for<T>(g[e]);
+                    }
+                    if (do_silu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                    }
+                    if (has_rb) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f(rrb[i][j][e]);
+                    }
+                    if (has_res) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f(rres[i][j][e]);
+                    }
+                    const bool live = mok[i] && nok[J0 + j];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = rstd * (v[e] - mean * cv[j][e]) + dv[j][e];
-                        if (GEGLU) g[e] = rstd * (g[e] - mean * cg[j][e]) + dg[j][e];
+                        v[e] = live ? Elem<T>::to_f(Elem<T>::from_f(v[e])) : 0.f;      // what is stored
+                        rs1[i] += v[e]; rs2[i] = fmaf(v[e], v[e], rs2[i]); acc[i][J0 + j][e] = v[e];
                     }
                 }
-                if (has_bias) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += Elem<T>::to_f(braw[j][e]); if (GEGLU) g[e] += Elem<T>::to_f(graw[j][e]); }
-                }
-                if (GEGLU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= gelu_for<T>(g[e]);
-                }
-                if (do_silu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-                }
-                if (has_rb) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f(rrb[i][j][e]);
-                }
-                if (has_res) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f(rres[i][j][e]);
-                }
-                const bool live = mok[i] && nok[j];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = live ? Elem<T>::to_f(Elem<T>::from_f(v[e])) : 0.f;      // what is stored
-                    rs1[i] += v[e]; rs2[i] = fmaf(v[e], v[e], rs2[i]); acc[i][j][e] = v[e];
-                }
             }
-        }
+        };
+        chunk(std::integral_constant<int, 0>{});
+        if constexpr (JC < TNO) chunk(std::integral_constant<int, JC>{});
+        if constexpr (2 * JC < TNO) chunk(std::integral_constant<int, 2 * JC>{});
+        if constexpr (3 * JC < TNO) chunk(std::integral_constant<int, 3 * JC>{});
+        static_assert(4 * JC >= TNO, "epilogue chunking covers at most four chunks");
 #ifdef ST_PROBE
         if (ptimes) ptimes[0] = probe_now();
 #endif

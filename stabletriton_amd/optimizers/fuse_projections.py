@@ -1,10 +1,11 @@
 """Graph-level GEMM consolidation (additions; cf. the reference's unused fused
 Q/K/V projection kernel, kernels/attention_proj.py:53-155):
 
-* `fuse_shared_input_linears`: plain bias-free linear_wrapper calls that read the
-  same tensor (to_q/to_k/to_v of self-attention, to_k/to_v of cross-attention,
-  unet_pt.py:122-132) become one `linear_cat_wrapper` GEMM; consumers get
-  column slices (the attention kernel takes strided q/k/v).
+* `fuse_shared_input_linears`: plain linear_wrapper calls that read the same tensor
+  (to_q/to_k/to_v of self-attention, to_k/to_v of cross-attention, unet_pt.py:122-132;
+  the 17 resnet time_emb_proj of SiLU(temb), unet_pt.py:72-76) become one
+  `linear_cat_wrapper` GEMM; consumers get column slices (the attention kernel takes
+  strided q/k/v, the conv epilogue a row-bias slice).
 * `split_context`: everything that depends only on `encoder_hidden_states`
   (the 77-token text context: 140 K/V projections, step-invariant - SURVEY.md 8a
   row L) moves into a separate context GraphModule, evaluated once per prompt.
@@ -22,14 +23,14 @@ from .wrappers import (layer_norm_wrapper, linear_cat_wrapper, linear_geglu_wrap
 
 
 def fuse_shared_input_linears(gm: fx.GraphModule) -> int:
-    groups: Dict[fx.Node, List[fx.Node]] = {}
+    groups: Dict[Tuple[fx.Node, bool], List[fx.Node]] = {}
     for n in gm.graph.nodes:
         if n.op == "call_function" and n.target is linear_wrapper and n.args[2] is False and isinstance(n.args[0], fx.Node):
             lin = gm.get_submodule(n.args[1].target)
-            if isinstance(lin, nn.Linear) and lin.bias is None:
-                groups.setdefault(n.args[0], []).append(n)
+            if isinstance(lin, nn.Linear):
+                groups.setdefault((n.args[0], lin.bias is None), []).append(n)
     fused = 0
-    for src, nodes in groups.items():
+    for (src, _), nodes in groups.items():
         if len(nodes) < 2:
             continue
         first = nodes[0]

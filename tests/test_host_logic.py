@@ -58,7 +58,7 @@ def test_pass_counts_match_reference_probe_on_sdxl():
     for k, v in EXPECTED.items():
         assert gm.rewrite_stats[k] == v, (k, gm.rewrite_stats[k], v)
     assert gm.rewrite_stats["geglu_in_gemm"] == 70 and gm.rewrite_stats["temb_rowbias"] == 17
-    assert gm.rewrite_stats["layer_norm_in_gemm"] == 210 and gm.rewrite_stats["shared_input_gemms"] == 71
+    assert gm.rewrite_stats["layer_norm_in_gemm"] == 210 and gm.rewrite_stats["shared_input_gemms"] == 72
     _install_context_split(gm)
     assert gm.rewrite_stats["context_outputs"] == 140
     left = [n for n in gm.graph.nodes if n.op == "call_module"]
