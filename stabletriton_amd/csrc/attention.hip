@@ -81,19 +81,25 @@ __device__ __attribute__((aligned(16))) unsigned int g_att_zero16[4] = {0u, 0u, 
 //   -> O^T += V(t)^T P^T -> S_cur = S_next.
 // The buffer refilled in trip t held tile t-1, whose last reads (V fragments of trip t-1) are in
 // registers before any wave reaches this trip's barrier; the DMA is issued after that barrier.
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
-                                                            const bf16* __restrict__ V, bf16* __restrict__ O,
-                                                            int T, int S, long ldq, long ldk, long ldv, long ldo, float scale_log2e,
-                                                            unsigned long long* probe) {
+// KS = 2 splits the keys over two wave groups of NW waves each (same query rows, key tiles
+// [0, n/2) and [n/2, n), each group with its own DMA ring); the groups merge their (O, m, l) through
+// LDS at the end.  It doubles the waves of launches that would leave SIMDs with a single wave.
+template <int NW, int KS = 1>
+__global__ __launch_bounds__(NW * KS * 64) void attn_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                                 const bf16* __restrict__ V, bf16* __restrict__ O,
+                                                                 int T, int S, long ldq, long ldk, long ldv, long ldo, float scale_log2e,
+                                                                 unsigned long long* probe) {
     constexpr int TILE_B = ATT_KV * 128;                 // bytes of one K (or V) tile image
     constexpr int BUF_B = 2 * TILE_B;                    // K image + V image
     constexpr int PIECES = 16 / NW > 0 ? 16 / NW : 1;    // 1-KiB DMA pieces per wave per tile (8 K + 8 V pieces)
     static_assert(16 % NW == 0, "waves must divide the 16 DMA pieces of a tile");
-    __shared__ __attribute__((aligned(16))) char lds[3 * BUF_B];
+    extern __shared__ __attribute__((aligned(16))) char lds_all[];      // KS rings of 3 tile buffers
 
     const int t_ = threadIdx.x, lane = t_ & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t_ >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(t_ >> 6);
+    const int kg = KS > 1 ? wave_all / NW : 0;           // key group of this wave
+    const int wave = wave_all - kg * NW;
+    char* lds = lds_all + kg * (3 * BUF_B);
     const int r32 = lane & 31, h = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
     const int q0 = (blockIdx.x * NW + wave) * 32;
@@ -110,6 +116,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restri
     for (int ks = 0; ks < 4; ++ks)
         qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (size_t)qrow * ldq + 16 * ks + 8 * h);
 
+    const int nkt_all = (S + ATT_KV - 1) / ATT_KV;
+    const int nkt = (nkt_all + KS - 1) / KS;              // trips of every key group (tiles past the end are all-masked)
+    const int kt0 = kg * nkt;                              // first key tile of this group
+
     // ---- LDS-DMA of one tile: piece p = wave*PIECES + i; p < 8 -> K row block p, else V row block p-8.
     // The LDS image is lane-linear, so the chunk swizzle goes on the per-lane SOURCE address.
     const int lr = lane >> 3, pc = lane & 7;
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restri
             const int pce = wave * PIECES + i;
             const int isv = pce >> 3, rb = pce & 7;
             const int row = rb * 8 + lr;
-            const int key = kt * ATT_KV + row;
+            const int key = (kt0 + kt) * ATT_KV + row;
             const int c = pc ^ (isv ? swz_v(row) : swz_k(row));
             const bf16* src = isv ? Vb + (size_t)key * ldv + c * 8 : Kb + (size_t)key * ldk + c * 8;
             if (key >= S) src = zeros;
@@ -145,8 +155,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restri
 
     f32x16 o0 = {0}, o1 = {0};
     float m = -1e30f, l = 0.f;
-    const int nkt = (S + ATT_KV - 1) / ATT_KV;
-
     dma_tile(0, 0);
     if (nkt > 1) dma_tile(1, 1);
     if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
@@ -181,8 +189,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restri
         if (kt + 1 < nkt) qk_tile(nb, n0, n1);
         AP_STAMP(t1)
         // mask the tail keys (only the last tile can have any)
-        if ((kt + 1) * ATT_KV > S) {
-            const int kbase = kt * ATT_KV + 4 * h;
+        if ((kt0 + kt + 1) * ATT_KV > S) {
+            const int kbase = (kt0 + kt) * ATT_KV + 4 * h;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kbase + (r & 3) + 8 * (r >> 2);
@@ -240,6 +248,27 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const bf16* __restri
     }
 #endif
 
+    if constexpr (KS > 1) {
+        // merge the key groups: group 1 parks (O, m, l) in LDS (the rings are dead), group 0 folds them in
+        __syncthreads();
+        float* park = reinterpret_cast<float*>(lds_all) + (size_t)wave * (34 * 64) + lane;
+        if (kg == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { park[r * 64] = o0[r]; park[(16 + r) * 64] = o1[r]; }
+            park[32 * 64] = m; park[33 * 64] = l;
+        }
+        __syncthreads();
+        if (kg == 1) return;
+        const float m2 = park[32 * 64], l2 = park[33 * 64];
+        const float m_new = fmaxf(m, m2);
+        const float a1 = fast_exp2(m - m_new), a2 = fast_exp2(m2 - m_new);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] = o0[r] * a1 + park[r * 64] * a2;
+            o1[r] = o1[r] * a1 + park[(16 + r) * 64] * a2;
+        }
+        l = l * a1 + l2 * a2;
+    }
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
     if (q0 + r32 < T) {
@@ -550,17 +579,28 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
                                (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c);
             return st_check_launch("attention");
         }
-        if (nw == 8)
-            hipLaunchKernelGGL(attn_bf16_kernel<8>, dim3(cdiv(T, 256), H, B), dim3(512), 0, st, (const bf16*)q, (const bf16*)k,
+        constexpr size_t RING = 3 * 2 * ATT_KV * 128;       // one DMA ring: three (K, V) tile buffers
+        // key split: launches that give most SIMDs a single wave (SDXL's 32x32 level: 160 blocks of 4 waves)
+        // run two key groups per block instead - twice the waves, half the tiles each, one LDS merge
+        static const int force_ks = [] { const char* e = getenv("ST_ATT_KS"); return e ? atoi(e) : -1; }();
+        const bool split = force_ks >= 0 ? force_ks == 2 : (nw == 4 && (long)cdiv(T, 128) * H * B <= 256 && S >= 512);
+        if (split) {
+            auto kfn = attn_bf16_kernel<4, 2>;
+            static bool once = (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * RING)), true);
+            (void)once;
+            hipLaunchKernelGGL(kfn, dim3(cdiv(T, 128), H, B), dim3(512), 2 * RING, st, (const bf16*)q, (const bf16*)k,
+                               (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c, ATT_PROBE_ARG);
+        } else if (nw == 8)
+            hipLaunchKernelGGL(attn_bf16_kernel<8>, dim3(cdiv(T, 256), H, B), dim3(512), RING, st, (const bf16*)q, (const bf16*)k,
                                (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c, ATT_PROBE_ARG);
         else if (nw == 4)
-            hipLaunchKernelGGL(attn_bf16_kernel<4>, dim3(cdiv(T, 128), H, B), dim3(256), 0, st, (const bf16*)q, (const bf16*)k,
+            hipLaunchKernelGGL(attn_bf16_kernel<4>, dim3(cdiv(T, 128), H, B), dim3(256), RING, st, (const bf16*)q, (const bf16*)k,
                                (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c, ATT_PROBE_ARG);
         else if (nw == 2)
-            hipLaunchKernelGGL(attn_bf16_kernel<2>, dim3(cdiv(T, 64), H, B), dim3(128), 0, st, (const bf16*)q, (const bf16*)k,
+            hipLaunchKernelGGL(attn_bf16_kernel<2>, dim3(cdiv(T, 64), H, B), dim3(128), RING, st, (const bf16*)q, (const bf16*)k,
                                (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c, ATT_PROBE_ARG);
         else
-            hipLaunchKernelGGL(attn_bf16_kernel<1>, dim3(cdiv(T, 32), H, B), dim3(64), 0, st, (const bf16*)q, (const bf16*)k,
+            hipLaunchKernelGGL(attn_bf16_kernel<1>, dim3(cdiv(T, 32), H, B), dim3(64), RING, st, (const bf16*)q, (const bf16*)k,
                                (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c, ATT_PROBE_ARG);
     } else if (dtype == ST_F32) {
         hipLaunchKernelGGL(attn_f32_kernel, dim3(cdiv(T, 128), H, B), dim3(128), 0, st, (const float*)q, (const float*)k,
