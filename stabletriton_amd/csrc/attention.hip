@@ -565,7 +565,10 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
         // waves wins over more blocks; 8 waves once that still leaves >= 128 blocks, else 4
         int nw = ((long)cdiv(T, 256) * H * B >= 128 && S > 256) ? 8 : 4;
         if (force_nw == 1 || force_nw == 2 || force_nw == 4 || force_nw == 8) nw = force_nw;
-        static const int rows16 = [] { const char* e = getenv("ST_ATT_R16"); return e ? atoi(e) : 0; }();
+        static const int rows16_env = [] { const char* e = getenv("ST_ATT_R16"); return e ? atoi(e) : -1; }();
+        // measured (tools/op_bench.py): 16-row waves win for the 77-key text context (more waves for a
+        // two-tile loop) and for the 4096-token level (2560 instead of 1280 waves)
+        const int rows16 = rows16_env >= 0 ? rows16_env : ((S <= 256 || (T >= 4096 && S >= 4096)) ? 4 : 0);
         if (rows16 == 16) {
             hipLaunchKernelGGL(attn16_bf16_kernel<16>, dim3(cdiv(T, 256), H, B), dim3(1024), 0, st, (const bf16*)q, (const bf16*)k,
                                (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c);

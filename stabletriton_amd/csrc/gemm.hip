@@ -1221,14 +1221,15 @@ extern "C" int st_ln_linear(const void* x, const float* row_stats, int row_stats
 // channels at a time: its K input values stay in registers, weight reads are wave-wide broadcasts
 // (all lanes of a wave work on the same channel strip).
 template <typename T, int KMAX>
-__global__ __launch_bounds__(256) void conv_thin_kernel(const GemmArgs p, int R) {
-    extern __shared__ __attribute__((aligned(16))) float wsm[];       // [K][Cout]
+__global__ __launch_bounds__(256) void conv_thin_kernel(const GemmArgs p, int R, int chunk) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];       // [K][chunk]: this block's output channels
     const T* x = (const T*)p.A;
     const T* w = (const T*)p.W;
     const int K = p.K, N = p.N;
-    for (int i = threadIdx.x; i < K * N; i += 256) {
-        const int n = i / K, k = i - n * K;
-        wsm[k * N + n] = Elem<T>::to_f(w[i]);
+    const int n_lo = blockIdx.y * chunk, n_hi = min(N, n_lo + chunk);  // blockIdx.y splits the output channels
+    for (int i = threadIdx.x; i < K * (n_hi - n_lo); i += 256) {
+        const int nl = i / K, k = i - nl * K;
+        wsm[k * chunk + nl] = Elem<T>::to_f(w[(size_t)(n_lo + nl) * K + k]);
     }
     __syncthreads();
     const int m = blockIdx.x * 256 + threadIdx.x;
@@ -1240,7 +1241,23 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GemmArgs p, int R)
     float xin[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) xin[k] = 0.f;
-    {
+    if (R == 3 && p.S == 3 && p.Cin == 4 && KMAX >= 36) {
+        // the SDXL conv_in shape, fully unrolled: static register indices, one 4-channel load per tap
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) {
+                int iy = oy * p.stride - p.pad + r, ix = ox * p.stride - p.pad + s_;
+                const int He = p.ups ? 2 * p.Hin : p.Hin, We = p.ups ? 2 * p.Win : p.Win;
+                const bool ok = iy >= 0 && ix >= 0 && iy < He && ix < We;
+                if (p.ups) { iy >>= 1; ix >>= 1; }
+                const T* xp = x + (((size_t)img * p.Hin + (ok ? iy : 0)) * p.Win + (ok ? ix : 0)) * 4;
+                float f[4];
+                Out4<T>::load(xp, f);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xin[(r * 3 + s_) * 4 + c] = ok ? f[c] : 0.f;
+            }
+    } else {
         int k = 0;
         for (int r = 0; r < R; ++r)
             for (int s_ = 0; s_ < p.S; ++s_) {
@@ -1256,7 +1273,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GemmArgs p, int R)
                 }
             }
     }
-    for (int n0 = 0; n0 < N; n0 += 16) {
+    for (int n0 = n_lo; n0 < n_hi; n0 += 16) {
         float acc[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -1264,7 +1281,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GemmArgs p, int R)
         for (int k = 0; k < KMAX; ++k) {
             if (k < K) {
                 const float xv = xin[k];
-                const float* wr = wsm + k * N + n0;
+                const float* wr = wsm + k * chunk + (n0 - n_lo);
 #pragma unroll
                 for (int e = 0; e < 16; e += 4) {
                     const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + e);
@@ -1319,11 +1336,18 @@ extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const v
     }
     // thin-input path: K = R*S*Cin small enough to keep one pixel's inputs in registers
     ST_REQUIRE(a.K <= 64 && Cout % 16 == 0, "conv2d: Cin=%d is neither a multiple of %d (implicit GEMM) nor thin (R*S*Cin <= 64, Cout %% 16 == 0)", Cin, kb);
-    const size_t lds = (size_t)a.K * Cout * sizeof(float);
+    // split the output channels over blockIdx.y until the launch has a few blocks per CU
+    const int bx = cdiv(a.M, 256);
+    int ny = cdiv(1024, bx);
+    if (ny > Cout / 16) ny = Cout / 16;
+    if (ny < 1) ny = 1;
+    const int chunk = cdiv(cdiv(Cout, ny), 16) * 16;
+    ny = cdiv(Cout, chunk);
+    const size_t lds = (size_t)a.K * chunk * sizeof(float);
     ST_REQUIRE(lds <= 64 * 1024, "conv2d(thin): weights do not fit LDS");
     if (dtype == ST_BF16)
-        hipLaunchKernelGGL((conv_thin_kernel<bf16, 64>), dim3(cdiv(a.M, 256)), dim3(256), lds, st, a, R);
+        hipLaunchKernelGGL((conv_thin_kernel<bf16, 64>), dim3(bx, ny), dim3(256), lds, st, a, R, chunk);
     else
-        hipLaunchKernelGGL((conv_thin_kernel<float, 64>), dim3(cdiv(a.M, 256)), dim3(256), lds, st, a, R);
+        hipLaunchKernelGGL((conv_thin_kernel<float, 64>), dim3(bx, ny), dim3(256), lds, st, a, R, chunk);
     return st_check_launch("conv2d(thin)");
 }

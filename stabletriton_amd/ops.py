@@ -54,7 +54,7 @@ def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     key = (device.type, device.index)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)      # hand-off words start at zero
         _workspaces[key] = ws
     return ws
 

@@ -73,7 +73,7 @@ def test_geglu(gpu, dtype, rows, F_):
 
 
 LIN_SHAPES = [(1024, 1280, 1280), (256, 640, 2560), (77, 2048, 640), (1, 1280, 320), (2, 320, 1280), (1000, 64, 200),
-              (130, 2816, 1280), (4096, 640, 640)]
+              (130, 2816, 1280), (4096, 640, 640), (1024, 5120, 1280), (96, 8192, 384)]      # the last two split K in-launch
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -88,6 +88,25 @@ def test_linear(gpu, dtype, M, K, N):
     r = rnd("lin.r", (M, N))
     assert_close(ops.linear(xg, wg, bg, residual=r.to(gpu, dtype)), F.linear(xr, wr, br) + rounded(r, dtype), dtype,
                  "linear+bias+residual")
+
+
+def test_split_k_is_bit_reproducible(gpu):
+    """The in-launch K split sums its slabs in slice order whichever block finishes last: repeated
+    launches (and launches interleaved with other split GEMMs that share the workspace) agree bitwise."""
+    dtype = torch.bfloat16
+    x, w, b = rnd("sk.x", (1024, 5120)).to(gpu, dtype), (rnd("sk.w", (1280, 5120)) * 5120 ** -0.5).to(gpu, dtype), rnd("sk.b", (1280,)).to(gpu, dtype)
+    x2, w2 = rnd("sk.x2", (77, 2048)).to(gpu, dtype), (rnd("sk.w2", (640, 2048)) * 2048 ** -0.5).to(gpu, dtype)
+    first = ops.linear(x, w, b)
+    for _ in range(5):
+        ops.linear(x2, w2, None)
+        assert torch.equal(ops.linear(x, w, b), first)
+    xc = rnd("sk.xc", (1, 1280, 32, 32)).to(gpu, dtype).contiguous(memory_format=torch.channels_last)
+    wc = (rnd("sk.wc", (1280, 1280, 3, 3)) * 11520 ** -0.5).to(gpu, dtype).contiguous(memory_format=torch.channels_last)
+    c0 = ops.conv2d(xc, wc, None, 1, 1)
+    for _ in range(3):
+        assert torch.equal(ops.conv2d(xc, wc, None, 1, 1), c0)
+    ref = F.conv2d(xc.float().cpu(), wc.float().cpu(), None, 1, 1)
+    assert_close(c0, ref, dtype, "conv split-K")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -126,7 +145,7 @@ def test_ln_linear(gpu, dtype, M, K, N, geglu):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,T,S,H", [(1, 256, 256, 10), (2, 128, 77, 5), (1, 1024, 1024, 20), (1, 100, 33, 2),
-                                     (1, 64, 1, 1), (1, 4096, 77, 10)])
+                                     (1, 64, 1, 1), (1, 4096, 77, 10), (1, 256, 640, 2), (1, 200, 1000, 3)])      # the last three (with 1024^2) take the key-split kernel
 def test_attention(gpu, dtype, B, T, S, H):
     C = H * 64
     q, k, v = rnd("att.q", (B, T, C)), rnd("att.k", (B, S, C)), rnd("att.v", (B, S, C))
