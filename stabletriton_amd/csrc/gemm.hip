@@ -34,6 +34,7 @@ struct GemmArgs {
     float* partial;              //   that finishes last sums the slabs in slice order and runs the epilogue (in-launch combine)
     size_t partial_bytes;
     int* tile_counters;          // one arrival counter per output tile (zero between launches)
+    int panel_h;                 // tile rows per panel of the block order (see gemm_dma_kernel); >= 1
     unsigned long long* probe;   // diagnostic builds only (-DST_PROBE): per-wave phase cycle sums
 };
 
@@ -590,7 +591,19 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     // split-K: tile-major block order, so a tile's slices sit next to each other on one XCD, where the
     // block that sums their slabs reads them fastest
     const int split = wg % p.splitk, tw = wg / p.splitk;
-    const int tile_n = tw / tiles_m, tile_m = tw - tile_n * tiles_m;
+    // Tiles are ordered panel by panel (panel_h tile rows each), column-major inside a panel, so the
+    // eight contiguous XCD shares of that order are rectangles: with one panel an XCD owns whole tile
+    // columns (every XCD re-reads all of A, W is read once); with two or four panels an XCD re-reads
+    // 1/2 or 1/4 of A and W is read by 2 or 4 XCDs.  The host picks what moves fewer bytes.
+    int tile_m, tile_n;
+    {
+        const int tiles_n_all = nblk / p.splitk / tiles_m;
+        const int per_panel = p.panel_h * tiles_n_all;
+        const int pn = tw / per_panel, rem = tw - pn * per_panel;
+        const int rows = min(p.panel_h, tiles_m - pn * p.panel_h);
+        tile_n = rem / rows;
+        tile_m = pn * p.panel_h + (rem - tile_n * rows);
+    }
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BNO;
 
@@ -986,7 +999,24 @@ static void launch_dma_one(const GemmArgs& a, hipStream_t st, int tiles_n) {
     auto kfn = gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, U, CONV, GEGLU, LNF>;
     static bool once = (allow_big_lds(kfn, lds), true);
     (void)once;
-    hipLaunchKernelGGL(kfn, dim3(cdiv(a.M, BM) * tiles_n * sk), dim3(WGM * WGN * 64), lds, st, a);
+    // XCD partition: bytes from beyond L2 ~ A * (8 / panels) + W * panels (A = activations, all of K)
+    GemmArgs b = a;
+    {
+        static const int force_pm = [] { const char* e = getenv("ST_GEMM_PANELS"); return e ? atoi(e) : 0; }();
+        const int tiles_m = cdiv(a.M, BM);
+        const double abytes = CONV ? (double)a.M * a.Cin * (a.ups ? 0.25 : 1.0) * a.stride * a.stride : (double)a.M * a.K;
+        const double wbytes = (double)(GEGLU ? 2 : 1) * a.N * a.K;
+        int best_p = 1;
+        double best = 1e300;
+        for (int pm = 1; pm <= 8; pm *= 2) {
+            if (pm > tiles_m) break;
+            const double c = abytes * (8.0 / pm) + wbytes * pm;
+            if (c < best) { best = c; best_p = pm; }
+        }
+        if (force_pm > 0) best_p = force_pm > tiles_m ? tiles_m : force_pm;
+        b.panel_h = cdiv(tiles_m, best_p);
+    }
+    hipLaunchKernelGGL(kfn, dim3(cdiv(a.M, BM) * tiles_n * sk), dim3(WGM * WGN * 64), lds, st, b);
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV>
