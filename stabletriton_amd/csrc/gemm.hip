@@ -568,8 +568,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     constexpr int KB = 8 * VEC;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;      // 1-KiB row blocks per wave
-    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split evenly over the waves");
+    // 1-KiB row blocks (DMA pieces) per wave.  When the pieces of a tile do not divide over the waves
+    // (BN = 80: ten pieces), the waves left without one issue a dummy DMA (16 zero bytes for every lane,
+    // one cache line) into a dump area, so that every wave counts the same vmcnt.
+    constexpr int A_PIECES = BM / 8, B_PIECES = BN / 8;
+    constexpr int A_IT = (A_PIECES + NW - 1) / NW, B_IT = (B_PIECES + NW - 1) / NW;
+    constexpr bool UNEVEN = (A_PIECES % NW != 0) || (B_PIECES % NW != 0);
     constexpr int G = (A_IT + B_IT) * U;                         // DMA instructions per wave per stage
     constexpr int A_BYTES = BM * 128, TILE = (BM + BN) * 128, STAGE = TILE * U;   // a stage = U consecutive K tiles
     static_assert(!GEGLU || (TN % 2 == 0), "GEGLU pairs value/gate n-tiles inside one wave");
@@ -577,6 +581,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     typedef typename Mma<T>::Frag Frag;
 
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* const dump = lds + STAGES * STAGE + BM * 8;          // after the ring and the LayerNorm (mean, rstd) rows
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -620,7 +625,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     for (int i = 0; i < A_IT; ++i) {
         const int row = (wave + i * NW) * 8 + lr;
         const int m = m0 + row;
-        const bool ok = m < p.M;
+        const bool ok = m < p.M && (!UNEVEN || wave + i * NW < A_PIECES);
         if (CONV) {
             const int hw = p.Hout * p.Wout;
             const int mm = ok ? m : 0;
@@ -651,7 +656,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
             wrow = ncol + half * p.N;
         } else {
             wrow = n0 + row;
-            ok = wrow < p.N;
+            ok = wrow < p.N && (!UNEVEN || wave + i * NW < B_PIECES);
         }
         b_ptr[i] = ok ? Wp + (size_t)wrow * p.K + lc * VEC : zeros;
         b_adv[i] = ok ? KB : 0;
@@ -743,10 +748,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
             } else {
                 src = a_ptr[i] + (size_t)kt * a_adv[i];
             }
-            dma16(src, base + (wave + i * NW) * 1024);
+            const int pa = wave + i * NW;
+            dma16(src, (!UNEVEN || pa < A_PIECES) ? base + pa * 1024 : dump);
         } else {
             const int j = i - A_IT;
-            dma16(b_ptr[j] + (size_t)kt * b_adv[j], base + A_BYTES + (wave + j * NW) * 1024);
+            const int pb = wave + j * NW;
+            dma16(b_ptr[j] + (size_t)kt * b_adv[j], (!UNEVEN || pb < B_PIECES) ? base + A_BYTES + pb * 1024 : dump);
         }
     };
     auto issue = [&](int st, int buf) {
@@ -814,6 +821,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     constexpr bool EARLY = (STAGES == 2);
     Frag fa[2][TM], fb[2][TN];
     auto read_group = [&](int buf, int g, int set) {
+#ifdef ST_FILL_ONLY
+        (void)buf; (void)g; (void)set; return;        // timing experiment: DMA stream only
+#endif
         const char* sa = lds + buf * STAGE + (g >> 1) * TILE;
         const char* sb = sa + A_BYTES;
         const int c = 4 * (g & 1) + q;
@@ -829,6 +839,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         }
     };
     auto mma_group = [&](int set) {
+#if defined(ST_FILL_ONLY)
+        (void)set; return;                              // timing experiment: no matrix work
+#elif defined(ST_NO_MMA)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[set][i]));      // keep the fragment reads alive
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[set][j]));
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -994,7 +1013,7 @@ static void launch_cfg(const GemmArgs& a, hipStream_t st) {
 
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV, bool GEGLU, bool LNF>
 static void launch_dma_one(const GemmArgs& a, hipStream_t st, int tiles_n) {
-    const size_t lds = (size_t)STAGES * U * (BM + BN) * 128 + (LNF ? (size_t)BM * 8 : 0);      // + LayerNorm (mean, rstd) per row
+    const size_t lds = (size_t)STAGES * U * (BM + BN) * 128 + (size_t)BM * 8 + 1024;      // ring + LayerNorm (mean, rstd) per row + DMA dump
     const int sk = a.splitk > 1 ? a.splitk : 1;
     auto kfn = gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, U, CONV, GEGLU, LNF>;
     static bool once = (allow_big_lds(kfn, lds), true);
@@ -1042,7 +1061,7 @@ static void launch_dma(const GemmArgs& a, hipStream_t st) {
 // overrides the heuristic for A/B runs.
 enum { CFG_64x64_S4 = 0, CFG_64x64_S8 = 1, CFG_64x64_S4_U2 = 2, CFG_128x64_S4 = 3, CFG_128x64_S3_U2 = 4,
        CFG_128x128_S3 = 5, CFG_64x64_S3 = 6, CFG_64x64_W8 = 7, CFG_128x64_W8 = 8, CFG_128x128_W8 = 9,
-       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_128x320_W8 = 23, CFG_128x256_W8 = 24, CFG_64x320_W8 = 25, CFG_COUNT };
+       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_128x320_W8 = 23, CFG_128x256_W8 = 24, CFG_64x320_W8 = 25, CFG_64x80_W4 = 26, CFG_128x80_W8 = 27, CFG_COUNT };
 
 static int cfg_bn(int cfg) {
     switch (cfg) {
@@ -1051,6 +1070,7 @@ static int cfg_bn(int cfg) {
         case CFG_64x64_W8_U2: case CFG_128x64_W8_S3: return 64;
         case CFG_256x256_W8: case CFG_128x256_W8: return 256;
         case CFG_128x320_W8: case CFG_64x320_W8: return 320;
+        case CFG_64x80_W4: case CFG_128x80_W8: return 80;
         default: return 128;
     }
 }
@@ -1100,7 +1120,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
         struct Cand { int cfg, bm, bn; double trip_us; };
         static const Cand cands[] = {{CFG_128x128_W8, 128, 128, 0.53}, {CFG_64x128_W8, 64, 128, 0.34}, {CFG_128x64_W8, 128, 64, 0.32},
                                      {CFG_64x64_W8, 64, 64, 0.19}, {CFG_128x320_W8, 128, 320, 1.38}, {CFG_64x320_W8, 64, 320, 0.64},
-                                     {CFG_256x128_W8, 256, 128, 0.72}};
+                                     {CFG_256x128_W8, 256, 128, 0.72}, {CFG_128x80_W8, 128, 80, 0.37}};
         static const int sks[] = {1, 2, 3, 4, 6, 8};
         static const int force_sk = [] { const char* e = getenv("ST_GEMM_SPLITK"); return e ? atoi(e) : -1; }();     // 0/1: never split
         const int nk = a.K / KB;
@@ -1109,7 +1129,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
         int cfg = CFG_64x64_W8, sk = 1;
         double best = 1e30;
         for (const Cand& c : cands) {
-            if ((a.epi & ST_EPI_GEGLU) && c.cfg == CFG_64x320_W8) continue;      // odd n-tiles per wave: no value/gate pairing
+            if ((a.epi & ST_EPI_GEGLU) && (c.cfg == CFG_64x320_W8 || c.bn == 80)) continue;      // odd n-tiles per wave: no value/gate pairing
             const long nt = tiles(c.bm, c.bn);
             const double trip = c.trip_us * (CONV ? 1.6 : 1.0);
             for (int k_ : sks) {
@@ -1143,7 +1163,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
         }
         if (sk > 1) {
             int bm = 128;
-            if (cfg == CFG_64x64_W8 || cfg == CFG_64x128_W8 || cfg == CFG_64x320_W8) bm = 64;
+            if (cfg == CFG_64x64_W8 || cfg == CFG_64x128_W8 || cfg == CFG_64x320_W8 || cfg == CFG_64x80_W4) bm = 64;
             if (cfg == CFG_256x128_W8) bm = 256;
             const long nt = tiles(bm, cfg_bn(cfg));
             if (nt <= 16384 && (size_t)sk * nt * bm * cfg_bn(cfg) * 4 + 65536 <= a.partial_bytes) {
@@ -1161,6 +1181,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             case CFG_256x128_W8: launch_dma<T, 256, 128, 4, 2, 3, 1, CONV>(b, st); break;
             case CFG_128x320_W8: launch_dma<T, 128, 320, 4, 2, 2, 1, CONV>(b, st); break;
             case CFG_64x320_W8: launch_dma<T, 64, 320, 2, 4, 3, 1, CONV>(b, st); break;
+            case CFG_128x80_W8: launch_dma<T, 128, 80, 8, 1, 4, 1, CONV>(b, st); break;
 #ifdef ST_DEV_CONFIGS
             case CFG_128x256_W8: launch_dma<T, 128, 256, 4, 2, 3, 1, CONV>(b, st); break;       // tile/pipeline variants kept for A/B sweeps (tools/op_bench.py with ST_GEMM_FORCE)
             case CFG_64x64_S4: launch_dma<T, 64, 64, 2, 2, 4, 1, CONV>(b, st); break;
@@ -1172,7 +1193,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             case CFG_64x64_S3: launch_dma<T, 64, 64, 2, 2, 3, 1, CONV>(b, st); break;
             case CFG_64x128_W8_S6: launch_dma<T, 64, 128, 2, 4, 6, 1, CONV>(b, st); break;
             case CFG_128x64_W8_S6: launch_dma<T, 128, 64, 4, 2, 6, 1, CONV>(b, st); break;
-            case CFG_128x128_W8_S4: launch_dma<T, 128, 128, 2, 4, 4, 1, CONV>(b, st); break;
+            case CFG_128x128_W8_S4: launch_dma<T, 128, 128, 2, 4, 3, 1, CONV>(b, st); break;       // (now the three-stage variant)
             case CFG_64x64_W8_S8: launch_dma<T, 64, 64, 4, 2, 8, 1, CONV>(b, st); break;
             case CFG_64x128_W8_U2: launch_dma<T, 64, 128, 2, 4, 3, 2, CONV>(b, st); break;
             case CFG_128x64_W8_U2: launch_dma<T, 128, 64, 4, 2, 3, 2, CONV>(b, st); break;
@@ -1182,7 +1203,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             case CFG_128x64_W8_S3: launch_dma<T, 128, 64, 4, 2, 3, 1, CONV>(b, st); break;
             case CFG_64x128_W8_S3: launch_dma<T, 64, 128, 2, 4, 3, 1, CONV>(b, st); break;
 #endif
-            default: launch_dma<T, 128, 128, 2, 4, 3, 1, CONV>(b, st); break;      // CFG_128x128_W8
+            default: launch_dma<T, 128, 128, 2, 4, 4, 1, CONV>(b, st); break;      // CFG_128x128_W8 (four stages: long-K shapes gain 15 %)
         }
         return st_check_launch(who);
     }
