@@ -539,8 +539,18 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 
+#ifndef ST_AUX_A
+#define ST_AUX_A 0
+#endif
+#ifndef ST_AUX_B
+#define ST_AUX_B 0
+#endif
+// cache-policy bits of the DMA (aux: 1 = sc0, 2 = nt, 16 = sc1): default policy for both operands - every
+// tile is re-read by the other blocks of its tile row / column through the XCD's L2 (measured: nt on
+// either stream is slower)
+template <int AUX = 0>
 __device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)src, (lds_void_t*)lds_wave_base, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)src, (lds_void_t*)lds_wave_base, 16, 0, AUX);
 }
 
 // number of a stage's G DMA entries that the first NG-1 MFMA groups issue (entry e goes with group e*NG/G)
@@ -749,11 +759,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
                 src = a_ptr[i] + (size_t)kt * a_adv[i];
             }
             const int pa = wave + i * NW;
-            dma16(src, (!UNEVEN || pa < A_PIECES) ? base + pa * 1024 : dump);
+            dma16<ST_AUX_A>(src, (!UNEVEN || pa < A_PIECES) ? base + pa * 1024 : dump);
         } else {
             const int j = i - A_IT;
             const int pb = wave + j * NW;
-            dma16(b_ptr[j] + (size_t)kt * b_adv[j], (!UNEVEN || pb < B_PIECES) ? base + A_BYTES + pb * 1024 : dump);
+            dma16<ST_AUX_B>(b_ptr[j] + (size_t)kt * b_adv[j], (!UNEVEN || pb < B_PIECES) ? base + A_BYTES + pb * 1024 : dump);
         }
     };
     auto issue = [&](int st, int buf) {
@@ -1061,7 +1071,7 @@ static void launch_dma(const GemmArgs& a, hipStream_t st) {
 // overrides the heuristic for A/B runs.
 enum { CFG_64x64_S4 = 0, CFG_64x64_S8 = 1, CFG_64x64_S4_U2 = 2, CFG_128x64_S4 = 3, CFG_128x64_S3_U2 = 4,
        CFG_128x128_S3 = 5, CFG_64x64_S3 = 6, CFG_64x64_W8 = 7, CFG_128x64_W8 = 8, CFG_128x128_W8 = 9,
-       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_128x320_W8 = 23, CFG_128x256_W8 = 24, CFG_64x320_W8 = 25, CFG_64x80_W4 = 26, CFG_128x80_W8 = 27, CFG_COUNT };
+       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_128x320_W8 = 23, CFG_128x256_W8 = 24, CFG_64x320_W8 = 25, CFG_64x80_W4 = 26, CFG_128x80_W8 = 27, CFG_128x160_W8 = 28, CFG_COUNT };
 
 static int cfg_bn(int cfg) {
     switch (cfg) {
@@ -1071,6 +1081,7 @@ static int cfg_bn(int cfg) {
         case CFG_256x256_W8: case CFG_128x256_W8: return 256;
         case CFG_128x320_W8: case CFG_64x320_W8: return 320;
         case CFG_64x80_W4: case CFG_128x80_W8: return 80;
+        case CFG_128x160_W8: return 160;
         default: return 128;
     }
 }
@@ -1182,7 +1193,9 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             case CFG_128x320_W8: launch_dma<T, 128, 320, 4, 2, 2, 1, CONV>(b, st); break;
             case CFG_64x320_W8: launch_dma<T, 64, 320, 2, 4, 3, 1, CONV>(b, st); break;
             case CFG_128x80_W8: launch_dma<T, 128, 80, 8, 1, 4, 1, CONV>(b, st); break;
+            case CFG_128x160_W8: launch_dma<T, 128, 160, 8, 1, 4, 1, CONV>(b, st); break;
 #ifdef ST_DEV_CONFIGS
+            case CFG_64x80_W4: launch_dma<T, 64, 80, 4, 1, 6, 1, CONV>(b, st); break;
             case CFG_128x256_W8: launch_dma<T, 128, 256, 4, 2, 3, 1, CONV>(b, st); break;       // tile/pipeline variants kept for A/B sweeps (tools/op_bench.py with ST_GEMM_FORCE)
             case CFG_64x64_S4: launch_dma<T, 64, 64, 2, 2, 4, 1, CONV>(b, st); break;
             case CFG_64x64_S8: launch_dma<T, 64, 64, 2, 2, 8, 1, CONV>(b, st); break;
