@@ -33,8 +33,8 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (guide: ~2.5 PF)
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
 BOUND = {"linear": "mfma", "conv2d": "mfma", "attention_self": "mfma", "attention_cross": "hbm",
          "group_norm": "hbm", "layer_norm": "hbm", "geglu": "hbm"}
-KERNEL = {"linear": "gemm_kernel<bf16,...,CONV=false>", "conv2d": "gemm_kernel<bf16,...,CONV=true>",
-          "attention_self": "attn_bf16_kernel", "attention_cross": "attn_bf16_kernel",
+KERNEL = {"linear": "gemm_dma_kernel<bf16,...,CONV=false>", "conv2d": "gemm_dma_kernel<bf16,...,CONV=true>",
+          "attention_self": "attn_bf16_kernel / attn16_bf16_kernel", "attention_cross": "attn16_bf16_kernel",
           "group_norm": "gn_stats_nhwc+gn_finalize+gn_apply_nhwc", "layer_norm": "ln_kernel", "geglu": "geglu_kernel"}
 
 
