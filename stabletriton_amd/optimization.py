@@ -18,7 +18,7 @@ from torch import fx, nn
 from . import _C
 from .optimizers import (dedupe_pure_calls, fuse_token_residual, fuse_attention, fuse_geglu, fuse_geglu_into_linear, fuse_layernorm_into_linear, fuse_residual_adds,
                          fuse_shared_input_linears,
-                         fuse_temb_add, fuse_timesteps, split_context, keep_channels_last, make_dynamic_graphed_callable, remove_dropout,
+                         fuse_temb_add, fuse_timesteps, split_context, split_region, keep_channels_last, make_dynamic_graphed_callable, remove_dropout,
                          replace_conv, replace_group_norm, replace_group_norm_activation, replace_layer_norm,
                          replace_linear, replace_linear_activ)
 
@@ -95,16 +95,38 @@ def _install_context_split(gm: fx.GraphModule) -> None:
     gm.rewrite_stats["context_outputs"] = len(
         [n for n in context_module.graph.nodes if n.op == "output"][0].args[0])
     gm.context_module = context_module
-    core = gm.forward                     # generated: (sample, timesteps, ehs, context_cache, added_cond_kwargs, **kw)
+    # The time path (sinusoidal features -> TimestepEmbedding MLPs -> the batched resnet time_emb_proj)
+    # depends only on the timestep and the added conditioning: a loop evaluates it once per schedule
+    # entry and feeds the per-step row back in (pipeline.DenoiseLoop).
+    time_module = None
+    if "timesteps" in names and "added_cond_kwargs" in names:
+        time_module = split_region(gm, ("timesteps", "added_cond_kwargs"), "time_cache", meta_sources=("sample",),
+                                   stop_at_slices=True, class_name="TimeModule")
+    core = gm.forward     # generated: (sample, timesteps, ehs, context_cache, added_cond_kwargs[, time_cache], **kw)
 
     def precompute_context(encoder_hidden_states):
         return context_module(encoder_hidden_states)
 
-    def forward_with_context(sample, timesteps, context_cache, added_cond_kwargs, **kwargs):
-        return core(sample, timesteps, None, context_cache, added_cond_kwargs, **kwargs)
+    if time_module is None:
+        def forward_with_context(sample, timesteps, context_cache, added_cond_kwargs, **kwargs):
+            return core(sample, timesteps, None, context_cache, added_cond_kwargs, **kwargs)
+    else:
+        gm.time_module = time_module
+        gm.rewrite_stats["time_outputs"] = len([n for n in time_module.graph.nodes if n.op == "output"][0].args[0])
+
+        def precompute_time(sample, timesteps, added_cond_kwargs):
+            """Time-path tensors of one schedule entry (`sample` is read for its batch size and dtype only)."""
+            return time_module(sample, timesteps, added_cond_kwargs)
+
+        def forward_with_context(sample, timesteps, context_cache, added_cond_kwargs, time_cache=None, **kwargs):
+            if time_cache is None:
+                time_cache = time_module(sample, timesteps, added_cond_kwargs)
+            return core(sample, timesteps, None, context_cache, added_cond_kwargs, time_cache, **kwargs)
+
+        gm.precompute_time = precompute_time
 
     def forward(sample, timesteps, encoder_hidden_states, added_cond_kwargs, **kwargs):
-        return core(sample, timesteps, None, context_module(encoder_hidden_states), added_cond_kwargs, **kwargs)
+        return forward_with_context(sample, timesteps, context_module(encoder_hidden_states), added_cond_kwargs, **kwargs)
 
     gm.precompute_context = precompute_context
     gm.forward_with_context = forward_with_context

@@ -7,7 +7,7 @@ from .replace_linear import replace_linear, replace_linear_activ
 from .replace_conv import replace_conv
 from .replace_timesteps import fuse_timesteps
 from .fuse_epilogues import fuse_geglu_into_linear, fuse_residual_adds, fuse_temb_add
-from .fuse_projections import fuse_layernorm_into_linear, fuse_shared_input_linears, split_context
+from .fuse_projections import fuse_layernorm_into_linear, fuse_shared_input_linears, split_context, split_region
 from .cleanup import dedupe_pure_calls, fuse_token_residual
 from .layout import keep_channels_last
 from .graphs import make_dynamic_graphed_callable

@@ -13,7 +13,7 @@ Q/K/V projection kernel, kernels/attention_proj.py:53-155):
 from __future__ import annotations
 
 import operator
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 from torch import fx, nn
@@ -121,19 +121,50 @@ def split_context(gm: fx.GraphModule, context_arg: str = "encoder_hidden_states"
     nothing could be hoisted.  `gm` gains a placeholder `context_cache` right after
     `context_arg`; its original placeholder stays (unused) so positions do not shift.
     """
+    return split_region(gm, (context_arg,), "context_cache", class_name="ContextModule")
+
+
+def split_region(gm: fx.GraphModule, sources: Sequence[str], cache_name: str, meta_sources: Sequence[str] = (),
+                 stop_at_slices: bool = False, class_name: str = "RegionModule") -> Optional[fx.GraphModule]:
+    """Move every node that depends only on the placeholders `sources` (plus parameters) into a new
+    GraphModule `region(*meta_sources, *sources) -> tuple`; `gm` gains the placeholder `cache_name`
+    after the last source and reads the region's outputs from it.
+
+    `meta_sources` are placeholders the region may use for metadata only (`x.shape`, `x.dtype`,
+    `x.device`): such getattr nodes (and pure functions of them) are duplicated into the region, not
+    moved.  With `stop_at_slices` tensor slicing (`t[..., a:b]`) of a region tensor stays in `gm`,
+    so one wide tensor crosses the boundary instead of its many views."""
     nodes = list(gm.graph.nodes)
-    ctx_ph = next((n for n in nodes if n.op == "placeholder" and n.target == context_arg), None)
-    if ctx_ph is None:
+    phs = {n.target: n for n in nodes if n.op == "placeholder"}
+    if any(s_ not in phs for s_ in sources) or any(m not in phs for m in meta_sources):
         return None
-    inside = {ctx_ph}
+    src_phs = [phs[s_] for s_ in sources]
+    meta_phs = {phs[m] for m in meta_sources}
+    inside = set(src_phs)              # depend on a source
+    meta_only = set()                  # depend on metadata of a meta source (and constants) only
     region: List[fx.Node] = []
     for n in nodes:
         if n.op in ("placeholder", "output", "get_attr"):
             continue
+        if (n.op == "call_function" and n.target is getattr and n.args[0] in meta_phs
+                and n.args[1] in ("shape", "dtype", "device")):
+            meta_only.add(n)
+            continue
         ins = n.all_input_nodes
-        if ins and all((i in inside) or i.op == "get_attr" for i in ins) and any(i in inside for i in ins):
-            inside.add(n)
-            region.append(n)
+        if not ins:
+            continue
+        ok = all((i in inside) or (i in meta_only) or i.op == "get_attr" for i in ins)
+        if not ok:
+            continue
+        if not any(i in inside for i in ins):
+            if all(i in meta_only for i in ins):
+                meta_only.add(n)
+            continue
+        if (stop_at_slices and n.op == "call_function" and n.target is operator.getitem
+                and n.args[0].op != "placeholder" and isinstance(n.args[1], (tuple, slice))):
+            continue
+        inside.add(n)
+        region.append(n)
     if not region:
         return None
     region_set = set(region)
@@ -141,25 +172,33 @@ def split_context(gm: fx.GraphModule, context_arg: str = "encoder_hidden_states"
     if not frontier:
         return None
 
-    # ---- build the context graph -------------------------------------------------------------
+    # ---- build the region graph --------------------------------------------------------------
     cg = fx.Graph()
-    env: Dict[fx.Node, fx.Node] = {ctx_ph: cg.placeholder(context_arg)}
+    env: Dict[fx.Node, fx.Node] = {}
+    order = [n for n in nodes if n.op == "placeholder" and (n in meta_phs or n in src_phs)]
+    for ph in order:
+        env[ph] = cg.placeholder(ph.target)
 
     def remap(x):
         if x in env:
             return env[x]
-        assert x.op == "get_attr", f"unexpected external dependency {x.format_node()}"
-        env[x] = cg.get_attr(x.target)
+        if x.op == "get_attr":
+            env[x] = cg.get_attr(x.target)
+        else:
+            assert x in meta_only, f"unexpected external dependency {x.format_node()}"
+            env[x] = cg.node_copy(x, remap)               # metadata helpers are duplicated on demand
         return env[x]
 
     for n in region:
         env[n] = cg.node_copy(n, remap)
     cg.output(tuple(env[n] for n in frontier))
-    context_module = fx.GraphModule(gm, cg, class_name="ContextModule")
+    region_module = fx.GraphModule(gm, cg, class_name=class_name)
+    region_module.input_names = [ph.target for ph in order]
 
     # ---- rewire the main graph ---------------------------------------------------------------
-    with gm.graph.inserting_after(ctx_ph):
-        cache = gm.graph.placeholder("context_cache")
+    last_src = [n for n in nodes if n.op == "placeholder" and n in src_phs][-1]
+    with gm.graph.inserting_after(last_src):
+        cache = gm.graph.placeholder(cache_name)
     first_user = next(n for n in gm.graph.nodes if n.op not in ("placeholder", "get_attr"))
     with gm.graph.inserting_before(first_user):
         for i, n in enumerate(frontier):
@@ -171,4 +210,4 @@ def split_context(gm: fx.GraphModule, context_arg: str = "encoder_hidden_states"
     gm.graph.eliminate_dead_code()
     gm.graph.lint()
     gm.recompile()
-    return context_module
+    return region_module

@@ -47,6 +47,10 @@ class DenoiseLoop:
         # UNet exposes the split (optimization._install_context_split)
         self._split = hasattr(unet, "precompute_context") and hasattr(unet, "forward_with_context")
         self.ctx = None
+        # the time path (timestep features, embedding MLPs, resnet time projections) depends only on the
+        # schedule entry and the added conditioning: one table row per step, filled in set_conditioning
+        self._tsplit = self._split and hasattr(unet, "precompute_time")
+        self.time_tables = None
 
     # ---- inputs --------------------------------------------------------------------------
     def set_conditioning(self, encoder_hidden_states, text_embeds, time_ids) -> None:
@@ -61,6 +65,15 @@ class DenoiseLoop:
             else:
                 for dst, src in zip(self.ctx, new):
                     dst.copy_(src)
+        if self._tsplit:
+            with torch.no_grad():
+                rows = [self.unet.precompute_time(self.x_in, self.timesteps[i], self._cond()) for i in range(self.n_steps)]
+                new = tuple(torch.stack([r[j] for r in rows]) for j in range(len(rows[0])))
+            if self.time_tables is None:
+                self.time_tables = new
+            else:
+                for dst, src in zip(self.time_tables, new):
+                    dst.copy_(src)
 
     def set_noise(self, latent_unit: torch.Tensor) -> None:
         """latent_unit ~ N(0,1); scaled by the scheduler's init sigma (fp32 state)."""
@@ -72,20 +85,25 @@ class DenoiseLoop:
     def _cond(self) -> Dict[str, torch.Tensor]:
         return {"text_embeds": self.text_embeds, "time_ids": self.time_ids}
 
-    def _unet(self, t):
+    def _unet(self, t, time_row=None):
         if self._split:
             if self.ctx is None:
                 raise RuntimeError("set_conditioning() must be called before running the loop")
+            if self._tsplit:
+                return self.unet.forward_with_context(self.x_in, t, self.ctx, self._cond(), time_cache=time_row)[0]
             return self.unet.forward_with_context(self.x_in, t, self.ctx, self._cond())[0]
         return self.unet(self.x_in, t, self.ehs, self._cond())[0]
 
     def _step_const(self, i: int) -> None:
-        eps = self._unet(self.timesteps[i])
+        row = tuple(tbl[i] for tbl in self.time_tables) if self._tsplit else None      # static views: no launch
+        eps = self._unet(self.timesteps[i], row)
         ops.euler_step(self.latent, eps, self.x_in, self.dsigma, self.in_scale, self.step_ids[i:i + 1])
 
     def _step_counted(self) -> None:
-        t = self.timesteps.index_select(0, self.step.long())[0]
-        eps = self._unet(t)
+        idx = self.step.long()
+        t = self.timesteps.index_select(0, idx)[0]
+        row = tuple(tbl.index_select(0, idx)[0] for tbl in self.time_tables) if self._tsplit else None
+        eps = self._unet(t, row)
         ops.euler_step(self.latent, eps, self.x_in, self.dsigma, self.in_scale, self.step)
         ops.step_advance(self.step, self.n_steps)
 

@@ -60,7 +60,11 @@ def test_pass_counts_match_reference_probe_on_sdxl():
     assert gm.rewrite_stats["geglu_in_gemm"] == 70 and gm.rewrite_stats["temb_rowbias"] == 17
     assert gm.rewrite_stats["layer_norm_in_gemm"] == 210 and gm.rewrite_stats["shared_input_gemms"] == 72
     _install_context_split(gm)
-    assert gm.rewrite_stats["context_outputs"] == 140
+    assert gm.rewrite_stats["context_outputs"] == 140 and gm.rewrite_stats["time_outputs"] == 1
+    # no M=batch GEMM is left in the per-step graph: the whole time path lives in gm.time_module
+    assert not [n for n in gm.graph.nodes if n.op == "call_function" and getattr(n.target, "__name__", "") == "timestep_wrapper"]
+    assert len([n for n in gm.time_module.graph.nodes if n.op == "call_function"
+                and getattr(n.target, "__name__", "") in ("linear_wrapper", "linear_cat_wrapper")]) == 4
     left = [n for n in gm.graph.nodes if n.op == "call_module"]
     assert not [n for n in left if isinstance(gm.get_submodule(n.target), (nn.Linear, nn.Conv2d, nn.GroupNorm, nn.LayerNorm, nn.Dropout))]
 
@@ -127,6 +131,11 @@ def test_rewritten_graph_is_equivalent_to_eager(monkeypatch, fuse):
             ctx = gm.precompute_context(x["encoder_hidden_states"])
             out2 = gm.forward_with_context(x["latent"], t, ctx, cond)[0]
             assert torch.equal(out, out2)
+            # the time path evaluated ahead (one table row per schedule entry) gives the same step
+            trow = gm.precompute_time(x["latent"], t, cond)
+            assert gm.rewrite_stats["time_outputs"] == len(trow) == 1
+            out3 = gm.forward_with_context(x["latent"], None, ctx, None, time_cache=trow)[0]
+            assert torch.equal(out, out3)
 
 
 def test_reference_style_self_tests(monkeypatch):
