@@ -40,6 +40,18 @@ static constexpr int ATT_KV = 64;          // keys per tile
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// max / sum with the lane 32 (or 16) away, through v_permlane32_swap / v_permlane16_swap instead of a
+// ds_bpermute: no LDS round trip and, above all, no s_waitcnt lgkmcnt(0) in the middle of the softmax
+// (that wait also drains the V fragment reads still in flight).  After the swap of two copies of x a lane
+// holds its own value in one register and its partner's in the other.  Inline asm: hipcc 7.2 folds the two
+// results of the builtin into one value (the sum came out as 2x); s_nop 1 covers the VALU-write hazard.
+__device__ __forceinline__ void att_swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void att_swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float xmax32(float x) { float a = x, b = x; att_swap32(a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xmax16(float x) { float a = x, b = x; att_swap16(a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xsum32(float x) { float a = x, b = x; att_swap32(a, b); return a + b; }
+__device__ __forceinline__ float xsum16(float x) { float a = x, b = x; att_swap16(a, b); return a + b; }
+
 typedef __attribute__((address_space(3))) const char lds_cchar;
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(lds_cchar*)p; }
 
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(NW * KS * 64) void attn_bf16_kernel(const bf16* __r
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xmax32(mx);
         const float m_new = fmaxf(m, mx * scale_log2e);
         float rs = 0.f;
 #pragma unroll
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(NW * KS * 64) void attn_bf16_kernel(const bf16* __r
         }
         l = l * a1 + l2 * a2;
     }
-    l += __shfl_xor(l, 32, 64);
+    l = xsum32(l);
     const float inv = 1.0f / l;
     if (q0 + r32 < T) {
         bf16* orow = O + (size_t)b * T * ldo + (size_t)(q0 + r32) * ldo + (size_t)head * ATT_D;
@@ -417,8 +429,7 @@ __global__ __launch_bounds__(NW * 64) void attn16_bf16_kernel(const bf16* __rest
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xmax32(xmax16(mx));
         const float m_new = fmaxf(m, mx * scale_log2e);
         float rs = 0.f;
 #pragma unroll
@@ -453,8 +464,7 @@ __global__ __launch_bounds__(NW * 64) void attn16_bf16_kernel(const bf16* __rest
         cur = nb;
     }
 
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = xsum32(xsum16(l));
     const float inv = 1.0f / l;
     if (q0 + c16 < T) {
         bf16* orow = O + (size_t)b * T * ldo + (size_t)(q0 + c16) * ldo + (size_t)head * ATT_D;

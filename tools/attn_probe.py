@@ -2,7 +2,7 @@
 import ctypes as C, os
 import torch
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.path.join(root, "stabletriton_amd/lib/probe/libst_probe.so"))
+lib = C.CDLL(os.path.join(root, "stabletriton_amd/lib/probe/libstabletriton_amd.so"))
 p = C.c_void_p
 lib.st_debug_set_att_probe.argtypes = [p]
 lib.st_attention.argtypes = [p, p, p, p] + [C.c_int] * 5 + [C.c_long] * 4 + [C.c_float, C.c_int, p]
