@@ -23,6 +23,7 @@ struct GemmArgs {
     int epi;
     // implicit-GEMM conv geometry (unused for dense)
     int Hin, Win, Cin, Hout, Wout, S, stride, pad, ups;
+    int R_, korder;              // filter rows; K traversal order of the conv loop (see gemm_dma_kernel)
     // LayerNorm folded into the GEMM (st_ln_linear): W already carries gamma; ln_c[n] = sum_k W'[n][k],
     // ln_d[n] = sum_k beta[k] W[n][k] (+ bias); y = rstd_m * (acc - mean_m * c_n) + d_n; the row statistics
     // come from the GEMM that produced x (it emits per-tile partial sums of the values it stores)
@@ -717,19 +718,38 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     // conv: position of the K tile that the next issue fetches, advanced once per stage (no divisions
     // in the loop; a K tile never straddles a filter tap because Cin is a multiple of the tile)
     int cs_r = 0, cs_s = 0, cs_c0 = 0;
+    // p.korder 1 walks K channel-slice-major (all R*S taps of 64 channels, then the next 64 channels): the
+    // nine shifted windows of one channel slice follow each other, so most of their lines are still in the
+    // CU's L1 when the next tap asks for them; 0 is tap-major (the memory order of W's K axis).
     if (CONV) {
-        const int k0 = kbase * KB;
-        const int tap = k0 / p.Cin;
-        cs_c0 = k0 - tap * p.Cin; cs_r = tap / p.S; cs_s = tap - cs_r * p.S;
+        if (p.korder) {
+            const int taps = p.R_ * p.S;
+            const int cs = kbase / taps, tap = kbase - cs * taps;
+            cs_c0 = cs * KB; cs_r = tap / p.S; cs_s = tap - cs_r * p.S;
+        } else {
+            const int k0 = kbase * KB;
+            const int tap = k0 / p.Cin;
+            cs_c0 = k0 - tap * p.Cin; cs_r = tap / p.S; cs_s = tap - cs_r * p.S;
+        }
     }
     auto conv_advance = [&](bool go) {              // branch-free: `go` false leaves the position where it is
-        cs_c0 += go ? KB * U : 0;
-        const bool w1 = cs_c0 >= p.Cin;
-        cs_c0 -= w1 ? p.Cin : 0;
-        cs_s += w1 ? 1 : 0;
-        const bool w2 = cs_s == p.S;
-        cs_s = w2 ? 0 : cs_s;
-        cs_r += w2 ? 1 : 0;
+        if (p.korder) {
+            cs_s += go ? 1 : 0;
+            const bool w1 = cs_s == p.S;
+            cs_s = w1 ? 0 : cs_s;
+            cs_r += w1 ? 1 : 0;
+            const bool w2 = cs_r == p.R_;
+            cs_r = w2 ? 0 : cs_r;
+            cs_c0 += w2 ? KB : 0;
+        } else {
+            cs_c0 += go ? KB * U : 0;
+            const bool w1 = cs_c0 >= p.Cin;
+            cs_c0 -= w1 ? p.Cin : 0;
+            cs_s += w1 ? 1 : 0;
+            const bool w2 = cs_s == p.S;
+            cs_s = w2 ? 0 : cs_s;
+            cs_r += w2 ? 1 : 0;
+        }
     };
     auto issue_one = [&](int st, int buf, int e) {
         const int u = e / PER_TILE, i = e - u * PER_TILE;
@@ -755,6 +775,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
                     ok = iy >= 0 && ix >= 0 && iy < p.Hin && ix < p.Win;
                 }
                 src = ok ? a_ptr[i] + ((size_t)iy * p.Win + ix) * p.Cin + c0 : zeros;
+#ifdef ST_CONV_SKIP_A
+                if (r != 0 || s_ != 0) src = zeros;          // timing experiment: fetch the input for one tap in nine
+#endif
             } else {
                 src = a_ptr[i] + (size_t)kt * a_adv[i];
             }
@@ -763,7 +786,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         } else {
             const int j = i - A_IT;
             const int pb = wave + j * NW;
-            dma16<ST_AUX_B>(b_ptr[j] + (size_t)kt * b_adv[j], (!UNEVEN || pb < B_PIECES) ? base + A_BYTES + pb * 1024 : dump);
+            const T* bsrc;
+            if (CONV && U == 1) bsrc = b_ptr[j] + (b_adv[j] ? (size_t)((cs_r * p.S + cs_s) * p.Cin + cs_c0) : 0);     // W[n][tap][c]
+            else bsrc = b_ptr[j] + (size_t)kt * b_adv[j];
+            dma16<ST_AUX_B>(bsrc, (!UNEVEN || pb < B_PIECES) ? base + A_BYTES + pb * 1024 : dump);
         }
     };
     auto issue = [&](int st, int buf) {
@@ -1385,6 +1411,10 @@ extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const v
     GemmArgs a = {};
     a.A = x; a.W = W; a.bias = bias; a.residual = residual; a.rowbias = rowbias; a.C = y;
     a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.S = S; a.stride = stride; a.pad = pad; a.ups = upsample2x ? 1 : 0;
+    {
+        static const int korder_env = [] { const char* e = getenv("ST_CONV_KORDER"); return e ? atoi(e) : -1; }();
+        a.R_ = R; a.korder = korder_env >= 0 ? korder_env : 0;
+    }
     a.Hout = (He + 2 * pad - R) / stride + 1;
     a.Wout = (We + 2 * pad - S) / stride + 1;
     ST_REQUIRE(a.Hout > 0 && a.Wout > 0, "conv2d: empty output");
