@@ -572,6 +572,57 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 
+// In-launch split-K combine (cdna guide, projection GEMM item 2).  Every slice stores its fp32
+// accumulators as a slab in FRAGMENT order (a wave-instruction writes 1 KiB contiguous) with
+// write-through stores and draws a ticket; the block that draws the last ticket re-reads ALL slabs in
+// slice order (bit-reproducible whichever block is last) and goes on to the epilogue (returns true).
+// Nobody waits on anybody, so there is no spin to hang in.  `lds` lends one word for the ticket.
+template <int TM, int TN, int TILE_ELEMS>
+__device__ __forceinline__ bool splitk_combine(const GemmArgs& p, f32x4 (&acc)[TM][TN], int tw, int split, char* lds, int t, int wave, int lane) {
+    float* slab0 = p.partial + (size_t)tw * p.splitk * TILE_ELEMS;
+    {
+        float* mine = slab0 + (size_t)split * TILE_ELEMS + (size_t)wave * (TM * TN * 256) + lane * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                // write-through (sc1) store: visible to every XCD once acknowledged, no release fence needed
+                const float* dst = mine + (i * TN + j) * 256;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(acc[i][j]) : "memory");
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its own stores ...
+    __syncthreads();                                          // ... before the one lane that signals for all
+    int* flag = reinterpret_cast<int*>(lds);
+    if (t == 0) *flag = __hip_atomic_fetch_add(p.tile_counters + tw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*flag != p.splitk - 1) return false;
+    if (t == 0) __hip_atomic_store(p.tile_counters + tw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // every slab load is sc1 (bypasses this CU's L1, which other CUs' stores never refresh)
+    for (int sl = 0; sl < p.splitk; ++sl) {
+        const float* src = slab0 + (size_t)sl * TILE_ELEMS + (size_t)wave * (TM * TN * 256) + lane * 4;
+        f32x4 part[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float* a_ = src + (i * TN + j) * 256;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[i][j]) : "v"(a_) : "memory");
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] += part[i][j];
+    }
+    return true;
+}
+
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV, bool GEGLU, bool LNF = false>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs p) {
     constexpr int NW = WGM * WGN;
@@ -952,52 +1003,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     wait_vmcnt<0>();                              // no LDS-DMA may outlive the workgroup's LDS allocation
     PROBE_STAMP(pr_end)
     if (p.splitk > 1) {
-        // In-launch split-K combine (cdna guide, projection GEMM item 2).  Every slice stores its fp32
-        // accumulators as a slab in FRAGMENT order (a wave-instruction writes 1 KiB contiguous), the
-        // block publishes with one agent-scope release and draws a ticket; the block that draws the
-        // last ticket acquires, re-reads ALL slabs in slice order (bit-reproducible whichever block is
-        // last) and runs the epilogue.  Nobody waits on anybody, so there is no spin to hang in.
-        float* slab0 = p.partial + (size_t)tw * p.splitk * (BM * BN);
-        {
-            float* mine = slab0 + (size_t)split * (BM * BN) + (size_t)wave * (TM * TN * 256) + lane * 4;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    // write-through (sc1) store: visible to every XCD once acknowledged, no release fence needed
-                    const float* dst = mine + (i * TN + j) * 256;
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(acc[i][j]) : "memory");
-                }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its own stores ...
-        __syncthreads();                                          // ... before the one lane that signals for all
-        int* flag = reinterpret_cast<int*>(lds);
-        if (t == 0) *flag = __hip_atomic_fetch_add(p.tile_counters + tw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (*flag != p.splitk - 1) return;
-        if (t == 0) __hip_atomic_store(p.tile_counters + tw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // every slab load is sc1 (bypasses this CU's L1, which other CUs' stores never refresh)
-        for (int sl = 0; sl < p.splitk; ++sl) {
-            const float* src = slab0 + (size_t)sl * (BM * BN) + (size_t)wave * (TM * TN * 256) + lane * 4;
-            f32x4 part[TM][TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const float* a_ = src + (i * TN + j) * 256;
-                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[i][j]) : "v"(a_) : "memory");
-                }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] += part[i][j];
-        }
+        if (!splitk_combine<TM, TN, BM * BN>(p, acc, tw, split, lds, t, wave, lane)) return;
     }
     if constexpr (LNF) {
         float mean[TM], rstd[TM];
@@ -1026,6 +1032,174 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         }
     }
 #endif
+}
+
+// =============================================================================
+// conv3x3, stride 1, pad 1, with the input patch resident in LDS ("halo" loop).
+// The K loop runs channel-slice-major: for every 64 input channels the (TH+2) x (W+2)
+// pixel patch that the block's TH full image rows need is staged ONCE (zero padding
+// included) and all nine taps read their A fragments from it at a pixel offset;
+// only the weights stream per tap (3-deep ring).  The implicit-GEMM loop above
+// fetches the same input pixels once per tap: for the 256x128 tiles this one issues
+// 2.3x fewer DMA pieces, which is what bounds these kernels.
+// Tile: BM = TH * W = 256 output pixels (TH full rows of one image) x BN = 128 channels,
+// 8 waves (4 x 2, 64 x 64 wave tiles); epilogue and in-launch split-K (over channel
+// slices) are shared with gemm_dma_kernel.
+// =============================================================================
+template <int WL2, int TH>
+__global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
+    typedef bf16 T;
+    constexpr int W = 1 << WL2, BM = TH * W, BN = 128, WGM = 4, WGN = 2, NW = 8;
+    static_assert(BM == 256, "tile = 256 output pixels");
+    constexpr int WTM = 64, WTN = 64, TM = 4, TN = 4, KB = 64;
+    constexpr int PWD = W + 2, PPX = (TH + 2) * PWD;                 // patch row pitch and pixel count
+    constexpr int PIECES_P = (PPX + 7) / 8, PB = PIECES_P * 1024;    // 1-KiB pieces (8 pixels x 128 B) of one patch
+    constexpr int PWV = (PIECES_P + NW - 1) / NW;                    // patch pieces per wave per channel slice
+    constexpr int STAGES = 3, WT_B = BN * 128, B_IT = BN / 8 / NW;   // weight ring, weight pieces per wave per trip
+    typedef typename Mma<T>::Frag Frag;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* const ring = lds + 2 * PB;
+    char* const dump = ring + STAGES * WT_B;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int lr = lane >> 3;
+    const int Hh = p.Hin;
+    const int tiles_m = p.M / BM;
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
+    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int split = wg % p.splitk, tw = wg / p.splitk;
+    const int tile_n = tw / tiles_m, tile_m = tw - tile_n * tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int rows_per_img = Hh / TH;
+    const int img = tile_m / rows_per_img, ty0 = (tile_m - img * rows_per_img) * TH;
+    const int ncs = p.Cin / KB;
+    const int cs_lo = (int)((long)split * ncs / p.splitk), cs_hi = (int)((long)(split + 1) * ncs / p.splitk);
+
+    const T* __restrict__ Xb = (const T*)p.A + (size_t)img * Hh * W * p.Cin;
+    const T* __restrict__ Wp = (const T*)p.W;
+    const T* zeros = reinterpret_cast<const T*>(g_zero16);
+
+    // ---- per-lane DMA sources -------------------------------------------------------------------
+    const T* pa_ptr[PWV];                           // patch pixel of piece e (channel slice 0), or null = zero fill
+#pragma unroll
+    for (int e = 0; e < PWV; ++e) {
+        const int pidx = e * NW + wave;
+        const int pp = pidx * 8 + lr;
+        const int py = pp / PWD, px = pp - py * PWD;
+        const int y = ty0 - 1 + py, x = px - 1;
+        const bool ok = pp < PPX && y >= 0 && y < Hh && x >= 0 && x < W;
+        const int lc = (lane & 7) ^ (pp & 7);
+        pa_ptr[e] = ok ? Xb + ((size_t)y * W + x) * p.Cin + lc * 8 : nullptr;
+    }
+    const T* pb_ptr[B_IT];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+        const int row = (wave + j * NW) * 8 + lr;
+        const int wrow = n0 + row;
+        pb_ptr[j] = wrow < p.N ? Wp + (size_t)wrow * p.K + ((lane & 7) ^ lr) * 8 : nullptr;
+    }
+    auto issue_patch = [&](int cs, int e) {         // piece e of this wave, channel slice cs (cs >= cs_hi: dummy)
+        const int pidx = e * NW + wave;
+        const bool live = pidx < PIECES_P && cs < cs_hi;
+        const T* src = (live && pa_ptr[e]) ? pa_ptr[e] + cs * KB : zeros;
+        dma16<0>(src, live ? lds + (cs & 1) * PB + pidx * 1024 : dump);
+    };
+    auto issue_w = [&](int cs, int tap, int slot) {  // the weight tile of trip (cs, tap); cs >= cs_hi: dummy
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            const bool live = cs < cs_hi;
+            const T* src = (live && pb_ptr[j]) ? pb_ptr[j] + (size_t)tap * p.Cin + cs * KB : zeros;
+            dma16<0>(src, live ? ring + slot * WT_B + (wave + j * NW) * 1024 : dump);
+        }
+    };
+
+    // ---- fragment addresses -----------------------------------------------------------------------
+    int pp0[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wm * WTM + i * 16 + r16;
+        pp0[i] = (row >> WL2) * PWD + (row & (W - 1));
+    }
+    int rowb[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) rowb[j] = wn * WTN + j * 16 + r16;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: the first patch, the first two weight tiles ------------------------------------------
+#pragma unroll
+    for (int e = 0; e < PWV; ++e) issue_patch(cs_lo, e);
+    issue_w(cs_lo, 0, 0);
+    issue_w(cs_lo, 1, 1);
+    wait_vmcnt<B_IT>();                              // all but the second weight tile have landed
+    __builtin_amdgcn_s_barrier();
+
+    int slot = 0;                                    // ring slot of the current trip
+    for (int cs = cs_lo; cs < cs_hi; ++cs) {
+        const char* patch = lds + (cs & 1) * PB;
+        auto trip = [&](auto tc) {
+            constexpr int tap = decltype(tc)::value;
+            constexpr int r = tap / 3, s_ = tap - r * 3;
+            // patch pieces of the NEXT channel slice go out with taps 0..4 (its buffer was last read in the
+            // previous slice), then the weight tile two trips ahead (its slot was read in the previous trip)
+            constexpr int n_p = tap < 5 ? PWV / 5 + (tap < PWV % 5 ? 1 : 0) : 0;
+            constexpr int p_lo = tap < 5 ? tap * (PWV / 5) + (tap < PWV % 5 ? tap : PWV % 5) : PWV;
+#pragma unroll
+            for (int e = 0; e < n_p; ++e) issue_patch(cs + 1, p_lo + e);
+            {
+                constexpr int tap2 = (tap + 2) % 9;
+                const int slot2 = slot >= 1 ? slot - 1 : 2;          // (slot + 2) % 3
+                issue_w(tap + 2 >= 9 ? cs + 1 : cs, tap2, slot2);
+            }
+            const char* wt = ring + slot * WT_B;
+            // (the row indices pass through an empty asm every trip: otherwise hipcc hoists all 9 x 2 x 8
+            // fragment addresses out of the channel-slice loop and spills)
+            int ppl[TM], rbl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { ppl[i] = pp0[i]; asm volatile("" : "+v"(ppl[i])); }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { rbl[j] = rowb[j]; asm volatile("" : "+v"(rbl[j])); }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                Frag fa[TM], fb[TN];
+                const int c = 4 * g + q;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int pp = ppl[i] + r * PWD + s_;
+                    fa[i] = *reinterpret_cast<const Frag*>(patch + pp * 128 + ((c ^ (pp & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[j] = *reinterpret_cast<const Frag*>(wt + rbl[j] * 128 + ((c ^ (rbl[j] & 7)) << 4));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], fb[j], fa[i]);
+            }
+            // the next trip's weight tile (issued one trip ago, before this trip's DMAs) must have landed - and
+            // with it, in issue order, every patch piece of the next slice
+            wait_vmcnt<n_p + B_IT>();
+            __builtin_amdgcn_s_barrier();
+            slot = slot == 2 ? 0 : slot + 1;
+        };
+        trip(std::integral_constant<int, 0>{}); trip(std::integral_constant<int, 1>{}); trip(std::integral_constant<int, 2>{});
+        trip(std::integral_constant<int, 3>{}); trip(std::integral_constant<int, 4>{}); trip(std::integral_constant<int, 5>{});
+        trip(std::integral_constant<int, 6>{}); trip(std::integral_constant<int, 7>{}); trip(std::integral_constant<int, 8>{});
+    }
+    wait_vmcnt<0>();                                 // no LDS-DMA may outlive the workgroup's LDS allocation
+    __builtin_amdgcn_s_barrier();
+    if (p.splitk > 1) {
+        if (!splitk_combine<TM, TN, BM * BN>(p, acc, tw, split, lds, t, wave, lane)) return;
+    }
+    gemm_epilogue<T, TM, TN, WTM, WTN, false, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n);
 }
 
 template <typename K>
@@ -1306,6 +1480,46 @@ extern "C" int st_ln_linear(const void* x, const float* row_stats, int row_stats
     return dtype == ST_BF16 ? gemm_dispatch<bf16, false>(a, st) : gemm_dispatch<float, false>(a, st);
 }
 
+// ---- host side of conv_halo_kernel --------------------------------------------------------------
+static bool conv_halo_applies(const GemmArgs& a, int R, int ups) {
+    static const bool off = [] { const char* e = getenv("ST_CONV_HALO"); return e && atoi(e) == 0; }();
+    if (off) return false;
+    if (R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || ups) return false;
+    if (a.Win != 32 && a.Win != 64) return false;
+    const int th = 256 / a.Win;
+    return a.Hin == a.Hout && a.Win == a.Wout && a.Hin % th == 0 && a.Cin % 64 == 0 && a.N % 4 == 0 && a.M % 256 == 0;
+}
+
+template <int WL2, int TH>
+static void conv_halo_go(const GemmArgs& b, int blocks, hipStream_t st) {
+    constexpr int W = 1 << WL2;
+    constexpr size_t lds = 2 * (size_t)(((TH + 2) * (W + 2) + 7) / 8) * 1024 + 3 * 128 * 128 + 1024;
+    auto kfn = conv_halo_kernel<WL2, TH>;
+    static bool once = (allow_big_lds(kfn, lds), true);
+    (void)once;
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, st, b);
+}
+
+static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
+    GemmArgs b = a;
+    const int tiles = (a.M / 256) * cdiv(a.N, 128);
+    const int ncs = a.Cin / 64;
+    // K split over channel slices: aim at one round of ~240 blocks; a slice keeps at least two channel slices
+    int sk = 1;
+    if (a.partial && tiles < 200) {
+        sk = (240 + tiles / 2) / tiles;
+        if (sk > ncs / 2) sk = ncs / 2;
+        if (sk < 1) sk = 1;
+        while (sk > 1 && ((size_t)sk * tiles * 256 * 128 * 4 + 65536 > a.partial_bytes || tiles > 16384)) --sk;
+    }
+    if (sk > 1) { b.splitk = sk; b.tile_counters = (int*)a.partial; b.partial = a.partial + 16384; }
+    b.stats_chunks = cdiv(a.N, 128);
+    if (a.row_stats && b.stats_chunks > a.stats_capacity) return st_fail("conv2d: row_stats buffer holds %d chunks, %d needed", a.stats_capacity, b.stats_chunks);
+    if (a.stats_chunks_out) *a.stats_chunks_out = a.row_stats ? b.stats_chunks : 0;
+    if (a.Win == 32) conv_halo_go<5, 8>(b, tiles * sk, st); else conv_halo_go<6, 4>(b, tiles * sk, st);
+    return st_check_launch("conv2d(halo)");
+}
+
 // ---- direct conv for thin inputs (conv_in: Cin = 4, K = R*S*Cin = 36) ---------------------
 // Weights sit in LDS as fp32 [K][Cout]; a thread owns one output pixel and a strip of 16 output
 // channels at a time: its K input values stay in registers, weight reads are wave-wide broadcasts
@@ -1426,6 +1640,7 @@ extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const v
     const int kb = dtype == ST_BF16 ? 64 : 32;
     if (Cin % kb == 0) {
         ST_REQUIRE(((uintptr_t)x | (uintptr_t)W | (uintptr_t)y) % 16 == 0, "conv2d: pointers must be 16-byte aligned");
+        if (dtype == ST_BF16 && conv_halo_applies(a, R, upsample2x)) return conv_halo_launch(a, st);
         return dtype == ST_BF16 ? gemm_dispatch<bf16, true>(a, st) : gemm_dispatch<float, true>(a, st);
     }
     // thin-input path: K = R*S*Cin small enough to keep one pixel's inputs in registers
