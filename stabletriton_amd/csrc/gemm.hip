@@ -1046,16 +1046,17 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
 // 8 waves (4 x 2, 64 x 64 wave tiles); epilogue and in-launch split-K (over channel
 // slices) are shared with gemm_dma_kernel.
 // =============================================================================
-template <int WL2, int TH>
+template <int WL2, int TH, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
     typedef bf16 T;
-    constexpr int W = 1 << WL2, BM = TH * W, BN = 128, WGM = 4, WGN = 2, NW = 8;
-    static_assert(BM == 256, "tile = 256 output pixels");
-    constexpr int WTM = 64, WTN = 64, TM = 4, TN = 4, KB = 64;
+    constexpr int W = 1 << WL2, BM = TH * W, NW = WGM * WGN;
+    static_assert(NW == 8 && BM % (16 * WGM) == 0 && BN % (16 * WGN) == 0 && W >= 16, "tile / wave layout");
+    constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 16, TN = WTN / 16, KB = 64;
     constexpr int PWD = W + 2, PPX = (TH + 2) * PWD;                 // patch row pitch and pixel count
     constexpr int PIECES_P = (PPX + 7) / 8, PB = PIECES_P * 1024;    // 1-KiB pieces (8 pixels x 128 B) of one patch
     constexpr int PWV = (PIECES_P + NW - 1) / NW;                    // patch pieces per wave per channel slice
-    constexpr int STAGES = 3, WT_B = BN * 128, B_IT = BN / 8 / NW;   // weight ring, weight pieces per wave per trip
+    constexpr int STAGES = 3, WT_B = BN * 128;                       // weight ring
+    constexpr int B_PIECES = BN / 8, B_IT = (B_PIECES + NW - 1) / NW;   // weight pieces (per wave per trip; idle slots issue a dummy)
     typedef typename Mma<T>::Frag Frag;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const ring = lds + 2 * PB;
@@ -1100,7 +1101,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
     for (int j = 0; j < B_IT; ++j) {
         const int row = (wave + j * NW) * 8 + lr;
         const int wrow = n0 + row;
-        pb_ptr[j] = wrow < p.N ? Wp + (size_t)wrow * p.K + ((lane & 7) ^ lr) * 8 : nullptr;
+        pb_ptr[j] = (wrow < p.N && wave + j * NW < B_PIECES) ? Wp + (size_t)wrow * p.K + ((lane & 7) ^ lr) * 8 : nullptr;
     }
     auto issue_patch = [&](int cs, int e) {         // piece e of this wave, channel slice cs (cs >= cs_hi: dummy)
         const int pidx = e * NW + wave;
@@ -1111,7 +1112,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
     auto issue_w = [&](int cs, int tap, int slot) {  // the weight tile of trip (cs, tap); cs >= cs_hi: dummy
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) {
-            const bool live = cs < cs_hi;
+            const bool live = cs < cs_hi && wave + j * NW < B_PIECES;
             const T* src = (live && pb_ptr[j]) ? pb_ptr[j] + (size_t)tap * p.Cin + cs * KB : zeros;
             dma16<0>(src, live ? ring + slot * WT_B + (wave + j * NW) * 1024 : dump);
         }
@@ -1485,16 +1486,17 @@ static bool conv_halo_applies(const GemmArgs& a, int R, int ups) {
     static const bool off = [] { const char* e = getenv("ST_CONV_HALO"); return e && atoi(e) == 0; }();
     if (off) return false;
     if (R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || ups) return false;
-    if (a.Win != 32 && a.Win != 64) return false;
-    const int th = 256 / a.Win;
-    return a.Hin == a.Hout && a.Win == a.Wout && a.Hin % th == 0 && a.Cin % 64 == 0 && a.N % 4 == 0 && a.M % 256 == 0;
+    if (a.Win != 32 && a.Win != 64 && a.Win != 128) return false;
+    const int bm = a.Win == 128 ? 128 : 256, th = bm / a.Win;
+    return a.Hin == a.Hout && a.Win == a.Wout && a.Hin % th == 0 && a.Cin % 64 == 0 && a.N % 4 == 0 && a.N >= 64 && a.M % bm == 0;
 }
 
-template <int WL2, int TH>
+template <int WL2, int TH, int BN, int WGM, int WGN>
 static void conv_halo_go(const GemmArgs& b, int blocks, hipStream_t st) {
     constexpr int W = 1 << WL2;
-    constexpr size_t lds = 2 * (size_t)(((TH + 2) * (W + 2) + 7) / 8) * 1024 + 3 * 128 * 128 + 1024;
-    auto kfn = conv_halo_kernel<WL2, TH>;
+    constexpr size_t lds = 2 * (size_t)(((TH + 2) * (W + 2) + 7) / 8) * 1024 + 3 * BN * 128 + 1024;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kfn = conv_halo_kernel<WL2, TH, BN, WGM, WGN>;
     static bool once = (allow_big_lds(kfn, lds), true);
     (void)once;
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, st, b);
@@ -1502,7 +1504,9 @@ static void conv_halo_go(const GemmArgs& b, int blocks, hipStream_t st) {
 
 static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
     GemmArgs b = a;
-    const int tiles = (a.M / 256) * cdiv(a.N, 128);
+    // 256 pixels x 128 channels at the 32- and 64-pixel levels; one 128-pixel row x 160 channels at the 128-pixel level
+    const int bm = a.Win == 128 ? 128 : 256, bn = a.Win == 128 ? 160 : 128;
+    const int tiles = (a.M / bm) * cdiv(a.N, bn);
     const int ncs = a.Cin / 64;
     // K split over channel slices: aim at one round of ~240 blocks; a slice keeps at least two channel slices
     int sk = 1;
@@ -1510,13 +1514,15 @@ static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
         sk = (240 + tiles / 2) / tiles;
         if (sk > ncs / 2) sk = ncs / 2;
         if (sk < 1) sk = 1;
-        while (sk > 1 && ((size_t)sk * tiles * 256 * 128 * 4 + 65536 > a.partial_bytes || tiles > 16384)) --sk;
+        while (sk > 1 && ((size_t)sk * tiles * bm * bn * 4 + 65536 > a.partial_bytes || tiles > 16384)) --sk;
     }
     if (sk > 1) { b.splitk = sk; b.tile_counters = (int*)a.partial; b.partial = a.partial + 16384; }
-    b.stats_chunks = cdiv(a.N, 128);
+    b.stats_chunks = cdiv(a.N, bn);
     if (a.row_stats && b.stats_chunks > a.stats_capacity) return st_fail("conv2d: row_stats buffer holds %d chunks, %d needed", a.stats_capacity, b.stats_chunks);
     if (a.stats_chunks_out) *a.stats_chunks_out = a.row_stats ? b.stats_chunks : 0;
-    if (a.Win == 32) conv_halo_go<5, 8>(b, tiles * sk, st); else conv_halo_go<6, 4>(b, tiles * sk, st);
+    if (a.Win == 32) conv_halo_go<5, 8, 128, 4, 2>(b, tiles * sk, st);
+    else if (a.Win == 64) conv_halo_go<6, 4, 128, 4, 2>(b, tiles * sk, st);
+    else conv_halo_go<7, 1, 160, 4, 2>(b, tiles * sk, st);
     return st_check_launch("conv2d(halo)");
 }
 
