@@ -1046,17 +1046,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
 // 8 waves (4 x 2, 64 x 64 wave tiles); epilogue and in-launch split-K (over channel
 // slices) are shared with gemm_dma_kernel.
 // =============================================================================
-template <int WL2, int TH, int BN, int WGM, int WGN>
+// UPS: the nearest-2x upsample folded in (W, TH count OUTPUT pixels; the patch holds INPUT pixels: output
+// (oy, ox) tap (r, s) reads input ((oy + r - 1) >> 1, (ox + s - 1) >> 1), zero outside).
+template <int WL2, int TH, int BN, int WGM, int WGN, bool UPS = false>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
     typedef bf16 T;
     constexpr int W = 1 << WL2, BM = TH * W, NW = WGM * WGN;
     static_assert(NW == 8 && BM % (16 * WGM) == 0 && BN % (16 * WGN) == 0 && W >= 16, "tile / wave layout");
+    static_assert(!UPS || TH % 2 == 0, "upsampled tiles start on an even output row");
     constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 16, TN = WTN / 16, KB = 64;
-    constexpr int PWD = W + 2, PPX = (TH + 2) * PWD;                 // patch row pitch and pixel count
+    constexpr int WI = UPS ? W / 2 : W;                              // input image width
+    constexpr int PROWS = UPS ? TH / 2 + 2 : TH + 2;                 // input rows the tile touches
+    constexpr int PWD = WI + 2, PPX = PROWS * PWD;                   // patch row pitch and pixel count
     constexpr int PIECES_P = (PPX + 7) / 8, PB = PIECES_P * 1024;    // 1-KiB pieces (8 pixels x 128 B) of one patch
     constexpr int PWV = (PIECES_P + NW - 1) / NW;                    // patch pieces per wave per channel slice
     constexpr int STAGES = 3, WT_B = BN * 128;                       // weight ring
-    constexpr int B_PIECES = BN / 8, B_IT = (B_PIECES + NW - 1) / NW;   // weight pieces (per wave per trip; idle slots issue a dummy)
+    constexpr int B_PIECES = BN / 8, B_IT = (B_PIECES + NW - 1) / NW;   // weight pieces (per wave per trip)
     typedef typename Mma<T>::Frag Frag;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const ring = lds + 2 * PB;
@@ -1067,7 +1072,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
     const int wm = wave / WGN, wn = wave - wm * WGN;
     const int r16 = lane & 15, q = lane >> 4;
     const int lr = lane >> 3;
-    const int Hh = p.Hin;
+    const int Hh = p.Hin;                            // input image height
     const int tiles_m = p.M / BM;
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
@@ -1075,12 +1080,13 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
     const int split = wg % p.splitk, tw = wg / p.splitk;
     const int tile_n = tw / tiles_m, tile_m = tw - tile_n * tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int rows_per_img = Hh / TH;
-    const int img = tile_m / rows_per_img, ty0 = (tile_m - img * rows_per_img) * TH;
+    const int rows_per_img = p.Hout / TH;
+    const int img = tile_m / rows_per_img, ty0 = (tile_m - img * rows_per_img) * TH;      // first OUTPUT row of the tile
+    const int iy_base = UPS ? (ty0 >> 1) - 1 : ty0 - 1;                                    // input row of patch row 0
     const int ncs = p.Cin / KB;
     const int cs_lo = (int)((long)split * ncs / p.splitk), cs_hi = (int)((long)(split + 1) * ncs / p.splitk);
 
-    const T* __restrict__ Xb = (const T*)p.A + (size_t)img * Hh * W * p.Cin;
+    const T* __restrict__ Xb = (const T*)p.A + (size_t)img * Hh * WI * p.Cin;
     const T* __restrict__ Wp = (const T*)p.W;
     const T* zeros = reinterpret_cast<const T*>(g_zero16);
 
@@ -1091,10 +1097,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
         const int pidx = e * NW + wave;
         const int pp = pidx * 8 + lr;
         const int py = pp / PWD, px = pp - py * PWD;
-        const int y = ty0 - 1 + py, x = px - 1;
-        const bool ok = pp < PPX && y >= 0 && y < Hh && x >= 0 && x < W;
+        const int y = iy_base + py, x = px - 1;
+        const bool ok = pp < PPX && y >= 0 && y < Hh && x >= 0 && x < WI;
         const int lc = (lane & 7) ^ (pp & 7);
-        pa_ptr[e] = ok ? Xb + ((size_t)y * W + x) * p.Cin + lc * 8 : nullptr;
+        pa_ptr[e] = ok ? Xb + ((size_t)y * WI + x) * p.Cin + lc * 8 : nullptr;
     }
     const T* pb_ptr[B_IT];
 #pragma unroll
@@ -1112,18 +1118,19 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
     auto issue_w = [&](int cs, int tap, int slot) {  // the weight tile of trip (cs, tap); cs >= cs_hi: dummy
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) {
-            const bool live = cs < cs_hi && wave + j * NW < B_PIECES;
+            if (wave + j * NW >= B_PIECES) continue;             // (uniform per wave: this wave has one piece fewer)
+            const bool live = cs < cs_hi;
             const T* src = (live && pb_ptr[j]) ? pb_ptr[j] + (size_t)tap * p.Cin + cs * KB : zeros;
             dma16<0>(src, live ? ring + slot * WT_B + (wave + j * NW) * 1024 : dump);
         }
     };
 
     // ---- fragment addresses -----------------------------------------------------------------------
-    int pp0[TM];
+    int pp0[TM];                                     // plain: patch pixel of tap (0,0); UPS: (output row, column) packed
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = wm * WTM + i * 16 + r16;
-        pp0[i] = (row >> WL2) * PWD + (row & (W - 1));
+        pp0[i] = UPS ? (((row >> WL2) << 16) | (row & (W - 1))) : (row >> WL2) * PWD + (row & (W - 1));
     }
     int rowb[TN];
 #pragma unroll
@@ -1140,7 +1147,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
     for (int e = 0; e < PWV; ++e) issue_patch(cs_lo, e);
     issue_w(cs_lo, 0, 0);
     issue_w(cs_lo, 1, 1);
-    wait_vmcnt<B_IT>();                              // all but the second weight tile have landed
+    // waves whose last weight slot does not exist (BN = 160: twenty pieces over eight waves) count one DMA fewer
+    constexpr bool UNEVEN_B = (B_PIECES % NW) != 0;
+    const bool short_wave = UNEVEN_B && wave >= B_PIECES % NW;
+    if (short_wave) wait_vmcnt<B_IT - 1>(); else wait_vmcnt<B_IT>();      // all but the second weight tile have landed
     __builtin_amdgcn_s_barrier();
 
     int slot = 0;                                    // ring slot of the current trip
@@ -1174,7 +1184,13 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
                 const int c = 4 * g + q;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const int pp = ppl[i] + r * PWD + s_;
+                    int pp;
+                    if constexpr (UPS) {
+                        const int uy = ty0 + (ppl[i] >> 16) + r - 1, ux = (ppl[i] & 0xffff) + s_ - 1;
+                        pp = ((uy >> 1) - iy_base) * PWD + (ux >> 1) + 1;
+                    } else {
+                        pp = ppl[i] + r * PWD + s_;
+                    }
                     fa[i] = *reinterpret_cast<const Frag*>(patch + pp * 128 + ((c ^ (pp & 7)) << 4));
                 }
 #pragma unroll
@@ -1187,7 +1203,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
             }
             // the next trip's weight tile (issued one trip ago, before this trip's DMAs) must have landed - and
             // with it, in issue order, every patch piece of the next slice
-            wait_vmcnt<n_p + B_IT>();
+            if (short_wave) wait_vmcnt<n_p + B_IT - 1>(); else wait_vmcnt<n_p + B_IT>();
             __builtin_amdgcn_s_barrier();
             slot = slot == 2 ? 0 : slot + 1;
         };
@@ -1485,18 +1501,24 @@ extern "C" int st_ln_linear(const void* x, const float* row_stats, int row_stats
 static bool conv_halo_applies(const GemmArgs& a, int R, int ups) {
     static const bool off = [] { const char* e = getenv("ST_CONV_HALO"); return e && atoi(e) == 0; }();
     if (off) return false;
-    if (R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || ups) return false;
+    if (R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1) return false;
+    if (a.Cin % 64 != 0 || a.N % 4 != 0 || a.N < 64) return false;
+    if (ups) {           // output 64 or 128 pixels wide, tiles of 256 output pixels
+        if (a.Wout != 2 * a.Win || a.Hout != 2 * a.Hin || (a.Wout != 64 && a.Wout != 128)) return false;
+        return a.Hout % (256 / a.Wout) == 0 && a.M % 256 == 0;
+    }
     if (a.Win != 32 && a.Win != 64 && a.Win != 128) return false;
     const int bm = a.Win == 128 ? 128 : 256, th = bm / a.Win;
-    return a.Hin == a.Hout && a.Win == a.Wout && a.Hin % th == 0 && a.Cin % 64 == 0 && a.N % 4 == 0 && a.N >= 64 && a.M % bm == 0;
+    return a.Hin == a.Hout && a.Win == a.Wout && a.Hin % th == 0 && a.M % bm == 0;
 }
 
-template <int WL2, int TH, int BN, int WGM, int WGN>
+template <int WL2, int TH, int BN, int WGM, int WGN, bool UPS = false>
 static void conv_halo_go(const GemmArgs& b, int blocks, hipStream_t st) {
     constexpr int W = 1 << WL2;
-    constexpr size_t lds = 2 * (size_t)(((TH + 2) * (W + 2) + 7) / 8) * 1024 + 3 * BN * 128 + 1024;
+    constexpr int PPX = UPS ? (TH / 2 + 2) * (W / 2 + 2) : (TH + 2) * (W + 2);
+    constexpr size_t lds = 2 * (size_t)((PPX + 7) / 8) * 1024 + 3 * BN * 128 + 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kfn = conv_halo_kernel<WL2, TH, BN, WGM, WGN>;
+    auto kfn = conv_halo_kernel<WL2, TH, BN, WGM, WGN, UPS>;
     static bool once = (allow_big_lds(kfn, lds), true);
     (void)once;
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, st, b);
@@ -1505,7 +1527,8 @@ static void conv_halo_go(const GemmArgs& b, int blocks, hipStream_t st) {
 static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
     GemmArgs b = a;
     // 256 pixels x 128 channels at the 32- and 64-pixel levels; one 128-pixel row x 160 channels at the 128-pixel level
-    const int bm = a.Win == 128 ? 128 : 256, bn = a.Win == 128 ? 160 : 128;
+    const bool ups = a.ups != 0;
+    const int bm = (!ups && a.Win == 128) ? 128 : 256, bn = (ups || a.Win == 128) ? 160 : 128;
     const int tiles = (a.M / bm) * cdiv(a.N, bn);
     const int ncs = a.Cin / 64;
     // K split over channel slices: aim at one round of ~240 blocks; a slice keeps at least two channel slices
@@ -1520,7 +1543,9 @@ static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
     b.stats_chunks = cdiv(a.N, bn);
     if (a.row_stats && b.stats_chunks > a.stats_capacity) return st_fail("conv2d: row_stats buffer holds %d chunks, %d needed", a.stats_capacity, b.stats_chunks);
     if (a.stats_chunks_out) *a.stats_chunks_out = a.row_stats ? b.stats_chunks : 0;
-    if (a.Win == 32) conv_halo_go<5, 8, 128, 4, 2>(b, tiles * sk, st);
+    if (ups && a.Wout == 64) conv_halo_go<6, 4, 160, 4, 2, true>(b, tiles * sk, st);
+    else if (ups) conv_halo_go<7, 2, 160, 4, 2, true>(b, tiles * sk, st);
+    else if (a.Win == 32) conv_halo_go<5, 8, 128, 4, 2>(b, tiles * sk, st);
     else if (a.Win == 64) conv_halo_go<6, 4, 128, 4, 2>(b, tiles * sk, st);
     else conv_halo_go<7, 1, 160, 4, 2>(b, tiles * sk, st);
     return st_check_launch("conv2d(halo)");

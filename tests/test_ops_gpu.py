@@ -171,7 +171,8 @@ CONVS = [  # N, Cin, H, W, Cout, k, stride, pad, upsample
     (1, 960, 16, 16, 320, 1, 1, 0, False), (1, 128, 16, 16, 128, 3, 1, 1, True), (1, 4, 32, 32, 320, 3, 1, 1, False),
     (2, 320, 24, 24, 4, 3, 1, 1, False), (1, 192, 9, 7, 64, 3, 1, 1, False), (1, 64, 9, 7, 64, 3, 2, 1, False),
     # the halo loop: 128-, 64- and 32-pixel rows, ragged channel tiles, two images
-    (1, 64, 128, 128, 320, 3, 1, 1, False), (1, 128, 64, 64, 200, 3, 1, 1, False), (2, 192, 32, 32, 136, 3, 1, 1, False)]
+    (1, 64, 128, 128, 320, 3, 1, 1, False), (1, 128, 64, 64, 200, 3, 1, 1, False), (2, 192, 32, 32, 136, 3, 1, 1, False),
+    (1, 64, 32, 32, 160, 3, 1, 1, True), (2, 64, 64, 64, 96, 3, 1, 1, True)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
