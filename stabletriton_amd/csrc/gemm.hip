@@ -1534,7 +1534,8 @@ static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
     // K split over channel slices: aim at one round of ~240 blocks; a slice keeps at least two channel slices
     int sk = 1;
     if (a.partial && tiles < 200) {
-        sk = (240 + tiles / 2) / tiles;
+        static const int target = [] { const char* e = getenv("ST_HALO_BLOCKS"); return e ? atoi(e) : 240; }();      // (developer knob)
+        sk = (target + tiles / 2) / tiles;
         if (sk > ncs / 2) sk = ncs / 2;
         if (sk < 1) sk = 1;
         while (sk > 1 && ((size_t)sk * tiles * bm * bn * 4 + 65536 > a.partial_bytes || tiles > 16384)) --sk;
