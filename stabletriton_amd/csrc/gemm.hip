@@ -1118,8 +1118,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
     auto issue_w = [&](int cs, int tap, int slot) {  // the weight tile of trip (cs, tap); cs >= cs_hi: dummy
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) {
-            if (wave + j * NW >= B_PIECES) continue;             // (uniform per wave: this wave has one piece fewer)
-            const bool live = cs < cs_hi;
+            // (BN = 160: twenty pieces over eight waves - the waves without a third piece issue a dummy, which keeps
+            // the trip straight-line code with one vmcnt for all waves; measured faster than a per-wave branch)
+            const bool live = cs < cs_hi && wave + j * NW < B_PIECES;
             const T* src = (live && pb_ptr[j]) ? pb_ptr[j] + (size_t)tap * p.Cin + cs * KB : zeros;
             dma16<0>(src, live ? ring + slot * WT_B + (wave + j * NW) * 1024 : dump);
         }
@@ -1147,10 +1148,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
     for (int e = 0; e < PWV; ++e) issue_patch(cs_lo, e);
     issue_w(cs_lo, 0, 0);
     issue_w(cs_lo, 1, 1);
-    // waves whose last weight slot does not exist (BN = 160: twenty pieces over eight waves) count one DMA fewer
-    constexpr bool UNEVEN_B = (B_PIECES % NW) != 0;
-    const bool short_wave = UNEVEN_B && wave >= B_PIECES % NW;
-    if (short_wave) wait_vmcnt<B_IT - 1>(); else wait_vmcnt<B_IT>();      // all but the second weight tile have landed
+    wait_vmcnt<B_IT>();                              // all but the second weight tile have landed
     __builtin_amdgcn_s_barrier();
 
     int slot = 0;                                    // ring slot of the current trip
@@ -1178,9 +1176,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
             for (int i = 0; i < TM; ++i) { ppl[i] = pp0[i]; asm volatile("" : "+v"(ppl[i])); }
 #pragma unroll
             for (int j = 0; j < TN; ++j) { rbl[j] = rowb[j]; asm volatile("" : "+v"(rbl[j])); }
+            // both 32-wide K halves are read up front: the second half's LDS latency hides under the first half's MFMAs
+            Frag fa[2][TM], fb[2][TN];
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                Frag fa[TM], fb[TN];
                 const int c = 4 * g + q;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
@@ -1191,19 +1190,27 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
                     } else {
                         pp = ppl[i] + r * PWD + s_;
                     }
-                    fa[i] = *reinterpret_cast<const Frag*>(patch + pp * 128 + ((c ^ (pp & 7)) << 4));
+                    fa[g][i] = *reinterpret_cast<const Frag*>(patch + pp * 128 + ((c ^ (pp & 7)) << 4));
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    fb[j] = *reinterpret_cast<const Frag*>(wt + rbl[j] * 128 + ((c ^ (rbl[j] & 7)) << 4));
+                    fb[g][j] = *reinterpret_cast<const Frag*>(wt + rbl[j] * 128 + ((c ^ (rbl[j] & 7)) << 4));
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], fb[j], fa[i]);
-            }
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], fb[g][j], fa[g][i]);
+            // pin the emitted order: DMAs, then every fragment read, then the MFMAs -
+            // left alone hipcc sinks each read to just before its first use and waits lgkmcnt(0) a dozen times per trip
+            __builtin_amdgcn_sched_group_barrier(0x020, n_p + B_IT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
+            __builtin_amdgcn_sched_barrier(0);
             // the next trip's weight tile (issued one trip ago, before this trip's DMAs) must have landed - and
             // with it, in issue order, every patch piece of the next slice
-            if (short_wave) wait_vmcnt<n_p + B_IT - 1>(); else wait_vmcnt<n_p + B_IT>();
+            wait_vmcnt<n_p + B_IT>();
             __builtin_amdgcn_s_barrier();
             slot = slot == 2 ? 0 : slot + 1;
         };
