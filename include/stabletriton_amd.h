@@ -134,6 +134,12 @@ int st_euler_step(float* latent, const void* eps, void* next_in, const float* ds
                   int dtype, void* stream);
 int st_step_advance(int* step, int n_steps, void* stream);
 
+/* Hint (host-side, per thread): the weight matrix the launch AFTER the next st_linear / st_ln_linear / st_conv2d
+ * call will read.  The next such call touches it (one dword per 128-byte line, spread over its blocks, during its
+ * epilogue) so that it sits in the memory-side cache when its own GEMM starts, and clears the hint.  Optional:
+ * without it cold weights cost every GEMM an HBM round trip in its prologue (no reference counterpart). */
+void st_hint_next_weights(const void* weights, size_t bytes);
+
 /* Sinusoidal timestep features (unet_pt.py:17-36; target of the reference's
  * fuse_timesteps pass, optimizers/replace_timesteps.py:33-58):
  *   out[b][j] = cos(t_b * f_j), out[b][dim/2 + j] = sin(t_b * f_j),

@@ -36,6 +36,7 @@ struct GemmArgs {
     size_t partial_bytes;
     int* tile_counters;          // one arrival counter per output tile (zero between launches)
     int panel_h;                 // tile rows per panel of the block order (see gemm_dma_kernel); >= 1
+    const void* next_w; size_t next_bytes;   // weights of the NEXT launch (host hint): touched during this epilogue
     unsigned long long* probe;   // diagnostic builds only (-DST_PROBE): per-wave phase cycle sums
 };
 
@@ -98,6 +99,20 @@ __device__ __forceinline__ unsigned long long probe_now() {
 #define PROBE_STAMP(var)
 #define PROBE_ADD(acc, t1, t0)
 #endif
+
+// The next launch's weights (host hint, st_hint_next_weights) are touched one dword per 128-byte line, each block
+// its slice, so that they sit in the memory-side cache when that launch starts (cold weights cost a GEMM 2-10 us:
+// DESIGN.md section 6).  The loads are fire-and-forget: `sink` must stay allocated until the wave ends.
+__device__ __forceinline__ void touch_next_weights(const GemmArgs& p, unsigned int& sink) {
+    if (!p.next_w) return;
+    const size_t lines = p.next_bytes >> 7;
+    const size_t per = (lines + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < lines ? lo + per : lines;
+    for (size_t l = lo + threadIdx.x; l < hi; l += blockDim.x) {
+        const char* a_ = (const char*)p.next_w + (l << 7);
+        asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(a_) : "memory");
+    }
+}
 
 template <typename T> struct Raw4 { typedef bf16x4 type; };
 template <> struct Raw4<float> { typedef f32x4 type; };
@@ -242,6 +257,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 #pragma unroll
         for (int i = 0; i < TM; ++i) { const int m = m0 + wm * WTM + i * 16 + r16; mok[i] = m < p.M; mrow[i] = mok[i] ? m : 0; }
         const T* __restrict__ bias = (const T*)p.bias;
+        unsigned int touch_next = 0;                       // destination of the next-weights touches (kept live to the end)
         // wide wave tiles take the load + arithmetic passes in column chunks of JC tiles (registers)
         constexpr int JC = TNO <= 5 ? TNO : 5;
         auto chunk = [&](auto jc) {
@@ -273,6 +289,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) rres[i][j] = ld_raw4<T>((const T*)p.residual + (size_t)mrow[i] * p.ldr + ncol[J0 + j]);
+            }
+            if constexpr (J0 == 0) {
+                // the next launch's weights: issued AFTER this pass's loads (so the arithmetic below does not wait for
+                // them), in flight while the arithmetic and the stores run; the wave's exit waits for them
+                touch_next_weights(p, touch_next);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -334,6 +355,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                     const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                     Out4<T>::store((T*)p.C + (size_t)mrow[i] * p.ldc + ncol[j], v);
                 }
+        asm volatile("" ::"v"(touch_next));
     }
 #ifdef ST_PROBE
     if (ptimes) ptimes[1] = probe_now();
@@ -1003,7 +1025,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     wait_vmcnt<0>();                              // no LDS-DMA may outlive the workgroup's LDS allocation
     PROBE_STAMP(pr_end)
     if (p.splitk > 1) {
-        if (!splitk_combine<TM, TN, BM * BN>(p, acc, tw, split, lds, t, wave, lane)) return;
+        if (!splitk_combine<TM, TN, BM * BN>(p, acc, tw, split, lds, t, wave, lane)) {
+            unsigned int sink = 0;                   // this block is done: its slice of the next weights, then exit
+            touch_next_weights(p, sink);
+            asm volatile("" ::"v"(sink));
+            return;
+        }
     }
     if constexpr (LNF) {
         float mean[TM], rstd[TM];
@@ -1221,7 +1248,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
     wait_vmcnt<0>();                                 // no LDS-DMA may outlive the workgroup's LDS allocation
     __builtin_amdgcn_s_barrier();
     if (p.splitk > 1) {
-        if (!splitk_combine<TM, TN, BM * BN>(p, acc, tw, split, lds, t, wave, lane)) return;
+        if (!splitk_combine<TM, TN, BM * BN>(p, acc, tw, split, lds, t, wave, lane)) {
+            unsigned int sink = 0;                   // this block is done: its slice of the next weights, then exit
+            touch_next_weights(p, sink);
+            asm volatile("" ::"v"(sink));
+            return;
+        }
     }
     gemm_epilogue<T, TM, TN, WTM, WTN, false, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n);
 }
@@ -1451,6 +1483,13 @@ static unsigned long long* g_probe = nullptr;
 extern "C" void st_debug_set_probe(void* p) { g_probe = (unsigned long long*)p; }
 #endif
 
+// Host hint: the weights the NEXT st_linear / st_ln_linear / st_conv2d launch of this thread will read; the launch
+// that follows the hint touches them during its epilogue and clears the hint.
+static thread_local const void* g_next_w = nullptr;
+static thread_local size_t g_next_bytes = 0;
+extern "C" void st_hint_next_weights(const void* p, size_t bytes) { g_next_w = p; g_next_bytes = bytes; }
+static void take_hint(GemmArgs& a) { a.next_w = g_next_w; a.next_bytes = g_next_bytes; g_next_w = nullptr; g_next_bytes = 0; }
+
 static int check_epilogue(const char* who, const GemmArgs& a) {
     ST_REQUIRE(!(a.epi & ST_EPI_BIAS) || a.bias, "%s: ST_EPI_BIAS without bias pointer", who);
     ST_REQUIRE(!(a.epi & ST_EPI_RESIDUAL) || a.residual, "%s: ST_EPI_RESIDUAL without residual pointer", who);
@@ -1479,6 +1518,7 @@ extern "C" int st_linear(const void* x, const void* W, const void* bias, const v
 #ifdef ST_PROBE
     a.probe = g_probe;
 #endif
+    take_hint(a);
     if (int e = check_epilogue("linear", a)) return e;
     hipStream_t st = (hipStream_t)stream;
     return dtype == ST_BF16 ? gemm_dispatch<bf16, false>(a, st) : gemm_dispatch<float, false>(a, st);
@@ -1500,6 +1540,7 @@ extern "C" int st_ln_linear(const void* x, const float* row_stats, int row_stats
     GemmArgs a = {};
     a.A = x; a.W = Wg; a.C = y; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.epi = epilogue;
     a.ln_c = c; a.ln_d = d; a.ln_eps = eps; a.splitk = 1; a.ln_stats = row_stats; a.ln_chunks = row_stats_chunks;
+    take_hint(a);
     hipStream_t st = (hipStream_t)stream;
     return dtype == ST_BF16 ? gemm_dispatch<bf16, false>(a, st) : gemm_dispatch<float, false>(a, st);
 }
@@ -1674,6 +1715,7 @@ extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const v
     a.M = N * a.Hout * a.Wout; a.N = Cout; a.K = R * S * Cin;
     a.lda = 0; a.ldc = Cout; a.ldr = Cout; a.rows_per_batch = a.Hout * a.Wout; a.epi = epilogue;
     a.splitk = 1; a.partial = (float*)workspace; a.partial_bytes = workspace ? workspace_bytes : 0;
+    take_hint(a);
     if (int e = check_epilogue("conv2d", a)) return e;
     hipStream_t st = (hipStream_t)stream;
     const int kb = dtype == ST_BF16 ? 64 : 32;

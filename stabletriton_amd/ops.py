@@ -8,6 +8,7 @@ launch goes to torch's current stream, so the ops are capturable.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -48,6 +49,55 @@ def _label(text: str) -> None:
     global _tag
     if _census is not None:
         _tag = text
+
+
+# ---- next-weights hints ------------------------------------------------------------------------
+# Every denoise step launches the same GEMMs over the same weights in the same order, and every one of
+# them finds its weights cold (5 GB of weights stream through per step).  The first step after
+# `weight_plan_begin()` records the order; later steps tell each launch which weights the launch after
+# it will read (st_hint_next_weights), and that launch touches them during its epilogue.
+_plan = []           # [(data_ptr, nbytes)] in launch order
+_plan_pos = 0
+_plan_state = "off"  # off | record | replay
+
+
+def weight_plan_begin() -> None:
+    """Call at the start of every step of a loop that repeats the same launches."""
+    global _plan_pos, _plan_state
+    if os.environ.get("ST_NO_WEIGHT_HINTS"):
+        _plan_state = "off"
+        return
+    if _plan_state == "off":
+        _plan_state = "record"
+        _plan.clear()
+    elif _plan_state == "record" and _plan_pos > 0:
+        _plan_state = "replay"
+    _plan_pos = 0
+
+
+def weight_plan_reset() -> None:
+    global _plan_state, _plan_pos
+    _plan_state, _plan_pos = "off", 0
+    _plan.clear()
+
+
+def _hint(lib, w: torch.Tensor) -> None:
+    """Called by the GEMM launchers right before their launch with the weights they are about to read."""
+    global _plan_pos, _plan_state
+    if _plan_state == "off":
+        return
+    me = (w.data_ptr(), w.numel() * w.element_size())
+    if _plan_state == "record":
+        _plan.append(me)
+        _plan_pos += 1
+        return
+    i = _plan_pos
+    if i >= len(_plan) or _plan[i] != me:            # the launch sequence changed: stop hinting
+        weight_plan_reset()
+        return
+    nxt = _plan[(i + 1) % len(_plan)]
+    lib.st_hint_next_weights(nxt[0], nxt[1])
+    _plan_pos += 1
 
 
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
@@ -209,6 +259,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         cap = min(STATS_MAX_CHUNKS, (N + 63) // 64)
         stats = torch.empty((M, cap, 2), dtype=torch.float32, device=x.device)
         chunks = ctypes.c_int(0)
+    _hint(lib, w)
     _label(f"M={M} N={N} K={K} epi={epi}{' stats' if emit_stats else ''}")
     _C.check(_timed("linear", 2.0 * M * w.shape[0] * K, float((M * K + w.numel() + M * N) * x.element_size()),
                     lib.st_linear, x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
@@ -236,6 +287,7 @@ def ln_linear(x: torch.Tensor, stats: "RowStats", w_folded: torch.Tensor, c: tor
     x2, M, lda = _rows2d(x)
     N = w_folded.shape[0] // 2 if geglu else w_folded.shape[0]
     out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+    _hint(lib, w_folded)
     _label(f"M={M} N={N} K={K} ln{' geglu' if geglu else ''}")
     _C.check(_timed("linear", 2.0 * M * w_folded.shape[0] * K, float((M * K + w_folded.numel() + M * N) * x.element_size()),
                     lib.st_ln_linear, x2.data_ptr(), stats.buf.data_ptr(), stats.chunks, w_folded.data_ptr(),
@@ -323,6 +375,7 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
             residual = residual.contiguous(memory_format=torch.channels_last)
         epi |= _C.EPI_RESIDUAL
     gws = _gemm_workspace(x.device)
+    _hint(lib, w)
     _label(f"Cin={Cin} H={H} Cout={Cout} k={R} s={stride} ups={int(upsample2x)} epi={epi}")
     _C.check(_timed("conv2d", 2.0 * N * Ho * Wo * Cout * R * S * Cin,
                     float((x.numel() + w.numel() + out.numel()) * x.element_size()), lib.st_conv2d, x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(rowbias), out.data_ptr(),
