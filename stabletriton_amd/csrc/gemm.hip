@@ -37,6 +37,7 @@ struct GemmArgs {
     int* tile_counters;          // one arrival counter per output tile (zero between launches)
     int panel_h;                 // tile rows per panel of the block order (see gemm_dma_kernel); >= 1
     const void* next_w; size_t next_bytes;   // weights of the NEXT launch (host hint): touched during this epilogue
+    int helper_blocks;           // > 0: that many extra blocks at the end of the grid (idle CUs) do the touching instead
     unsigned long long* probe;   // diagnostic builds only (-DST_PROBE): per-wave phase cycle sums
 };
 
@@ -103,11 +104,14 @@ __device__ __forceinline__ unsigned long long probe_now() {
 // The next launch's weights (host hint, st_hint_next_weights) are touched one dword per 128-byte line, each block
 // its slice, so that they sit in the memory-side cache when that launch starts (cold weights cost a GEMM 2-10 us:
 // DESIGN.md section 6).  The loads are fire-and-forget: `sink` must stay allocated until the wave ends.
-__device__ __forceinline__ void touch_next_weights(const GemmArgs& p, unsigned int& sink) {
-    if (!p.next_w) return;
+__device__ __forceinline__ void touch_next_weights(const GemmArgs& p, unsigned int& sink, bool helper = false) {
+    if (!p.next_w || (p.helper_blocks > 0) != helper) return;
     const size_t lines = p.next_bytes >> 7;
-    const size_t per = (lines + gridDim.x - 1) / gridDim.x;
-    const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < lines ? lo + per : lines;
+    // slices: over the helper blocks (the last helper_blocks of the grid) when there are any, else over all blocks
+    const size_t nsl = helper ? p.helper_blocks : gridDim.x;
+    const size_t me = helper ? blockIdx.x - (gridDim.x - p.helper_blocks) : blockIdx.x;
+    const size_t per = (lines + nsl - 1) / nsl;
+    const size_t lo = me * per, hi = lo + per < lines ? lo + per : lines;
     for (size_t l = lo + threadIdx.x; l < hi; l += blockDim.x) {
         const char* a_ = (const char*)p.next_w + (l << 7);
         asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(a_) : "memory");
@@ -673,7 +677,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     const int tiles_m = (p.M + BM - 1) / BM;
     // XCD-aware block order: blocks that share an XCD (blockIdx % 8) take consecutive
     // tiles, so the W panel of a tile column is fetched into one L2, not eight
-    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int nblk = gridDim.x - p.helper_blocks, bid = blockIdx.x;
+    if (bid >= nblk) {                               // helper block on an otherwise idle CU: the next launch's weights
+        unsigned int sink = 0;
+        touch_next_weights(p, sink, true);
+        asm volatile("" ::"v"(sink));
+        return;
+    }
     const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
     const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     constexpr int BNO = GEGLU ? BN / 2 : BN;
@@ -1301,7 +1311,12 @@ static void launch_dma_one(const GemmArgs& a, hipStream_t st, int tiles_n) {
         if (force_pm > 0) best_p = force_pm > tiles_m ? tiles_m : force_pm;
         b.panel_h = cdiv(tiles_m, best_p);
     }
-    hipLaunchKernelGGL(kfn, dim3(cdiv(a.M, BM) * tiles_n * sk), dim3(WGM * WGN * 64), lds, st, b);
+    const int main_blocks = cdiv(a.M, BM) * tiles_n * sk;
+    // launches that leave CUs idle hand the next-weights touches to helper blocks on those CUs (they run beside the K
+    // loops instead of extending the epilogues)
+    static const bool no_helpers = getenv("ST_NO_HELPER_BLOCKS") != nullptr;
+    b.helper_blocks = (b.next_w && main_blocks <= 208 && !no_helpers) ? (256 - main_blocks > 96 ? 96 : 256 - main_blocks) : 0;
+    hipLaunchKernelGGL(kfn, dim3(main_blocks + b.helper_blocks), dim3(WGM * WGN * 64), lds, st, b);
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV>
