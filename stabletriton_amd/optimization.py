@@ -15,7 +15,7 @@ from typing import Dict
 import torch
 from torch import fx, nn
 
-from . import _C
+from . import _C, ops
 from .optimizers import (dedupe_pure_calls, fuse_token_residual, fuse_attention, fuse_geglu, fuse_geglu_into_linear, fuse_layernorm_into_linear, fuse_residual_adds,
                          fuse_shared_input_linears,
                          fuse_temb_add, fuse_timesteps, split_context, split_region, keep_channels_last, make_dynamic_graphed_callable, remove_dropout,
@@ -109,6 +109,7 @@ def _install_context_split(gm: fx.GraphModule) -> None:
 
     if time_module is None:
         def forward_with_context(sample, timesteps, context_cache, added_cond_kwargs, **kwargs):
+            ops.weight_plan_begin()
             return core(sample, timesteps, None, context_cache, added_cond_kwargs, **kwargs)
     else:
         gm.time_module = time_module
@@ -119,6 +120,7 @@ def _install_context_split(gm: fx.GraphModule) -> None:
             return time_module(sample, timesteps, added_cond_kwargs)
 
         def forward_with_context(sample, timesteps, context_cache, added_cond_kwargs, time_cache=None, **kwargs):
+            ops.weight_plan_begin()       # one call = one pass over the same GEMMs: lets each launch warm the next one's weights
             if time_cache is None:
                 time_cache = time_module(sample, timesteps, added_cond_kwargs)
             return core(sample, timesteps, None, context_cache, added_cond_kwargs, time_cache, **kwargs)
@@ -126,7 +128,8 @@ def _install_context_split(gm: fx.GraphModule) -> None:
         gm.precompute_time = precompute_time
 
     def forward(sample, timesteps, encoder_hidden_states, added_cond_kwargs, **kwargs):
-        return forward_with_context(sample, timesteps, context_module(encoder_hidden_states), added_cond_kwargs, **kwargs)
+        ctx = context_module(encoder_hidden_states)          # (outside the per-step weight plan: a loop evaluates it once)
+        return forward_with_context(sample, timesteps, ctx, added_cond_kwargs, **kwargs)
 
     gm.precompute_context = precompute_context
     gm.forward_with_context = forward_with_context

@@ -95,13 +95,11 @@ class DenoiseLoop:
         return self.unet(self.x_in, t, self.ehs, self._cond())[0]
 
     def _step_const(self, i: int) -> None:
-        ops.weight_plan_begin()
         row = tuple(tbl[i] for tbl in self.time_tables) if self._tsplit else None      # static views: no launch
         eps = self._unet(self.timesteps[i], row)
         ops.euler_step(self.latent, eps, self.x_in, self.dsigma, self.in_scale, self.step_ids[i:i + 1])
 
     def _step_counted(self) -> None:
-        ops.weight_plan_begin()
         idx = self.step.long()
         t = self.timesteps.index_select(0, idx)[0]
         row = tuple(tbl.index_select(0, idx)[0] for tbl in self.time_tables) if self._tsplit else None
