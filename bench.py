@@ -5,130 +5,38 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one denoise iteration (UNet forward + scheduler update) of one
-prompt per GPU.  N>1 is launched by torch.distributed.run (one rank per GPU):
-rank 0 generates the synthetic weights and broadcasts them over RCCL, then every
-rank runs its own independent trajectory (no per-step traffic, weak scaling).
-Rank 0 prints ONE JSON line.  At N=1 the line also carries a per-kernel roofline
-(HIP-event census of one eager step) and the CPU baseline (the oracle restatement
-of the reference's eager path, timed on the host cores for a bounded sample).
+prompt per GPU.  N>1 runs one rank per GPU: under torch.distributed.run the
+ranks come from the environment; invoked plainly, this process spawns the N
+ranks itself (fresh child processes, before anything touches the GPU) and
+relays rank 0's line.  Rank 0 generates the synthetic weights and broadcasts
+them over RCCL, then every rank runs its own independent trajectory (no
+per-step traffic, weak scaling).  Rank 0 prints ONE JSON line.  At N=1 the line
+also carries a per-kernel roofline (HIP-event census of one eager step scaled to
+the graph-replay step time) and the CPU baseline (the oracle restatement of the
+reference's eager path, timed on the host cores for a bounded sample).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-from stabletriton_amd import ops, parallel, synth                      # noqa: E402
-from stabletriton_amd.optimization import optimize_model              # noqa: E402
-from stabletriton_amd.pipeline import DenoiseLoop                     # noqa: E402
-from stabletriton_amd.scheduler import euler_discrete_tables          # noqa: E402
-from stabletriton_amd.unet import SDXL_BASE, UNet2DConditionModel     # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (guide: ~2.5 PF)
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
 BOUND = {"linear": "mfma", "conv2d": "mfma", "attention_self": "mfma", "attention_cross": "hbm",
          "group_norm": "hbm", "layer_norm": "hbm", "geglu": "hbm"}
-KERNEL = {"linear": "gemm_dma_kernel<bf16,...,CONV=false>", "conv2d": "gemm_dma_kernel<bf16,...,CONV=true>",
+KERNEL = {"linear": "gemm_dma_kernel / gemm8p_kernel <bf16, CONV=false>", "conv2d": "conv_halo_kernel / gemm_dma_kernel<bf16, CONV=true>",
           "attention_self": "attn_bf16_kernel / attn16_bf16_kernel", "attention_cross": "attn16_bf16_kernel",
           "group_norm": "gn_stats_nhwc+gn_finalize+gn_apply_nhwc", "layer_norm": "ln_kernel", "geglu": "geglu_kernel"}
 
 
-def build_model(dev, dtype, rank, world):
-    with torch.device("meta"):
-        model = UNet2DConditionModel(SDXL_BASE)
-    model = model.to_empty(device=dev).to(dtype).eval().requires_grad_(False)
-    t0 = time.time()
-    if rank == 0:
-        synth.fill_module_(model, 0)
-    n_bcast = parallel.broadcast_module(model, src=0) if world > 1 else 0
-    torch.cuda.synchronize(dev)
-    return model, time.time() - t0, n_bcast
-
-
-def census(loop):
-    """One eager step with HIP events around every operator launch (same stream).
-
-    The host needs ~20-40 us of Python per launch, more than most kernels run, so a naive eager
-    pass would time an idle GPU waiting for the host.  The measured step is therefore enqueued
-    behind a spin kernel: by the time the GPU reaches it every launch and event record is already
-    in the queue, kernels run back to back as in the graph, and event deltas are device times."""
-    store = []
-    loop_mode, loop.mode = loop.mode, "eager"
-    ops.set_census(None)
-    loop.run_steps(1)                      # warm the eager path
-    torch.cuda.synchronize()
-    step0 = int(loop.step.item())
-    torch.cuda._sleep(int(6e8))            # ~0.25 s head start for the host
-    # cost of the event pair itself (nothing launched in between), measured in the same queued regime
-    empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
-    for a, b in empty:
-        a.record(); b.record()
-    ops.set_census(store)
-    for i in range(1):
-        loop._step_const((step0 + i) % loop.n_steps)
-    ops.set_census(None)
-    torch.cuda.synchronize()
-    loop.mode = loop_mode
-    pair_ms = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
-    fam = {}
-    for name, flops, nbytes, e0, e1, _tag in store:
-        f = fam.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
-        f["launches"] += 1
-        f["ms"] += max(e0.elapsed_time(e1) - pair_ms, 0.0)
-        f["flops"] += flops
-        f["bytes"] += nbytes
-    if os.environ.get("ST_CENSUS_SHAPES"):           # developer view: time per (operator, shape)
-        rows = {}
-        for name, flops, nbytes, e0, e1, tag in store:
-            r = rows.setdefault((name, tag), [0, 0.0, 0.0])
-            r[0] += 1; r[1] += max(e0.elapsed_time(e1) - pair_ms, 0.0); r[2] += flops
-        for (name, tag), (cnt, ms, fl) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
-            print(f"  {ms:7.3f} ms  x{cnt:3d}  {ms / cnt * 1e3:7.1f} us  {fl / max(ms, 1e-9) / 1e9:7.1f} TF/s  {name:16s} {tag}", file=sys.stderr)
-    return fam
-
-
-def measured_traffic(name):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json), or None."""
-    try:
-        import glob
-        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
-        return json.load(open(latest)).get(f"{name}_bytes_per_launch")
-    except Exception:
-        return None
-
-
-def roofline_of(name, f):
-    sec = f["ms"] * 1e-3
-    if BOUND[name] == "mfma":
-        ach, peak, unit = f["flops"] / sec / 1e12, PEAK_BF16_TFLOPS, "TFLOP/s"
-    else:
-        ach, peak, unit = f["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s"
-    return {"kernel": KERNEL[name], "op": name, "bound": BOUND[name], "achieved": round(ach, 2), "peak": peak, "unit": unit,
-            "frac": round(ach / peak, 4), "traffic": measured_traffic(name), "launches_per_step": f["launches"],
-            "avg_launch_us": round(f["ms"] * 1e3 / f["launches"], 2), "ms_per_step": round(f["ms"], 3)}
-
-
-def cpu_baseline(model, latent_hw):
-    """Oracle (CPU restatement of the reference eager path, fp32) on the host cores."""
-    from oracle import unet_oracle as orc          # checker/baseline only, never on the product path
-    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    x = synth.denoise_inputs(1, latent_hw, 1234)
-    cores = torch.get_num_threads()
-    with torch.no_grad():
-        t0 = time.time()
-        orc.unet_forward(sd, x["latent"], torch.tensor(981.0), x["encoder_hidden_states"], x["text_embeds"], x["time_ids"])
-        dt = time.time() - t0
-    return {"value": round(1.0 / dt, 5), "unit": "it/s", "cores": cores, "kind": "port",
-            "sample": f"1 UNet step, latent {latent_hw}x{latent_hw}, bs=1, fp32 eager torch on {cores} threads, "
-                      f"first call (no warm-up), {dt:.1f} s"}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -140,28 +48,295 @@ def main():
     ap.add_argument("--no-census", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a same-device rehearsal)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+# ---------------------------------------------------------------------------------------------------
+# plain `python bench.py --gpus N`: spawn the ranks (nothing in this process has touched the GPU yet)
+# ---------------------------------------------------------------------------------------------------
+def self_launch(args, cmd=None) -> int:
+    """Spawn `args.gpus` ranks of `cmd` (default: this script with the same arguments), relay rank 0's stdout,
+    return non-zero if any rank failed."""
+    if cmd is None:
+        cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    logdir = tempfile.mkdtemp(prefix="st_bench_")
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = open(os.path.join(logdir, f"rank{r}.out"), "w")
+        err = open(os.path.join(logdir, f"rank{r}.err"), "w")
+        procs.append((subprocess.Popen(cmd, env=env, stdout=out, stderr=err), out, err))
+    rc = 0
+    deadline = time.time() + 3000
+    for p, out, err in procs:
+        try:
+            code = p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            code = -9
+        rc = rc or code
+        out.close(); err.close()
+    if rc != 0:
+        for p, _, _ in procs:          # a failed rank leaves the others stuck in a collective: end exactly our children
+            if p.poll() is None:
+                p.kill()
+        for r in range(args.gpus):
+            tail = open(os.path.join(logdir, f"rank{r}.err")).read()[-2000:]
+            sys.stderr.write(f"---- rank {r} stderr (tail) ----\n{tail}\n")
+        return rc if rc > 0 else 1
+    sys.stdout.write(open(os.path.join(logdir, "rank0.out")).read())
+    sys.stdout.flush()
+    sys.stderr.write(open(os.path.join(logdir, "rank0.err")).read()[-4000:])
+    return 0
+
+
+def build_model(dev, dtype, rank, world):
+    import torch
+    from stabletriton_amd import parallel, synth
+    from stabletriton_amd.unet import SDXL_BASE, UNet2DConditionModel
+    with torch.device("meta"):
+        model = UNet2DConditionModel(SDXL_BASE)
+    model = model.to_empty(device=dev).to(dtype).eval().requires_grad_(False)
+    t0 = time.time()
+    if rank == 0:
+        synth.fill_module_(model, 0)
+    torch.cuda.synchronize(dev)
+    t_fill = time.time() - t0
+    t0 = time.time()
+    n_bcast = parallel.broadcast_module(model, src=0) if world > 1 else 0
+    torch.cuda.synchronize(dev)
+    return model, t_fill, time.time() - t0, n_bcast
+
+
+def census(loop):
+    """One eager step with HIP events around every operator launch (same stream).
+
+    The host needs ~20-40 us of Python per launch, more than most kernels run, so a naive eager
+    pass would time an idle GPU waiting for the host.  The measured step is therefore enqueued
+    behind a spin kernel: by the time the GPU reaches it every launch and event record is already
+    in the queue, kernels run back to back as in the graph, and event deltas are device times.
+
+    Returns (families, step_ms, marker_ms): per family the summed event deltas with the cost of one
+    event record removed, the step's device time with every record removed (operator launches plus
+    the torch glue kernels between them), and the per-record cost."""
+    import torch
+    from stabletriton_amd import ops
+    store = []
+    loop_mode, loop.mode = loop.mode, "eager"
+    ops.set_census(None)
+    loop.run_steps(1)                      # warm the eager path
+    torch.cuda.synchronize()
+    step0 = int(loop.step.item())
+    torch.cuda._sleep(int(6e8))            # ~0.25 s head start for the host
+    # cost of an event record (nothing launched in between), measured in the same queued regime
+    empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+    for a, b in empty:
+        a.record(); b.record()
+    ops.set_census(store)
+    loop._step_const(step0 % loop.n_steps)
+    ops.set_census(None)
+    torch.cuda.synchronize()
+    loop.mode = loop_mode
+    pair_ms = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
+    fam = {}
+    for name, flops, nbytes, e0, e1, _tag in store:
+        f = fam.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        f["launches"] += 1
+        f["ms"] += max(e0.elapsed_time(e1) - pair_ms, 0.0)
+        f["flops"] += flops
+        f["bytes"] += nbytes
+    wall = store[0][3].elapsed_time(store[-1][4])
+    step_ms = wall - (2 * len(store) - 1) * pair_ms
+    if os.environ.get("ST_CENSUS_SHAPES"):           # developer view: time per (operator, shape)
+        rows = {}
+        for name, flops, nbytes, e0, e1, tag in store:
+            r = rows.setdefault((name, tag), [0, 0.0, 0.0])
+            r[0] += 1; r[1] += max(e0.elapsed_time(e1) - pair_ms, 0.0); r[2] += flops
+        for (name, tag), (cnt, ms, fl) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+            print(f"  {ms:7.3f} ms  x{cnt:3d}  {ms / cnt * 1e3:7.1f} us  {fl / max(ms, 1e-9) / 1e9:7.1f} TF/s  {name:16s} {tag}", file=sys.stderr)
+        print(f"  census step {step_ms:.3f} ms (operators {sum(f['ms'] for f in fam.values()):.3f} ms, {len(store)} launches, "
+              f"event record {pair_ms * 1e3:.2f} us)", file=sys.stderr)
+    return fam, step_ms, pair_ms
+
+
+def committed_profile(name):
+    """Per-family numbers of the committed rocprofv3 run of this command (profiles/rNN_families.json, written by
+    tools/profile_families.py from the kernel-trace CSV) and the PMC traffic (profiles/rNN_traffic.json), or None."""
+    import glob
+    out = {}
+    try:
+        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_families.json")))[-1]
+        rec = json.load(open(latest)).get("families", {}).get(name)
+        if rec:
+            out = {"source": os.path.relpath(latest, ROOT), "ms_per_step": rec["ms_per_step"], "avg_launch_us": rec["avg_launch_us"],
+                   "launches_per_step": rec["launches_per_step"]}
+    except Exception:
+        pass
+    traffic = mfma_busy = None
+    try:
+        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+        t = json.load(open(latest))
+        traffic = t.get(f"{name}_bytes_per_launch")
+        mfma_busy = t.get(f"{name}_mfma_busy")
+    except Exception:
+        pass
+    return out, traffic, mfma_busy
+
+
+def roofline_of(name, f, scale):
+    """`scale` = graph-replay step time / census step time: a kernel in the replayed graph also pays the dependent-launch
+    boundary in front of it (rocprofv3 attributes it to the kernel), an event-bracketed one does not; the per-family times
+    are the census shares of the step the graph actually runs."""
+    ms = f["ms"] * scale
+    sec = ms * 1e-3
+    if BOUND[name] == "mfma":
+        ach, peak, unit = f["flops"] / sec / 1e12, PEAK_BF16_TFLOPS, "TFLOP/s"
+    else:
+        ach, peak, unit = f["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s"
+    prof, traffic, mfma_busy = committed_profile(name)
+    r = {"kernel": KERNEL[name], "op": name, "bound": BOUND[name], "achieved": round(ach, 2), "peak": peak, "unit": unit,
+         "frac": round(ach / peak, 4), "traffic": traffic, "launches_per_step": f["launches"],
+         "avg_launch_us": round(ms * 1e3 / f["launches"], 2), "ms_per_step": round(ms, 3),
+         "kernel_only_ms": round(f["ms"], 3)}
+    if mfma_busy is not None:
+        r["mfma_busy"] = mfma_busy
+    if prof:
+        work = f["flops"] / 1e12 if BOUND[name] == "mfma" else f["bytes"] / 1e9
+        prof["frac"] = round(work / (prof["ms_per_step"] * 1e-3) / peak, 4)
+        r["rocprof"] = prof
+    return r
+
+
+def host_cores():
+    """(threads to use, description): physical cores of the host, capped by this process's affinity mask and cgroup CPU quota."""
+    logical = os.cpu_count() or 1
+    phys = None
+    try:
+        seen = set()
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    seen.add((pid, cid))
+                pid = cid = None
+        phys = len(seen) or None
+    except OSError:
+        pass
+    use = phys or logical
+    try:
+        use = min(use, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+            use = min(use, quota)
+    except (OSError, ValueError):
+        pass
+    return max(1, use), f"{phys or '?'} physical / {logical} logical cores" + (f", cgroup quota {quota}" if quota else "")
+
+
+def cpu_baseline(model, latent_hw):
+    """Oracle (CPU restatement of the reference eager path, fp32) on the host cores: 1 warm-up + 2 timed steps, median."""
+    import torch
+    from oracle import unet_oracle as orc          # checker/baseline only, never on the product path
+    from stabletriton_amd import synth
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    x = synth.denoise_inputs(1, latent_hw, 1234)
+    cores, desc = host_cores()
+    before = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    times = []
+    try:
+        with torch.no_grad():
+            for _ in range(3):
+                t0 = time.time()
+                orc.unet_forward(sd, x["latent"], torch.tensor(981.0), x["encoder_hidden_states"], x["text_embeds"], x["time_ids"])
+                times.append(time.time() - t0)
+    finally:
+        torch.set_num_threads(before)
+    dt = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": round(1.0 / dt, 5), "unit": "it/s", "cores": cores, "kind": "port",
+            "sample": f"UNet steps at latent {latent_hw}x{latent_hw}, bs=1, fp32 eager torch (oracle) on {cores} threads ({desc}): "
+                      f"1 warm-up ({times[0]:.1f} s) + 2 timed ({times[1]:.1f}, {times[2]:.1f} s), median {dt:.1f} s per step"}
+
+
+def rccl_report(path):
+    """What RCCL logged at communicator init (NCCL_DEBUG=INFO to a per-rank file): rank count and transports seen."""
+    try:
+        txt = open(path, errors="replace").read()
+    except OSError:
+        return None
+    import re
+    nranks = sorted({int(m) for m in re.findall(r"nranks (\d+)", txt)})
+    via = sorted(set(re.findall(r"via ([A-Za-z0-9/_-]+)", txt)))
+    return {"nranks_logged": nranks[-1] if nranks else None, "transports": via[:6],
+            "channels": len(set(re.findall(r"Channel (\d+)", txt)))}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import torch
+    from stabletriton_amd import parallel, synth
+    from stabletriton_amd.optimization import optimize_model
+    from stabletriton_amd.pipeline import DenoiseLoop
+    from stabletriton_amd.scheduler import euler_discrete_tables
+
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    rccl_log = None
+    if world_env > 1 and args.backend == "nccl":
+        rccl_log = os.path.join(tempfile.gettempdir(), f"st_rccl_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('RANK', '0')}.log")
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,P2P,NET")
+        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
     rank, world, local = parallel.init_from_env(args.backend)
     if args.same_device:
         local = 0
-    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     dtype = torch.bfloat16
     n_sched = 50
 
-    model, t_weights, n_bcast = build_model(dev, dtype, rank, world)
+    model, t_fill, t_bcast, n_bcast = build_model(dev, dtype, rank, world)
+    ranks_seen = world
+    if world > 1:
+        ones = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
+        torch.distributed.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        assert ranks_seen == world, f"all_reduce saw {ranks_seen} ranks, expected {world}"
     gm = optimize_model(model, cuda_graph=False)
     mode = args.mode
     if mode == "auto":
         mode = "loop" if (args.steps % n_sched == 0 and args.warmup % n_sched == 0) else "step"
     loop = DenoiseLoop(gm, args.batch, args.latent, dtype, dev, euler_discrete_tables(n_sched), mode=mode)
     x = synth.denoise_inputs(args.batch, args.latent, 1234 + rank, device=dev)
-    loop.set_conditioning(x["encoder_hidden_states"].to(dtype), x["text_embeds"].to(dtype), x["time_ids"].to(dtype))
+    cond = (x["encoder_hidden_states"].to(dtype), x["text_embeds"].to(dtype), x["time_ids"].to(dtype))
+    loop.set_conditioning(*cond)
     loop.set_noise(x["latent"])
 
     with torch.no_grad():
+        # per-prompt setup (text K/V projections + the 50-row time table), amortised over a trajectory: timed on its own
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        loop.set_conditioning(*cond)
+        torch.cuda.synchronize(dev)
+        prompt_setup_ms = (time.perf_counter() - t0) * 1e3
+
         t0 = time.time()
         loop.capture()
         t_capture = time.time() - t0
@@ -178,25 +353,38 @@ def main():
         elapsed = parallel.max_over_ranks(elapsed, dev)
         finite = bool(torch.isfinite(loop.latent).all())
 
+        ms_per_step = elapsed / args.steps * 1e3
         result = {
             "metric": "denoise it/s, SDXL UNet 1024x1024 50-step, bs=1 per GPU",
             "value": round(world * args.batch * args.steps / elapsed, 3),
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"SDXL-base UNet, latent {args.latent}x{args.latent} (1024x1024 px), bs={args.batch}/GPU, "
                                    f"{n_sched}-step Euler-discrete loop, hipGraph mode={mode}, no CFG",
                        "parallelism": f"prompt-parallel x{world}", "weights": "synthetic seed 0",
                        "weight_broadcasts": n_bcast},
-            "finite": finite, "capture_s": round(t_capture, 2), "weights_s": round(t_weights, 2),
+            "finite": finite, "capture_s": round(t_capture, 2), "weights_s": round(t_fill, 2),
+            "prompt_setup_ms": round(prompt_setup_ms, 2),
+            "it_per_s_incl_prompt_setup": round(world * args.batch * n_sched / (n_sched * ms_per_step * 1e-3 + prompt_setup_ms * 1e-3), 3),
         }
+        if world > 1:
+            result["bcast_s"] = round(t_bcast, 3)
+            result["ranks_seen"] = ranks_seen
+            result["backend"] = args.backend
+            if rccl_log:
+                result["rccl"] = rccl_report(rccl_log)
         if rank == 0 and world == 1:
             if not args.no_census:
-                fam = census(loop)
-                roofs = {k: roofline_of(k, v) for k, v in fam.items()}
+                fam, census_ms, marker_ms = census(loop)
+                scale = ms_per_step / census_ms
+                roofs = {k: roofline_of(k, v, scale) for k, v in fam.items()}
                 dominant = max(fam, key=lambda k: fam[k]["ms"])
                 result["roofline"] = roofs[dominant]
                 result["kernels"] = sorted(roofs.values(), key=lambda r: -r["ms_per_step"])
+                result["census"] = {"step_ms": round(census_ms, 3), "graph_step_ms": round(ms_per_step, 3),
+                                    "event_record_us": round(marker_ms * 1e3, 2),
+                                    "operator_share": round(sum(f["ms"] for f in fam.values()) / census_ms, 4)}
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(model, args.latent)
     if rank == 0:

@@ -38,7 +38,8 @@ enum {
     ST_EPI_ROWBIAS   = 16   /* + rowbias[batch(m)][n]     (time-embedding add)    */
 };
 
-int         st_abi_version(void);          /* bumps on any signature or contract change (4: zeroed workspaces) */
+int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 6
+                                              (6: next-weights hint passed per call, st_timestep_sincos) */
 const char* st_last_error(void);           /* host string, thread-local     */
 
 /* GroupNorm (+SiLU).  Replaces reference group_norm_wrapper
@@ -81,12 +82,18 @@ int st_geglu(const void* state, const void* gate, void* out, int rows, int F,
  * `row_stats` (may be NULL): device buffer of M * row_stats_capacity float2; when given, the
  * kernel also writes, per output row and per N tile, (sum, sum of squares) of the values it
  * stored - the LayerNorm partials st_ln_linear consumes; the number of tiles actually used is
- * returned through the HOST pointer `row_stats_chunks` (0 = none written). */
+ * returned through the HOST pointer `row_stats_chunks` (0 = none written).
+ * `next_weights` / `next_weights_bytes` (may be NULL / 0; no reference counterpart): the weight matrix the
+ * GEMM-shaped launch AFTER this one will read.  This launch touches it (one dword per 128-byte line, spread
+ * over its blocks, during its epilogue or from helper blocks on idle CUs) so that it waits in the memory-side
+ * cache when its own GEMM starts; without it cold weights cost every GEMM an HBM round trip in its prologue.
+ * The buffer must stay allocated until this launch has run (also under graph replay). */
 int st_linear(const void* x, const void* W, const void* bias, const void* residual,
               const void* rowbias, void* y, int M, int N, int K,
               long lda, long ldc, long ldr, int rows_per_batch,
               int epilogue, int dtype, void* workspace, size_t workspace_bytes,
-              float* row_stats, int row_stats_capacity, int* row_stats_chunks, void* stream);
+              float* row_stats, int row_stats_capacity, int* row_stats_chunks,
+              const void* next_weights, size_t next_weights_bytes, void* stream);
 
 /* LayerNorm folded into the Linear (or GEGLU projection) that consumes it - the pair
  * layer_norm_wrapper -> linear_wrapper of the reference graph (replace_layernorm.py:17-24,
@@ -98,7 +105,8 @@ int st_linear(const void* x, const void* W, const void* bias, const void* residu
  * With ST_EPI_GEGLU, Wg has 2N rows and c, d 2N entries. */
 int st_ln_linear(const void* x, const float* row_stats, int row_stats_chunks, const void* Wg,
                  const float* c, const float* d, void* y, int M, int N, int K, long lda,
-                 long ldc, float eps, int epilogue, int dtype, void* stream);
+                 long ldc, float eps, int epilogue, int dtype,
+                 const void* next_weights, size_t next_weights_bytes, void* stream);
 
 /* Fused attention core: out = softmax(q k^T * scale) v per head, no mask.
  * Replaces attention_wrapper (optimizers/replace_attention.py:60-68); inputs
@@ -115,11 +123,12 @@ int st_attention(const void* q, const void* k, const void* v, void* out,
  * to cuDNN (optimizations.txt:5).  `upsample2x` folds a nearest 2x upsample of
  * the input into the gather (unet_pt.py:264-266).  Epilogue flags as for
  * st_linear; rowbias is (N_batch, Cout) (the time-embedding projection,
- * unet_pt.py:82-83), residual is NHWC (N,Hout,Wout,Cout).  workspace: as st_linear. */
+ * unet_pt.py:82-83), residual is NHWC (N,Hout,Wout,Cout).  workspace, next_weights: as st_linear. */
 int st_conv2d(const void* x, const void* W, const void* bias, const void* residual,
               const void* rowbias, void* y, int N, int Hin, int Win, int Cin,
               int Cout, int R, int S, int stride, int pad, int upsample2x,
-              int epilogue, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+              int epilogue, int dtype, void* workspace, size_t workspace_bytes,
+              const void* next_weights, size_t next_weights_bytes, void* stream);
 
 /* Euler-discrete update of the fp32 latent and preparation of the next UNet
  * input (restated diffusers EulerDiscreteScheduler, see
@@ -134,12 +143,6 @@ int st_euler_step(float* latent, const void* eps, void* next_in, const float* ds
                   int dtype, void* stream);
 int st_step_advance(int* step, int n_steps, void* stream);
 
-/* Hint (host-side, per thread): the weight matrix the launch AFTER the next st_linear / st_ln_linear / st_conv2d
- * call will read.  The next such call touches it (one dword per 128-byte line, spread over its blocks, during its
- * epilogue) so that it sits in the memory-side cache when its own GEMM starts, and clears the hint.  Optional:
- * without it cold weights cost every GEMM an HBM round trip in its prologue (no reference counterpart). */
-void st_hint_next_weights(const void* weights, size_t bytes);
-
 /* Sinusoidal timestep features (unet_pt.py:17-36; target of the reference's
  * fuse_timesteps pass, optimizers/replace_timesteps.py:33-58):
  *   out[b][j] = cos(t_b * f_j), out[b][dim/2 + j] = sin(t_b * f_j),
@@ -147,6 +150,11 @@ void st_hint_next_weights(const void* weights, size_t bytes);
  * t is fp32 on the device; out is (batch, dim) of `dtype`. */
 int st_timestep_features(const float* t, long t_stride, const int* step, void* out,
                          int batch, int dim, int dtype, void* stream);
+
+/* The reference's own timestep operator, elementwise (optimizers/replace_timesteps.py:33-40 ->
+ * kernels/timestep.py:13-45): x is fp32 of shape (..., half), n elements in all;
+ *   sin_out[i] = sin(x[i] * f_j), cos_out[i] = cos(x[i] * f_j), j = i % half, f_j = exp(-ln(1e4) * j / half). */
+int st_timestep_sincos(const float* x, float* sin_out, float* cos_out, long n, int half, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,9 @@ reference source is copied.
     python oracle/make_golden.py f1 f2          # seconds .. a minute
     python oracle/make_golden.py f3_64          # ~4 min   (50 Euler steps, latent 64)
     python oracle/make_golden.py f3_128         # ~20 min  (50 Euler steps, latent 128)
+    python oracle/make_golden.py f1_b4          # ~1 min   (BASELINE config #3 rows: batch 4, per-row distinct conditioning)
+    python oracle/make_golden.py f3_b2          # ~8 min   (two independent 50-step trajectories in one batch, latent 64)
+    python oracle/make_golden.py f3_cfg         # ~8 min   (the Diffusers call-site protocol: CFG batch 2, 50 steps, latent 64)
 """
 from __future__ import annotations
 
@@ -156,6 +159,71 @@ def f3(ref, hw):
     save(f"f3_euler50_latent{hw}", final=final, eps_abs_mean=np.asarray(trace, dtype=np.float32), latent_hw=hw)
 
 
+@torch.no_grad()
+def f1_b4(ref):
+    """BASELINE config #3 (bs=4, 77-token text conditioning, per-row distinct): one eager step of the
+    reference at latent 64 with a scalar timestep (reference: `timesteps.expand(batch)`, unet_pt.py:473)
+    and one with a different timestep per row (ComfyUI-style callers pass a (B,) tensor)."""
+    m = ref_unet(ref)
+    x = synth.denoise_inputs(4, 64, INPUT_SEED)
+    cond = {"text_embeds": x["text_embeds"], "time_ids": x["time_ids"]}
+    out = m(x["latent"], torch.tensor(500.0), x["encoder_hidden_states"], cond)[0]
+    tvec = torch.tensor([999.0, 700.0, 400.0, 100.0])
+    out_tvec = m(x["latent"], tvec, x["encoder_hidden_states"], cond)[0]
+    sd = {k: v for k, v in m.state_dict().items()}
+    mine = orc.unet_forward(sd, x["latent"], torch.tensor(500.0), x["encoder_hidden_states"], x["text_embeds"], x["time_ids"])
+    print("F1_b4 |oracle - reference| max =", float((mine - out).abs().max()), " |ref| max =", float(out.abs().max()))
+    mine = orc.unet_forward(sd, x["latent"], tvec, x["encoder_hidden_states"], x["text_embeds"], x["time_ids"])
+    print("F1_b4(tvec) |oracle - reference| max =", float((mine - out_tvec).abs().max()))
+    save("f1_unet_step_latent64_b4", out=out, out_tvec=out_tvec, timestep=500.0, timesteps_vec=tvec, latent_hw=64, batch=4)
+
+
+@torch.no_grad()
+def f3_b2(ref, hw=64):
+    """Two independent prompts in one batch through the 50-step Euler loop (the batched DenoiseLoop)."""
+    m = ref_unet(ref)
+    x = synth.denoise_inputs(2, hw, INPUT_SEED)
+    tables = euler_discrete_tables(50)
+    cond = {"text_embeds": x["text_embeds"], "time_ids": x["time_ids"]}
+    t0 = time.time()
+    n = [0]
+
+    def fn(x_in, t):
+        n[0] += 1
+        if n[0] % 5 == 0:
+            print(f"  step {n[0]}  {time.time() - t0:.0f}s", flush=True)
+        return m(x_in, t, x["encoder_hidden_states"], cond)[0]
+
+    final = orc.euler_denoise(fn, x["latent"], tables)
+    save(f"f3_euler50_latent{hw}_b2", final=final, latent_hw=hw, batch=2)
+
+
+CFG_SCALE = 5.0           # SDXL pipeline default guidance_scale
+
+
+@torch.no_grad()
+def f3_cfg(ref, hw=64):
+    """The protocol of the reference's call site (implementations/Diffusers/load_sdxl_pipeline.py:39-46 ->
+    diffusers 0.21.2 SDXL pipeline): ONE latent, the UNet sees batch 2 = [negative, positive] conditioning
+    every step, eps = eps_neg + g * (eps_pos - eps_neg), Euler update.  The loop code is orc.euler_denoise_cfg
+    on both sides."""
+    m = ref_unet(ref)
+    x = synth.denoise_inputs(2, hw, INPUT_SEED)          # row 0 = negative prompt, row 1 = prompt
+    tables = euler_discrete_tables(50)
+    cond = {"text_embeds": x["text_embeds"], "time_ids": x["time_ids"]}
+    t0 = time.time()
+    n = [0]
+
+    def fn(x_in2, t):
+        n[0] += 1
+        if n[0] % 5 == 0:
+            print(f"  step {n[0]}  {time.time() - t0:.0f}s", flush=True)
+        return m(x_in2, t, x["encoder_hidden_states"], cond)[0]
+
+    final = orc.euler_denoise_cfg(fn, x["latent"][:1], tables, CFG_SCALE)
+    save(f"f3_cfg50_latent{hw}", final=final, latent_hw=hw, guidance_scale=CFG_SCALE)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(os.cpu_count() or 8)
     ref = load_reference()
@@ -164,6 +232,12 @@ if __name__ == "__main__":
             f1(ref)
         elif what == "f2":
             f2(ref)
+        elif what == "f1_b4":
+            f1_b4(ref)
+        elif what == "f3_b2":
+            f3_b2(ref)
+        elif what == "f3_cfg":
+            f3_cfg(ref)
         elif what.startswith("f3_"):
             f3(ref, int(what[3:]))
         else:

@@ -189,3 +189,21 @@ def euler_denoise(unet_fn, latent_unit, tables, n_steps: Optional[int] = None) -
         eps = unet_fn(x_in, torch.tensor(float(tables.timesteps[i])))
         x = x + eps.float() * float(dsigma[i])
     return x
+
+
+def euler_denoise_cfg(unet_fn, latent_unit, tables, guidance_scale: float, n_steps: Optional[int] = None) -> torch.Tensor:
+    """Classifier-free-guidance form of the loop, as the reference's call site runs it
+    (implementations/Diffusers/load_sdxl_pipeline.py:39-46 -> diffusers 0.21.2
+    StableDiffusionXLPipeline.__call__: `latent_model_input = cat([latents] * 2)`,
+    `noise_pred = uncond + g * (text - uncond)`; third-party arithmetic, parity unpinned like
+    the scheduler).  `unet_fn(x_in2, t)` takes the duplicated (2, ...) input, row 0 = negative
+    conditioning; `latent_unit` is (1, ...)."""
+    x = latent_unit.float() * tables.init_noise_sigma
+    n = tables.n_steps if n_steps is None else n_steps
+    in_scale, dsigma = tables.in_scale(), tables.dsigma()
+    for i in range(n):
+        x_in = torch.cat([x, x]) * float(in_scale[i])
+        eps2 = unet_fn(x_in, torch.tensor(float(tables.timesteps[i]))).float()
+        eps = eps2[0:1] + guidance_scale * (eps2[1:2] - eps2[0:1])
+        x = x + eps * float(dsigma[i])
+    return x

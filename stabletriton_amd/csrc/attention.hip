@@ -18,6 +18,16 @@
 #include "common.h"
 #include <stdlib.h>
 
+static inline int att_dev_env_int(const char* name, int dflt) {      // developer knobs: -DST_DEV_CONFIGS builds only
+#ifdef ST_DEV_CONFIGS
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
 #ifdef ST_PROBE
 static unsigned long long* g_att_probe = nullptr;
 extern "C" void st_debug_set_att_probe(void* p) { g_att_probe = (unsigned long long*)p; }
@@ -570,12 +580,12 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
         const float c = scale * 1.4426950408889634f;
         // waves (32 query rows each) per block: fewer rows per block = more blocks to spread over
         // the 256 CUs and to co-schedule (MFMA of one wave under the softmax VALU of another)
-        static const int force_nw = [] { const char* e = getenv("ST_ATT_NW"); return e ? atoi(e) : 0; }();
+        static const int force_nw = att_dev_env_int("ST_ATT_NW", 0);
         // measured (tools/op_bench.py): the loop is latency-bound, so the K/V staging shared by more
         // waves wins over more blocks; 8 waves once that still leaves >= 128 blocks, else 4
         int nw = ((long)cdiv(T, 256) * H * B >= 128 && S > 256) ? 8 : 4;
         if (force_nw == 1 || force_nw == 2 || force_nw == 4 || force_nw == 8) nw = force_nw;
-        static const int rows16_env = [] { const char* e = getenv("ST_ATT_R16"); return e ? atoi(e) : -1; }();
+        static const int rows16_env = att_dev_env_int("ST_ATT_R16", -1);
         // measured (tools/op_bench.py): 16-row waves win for the 77-key text context (more waves for a
         // two-tile loop) and for the 4096-token level (2560 instead of 1280 waves)
         const int rows16 = rows16_env >= 0 ? rows16_env : ((S <= 256 || (T >= 4096 && S >= 4096)) ? 4 : 0);
@@ -595,7 +605,7 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
         constexpr size_t RING = 3 * 2 * ATT_KV * 128;       // one DMA ring: three (K, V) tile buffers
         // key split: launches that give most SIMDs a single wave (SDXL's 32x32 level: 160 blocks of 4 waves)
         // run two key groups per block instead - twice the waves, half the tiles each, one LDS merge
-        static const int force_ks = [] { const char* e = getenv("ST_ATT_KS"); return e ? atoi(e) : -1; }();
+        static const int force_ks = att_dev_env_int("ST_ATT_KS", -1);
         const bool split = force_ks >= 0 ? force_ks == 2 : (nw == 4 && (long)cdiv(T, 128) * H * B <= 256 && S >= 512);
         if (split) {
             auto kfn = attn_bf16_kernel<4, 2>;

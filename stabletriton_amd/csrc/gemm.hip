@@ -41,6 +41,18 @@ struct GemmArgs {
     unsigned long long* probe;   // diagnostic builds only (-DST_PROBE): per-wave phase cycle sums
 };
 
+// Developer knobs (tile / split overrides for A/B sweeps) exist only in -DST_DEV_CONFIGS builds; the product
+// library never reads the environment.
+static inline int dev_env_int(const char* name, int dflt) {
+#ifdef ST_DEV_CONFIGS
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
     typedef bf16x8 Frag;
@@ -101,9 +113,9 @@ __device__ __forceinline__ unsigned long long probe_now() {
 #define PROBE_ADD(acc, t1, t0)
 #endif
 
-// The next launch's weights (host hint, st_hint_next_weights) are touched one dword per 128-byte line, each block
+// The next launch's weights (the `next_weights` argument of the entry points) are touched one dword per 128-byte line, each block
 // its slice, so that they sit in the memory-side cache when that launch starts (cold weights cost a GEMM 2-10 us:
-// DESIGN.md section 6).  The loads are fire-and-forget: `sink` must stay allocated until the wave ends.
+// DESIGN.md section 6).  The loads are fire-and-forget: `sink` stays allocated until retire_touches(sink).
 __device__ __forceinline__ void touch_next_weights(const GemmArgs& p, unsigned int& sink, bool helper = false) {
     if (!p.next_w || (p.helper_blocks > 0) != helper) return;
     const size_t lines = p.next_bytes >> 7;
@@ -112,11 +124,15 @@ __device__ __forceinline__ void touch_next_weights(const GemmArgs& p, unsigned i
     const size_t me = helper ? blockIdx.x - (gridDim.x - p.helper_blocks) : blockIdx.x;
     const size_t per = (lines + nsl - 1) / nsl;
     const size_t lo = me * per, hi = lo + per < lines ? lo + per : lines;
-    for (size_t l = lo + threadIdx.x; l < hi; l += blockDim.x) {
+    const size_t step = blockDim.x;                  // read once: inside the loop the asm's memory clobber would force a reload (and a vmcnt(0)) per trip
+    for (size_t l = lo + threadIdx.x; l < hi; l += step) {
         const char* a_ = (const char*)p.next_w + (l << 7);
         asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(a_) : "memory");
     }
 }
+// End of a touch destination's life: the loads are invisible to the compiler's waitcnt pass, so the register may only be
+// handed back once they have returned.
+__device__ __forceinline__ void retire_touches(unsigned int& sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory"); }
 
 template <typename T> struct Raw4 { typedef bf16x4 type; };
 template <> struct Raw4<float> { typedef f32x4 type; };
@@ -359,7 +375,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                     const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                     Out4<T>::store((T*)p.C + (size_t)mrow[i] * p.ldc + ncol[j], v);
                 }
-        asm volatile("" ::"v"(touch_next));
+        retire_touches(touch_next);
     }
 #ifdef ST_PROBE
     if (ptimes) ptimes[1] = probe_now();
@@ -681,7 +697,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     if (bid >= nblk) {                               // helper block on an otherwise idle CU: the next launch's weights
         unsigned int sink = 0;
         touch_next_weights(p, sink, true);
-        asm volatile("" ::"v"(sink));
+        retire_touches(sink);
         return;
     }
     const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
@@ -1038,7 +1054,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         if (!splitk_combine<TM, TN, BM * BN>(p, acc, tw, split, lds, t, wave, lane)) {
             unsigned int sink = 0;                   // this block is done: its slice of the next weights, then exit
             touch_next_weights(p, sink);
-            asm volatile("" ::"v"(sink));
+            retire_touches(sink);
             return;
         }
     }
@@ -1261,7 +1277,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
         if (!splitk_combine<TM, TN, BM * BN>(p, acc, tw, split, lds, t, wave, lane)) {
             unsigned int sink = 0;                   // this block is done: its slice of the next weights, then exit
             touch_next_weights(p, sink);
-            asm volatile("" ::"v"(sink));
+            retire_touches(sink);
             return;
         }
     }
@@ -1297,7 +1313,7 @@ static void launch_dma_one(const GemmArgs& a, hipStream_t st, int tiles_n) {
     // XCD partition: bytes from beyond L2 ~ A * (8 / panels) + W * panels (A = activations, all of K)
     GemmArgs b = a;
     {
-        static const int force_pm = [] { const char* e = getenv("ST_GEMM_PANELS"); return e ? atoi(e) : 0; }();
+        static const int force_pm = dev_env_int("ST_GEMM_PANELS", 0);
         const int tiles_m = cdiv(a.M, BM);
         const double abytes = CONV ? (double)a.M * a.Cin * (a.ups ? 0.25 : 1.0) * a.stride * a.stride : (double)a.M * a.K;
         const double wbytes = (double)(GEGLU ? 2 : 1) * a.N * a.K;
@@ -1314,7 +1330,7 @@ static void launch_dma_one(const GemmArgs& a, hipStream_t st, int tiles_n) {
     const int main_blocks = cdiv(a.M, BM) * tiles_n * sk;
     // launches that leave CUs idle hand the next-weights touches to helper blocks on those CUs (they run beside the K
     // loops instead of extending the epilogues)
-    static const bool no_helpers = getenv("ST_NO_HELPER_BLOCKS") != nullptr;
+    static const bool no_helpers = dev_env_int("ST_NO_HELPER_BLOCKS", 0) != 0;
     b.helper_blocks = (b.next_w && main_blocks <= 208 && !no_helpers) ? (256 - main_blocks > 96 ? 96 : 256 - main_blocks) : 0;
     hipLaunchKernelGGL(kfn, dim3(main_blocks + b.helper_blocks), dim3(WGM * WGN * 64), lds, st, b);
 }
@@ -1362,7 +1378,7 @@ static int g_dbg_cfg = -1, g_dbg_fusek = -1;
 extern "C" void st_debug_force_gemm(int cfg, int fusek) { g_dbg_cfg = cfg; g_dbg_fusek = fusek; }
 #endif
 static int forced_cfg() {
-    static int v = [] { const char* e = getenv("ST_GEMM_FORCE"); return e ? atoi(e) : -1; }();
+    static int v = dev_env_int("ST_GEMM_FORCE", -1);
 #ifdef ST_DEV_CONFIGS
     if (g_dbg_cfg >= 0) return g_dbg_cfg;
 #endif
@@ -1404,7 +1420,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
                                      {CFG_64x64_W8, 64, 64, 0.19}, {CFG_128x320_W8, 128, 320, 1.38}, {CFG_64x320_W8, 64, 320, 0.64},
                                      {CFG_256x128_W8, 256, 128, 0.72}, {CFG_128x80_W8, 128, 80, 0.37}};
         static const int sks[] = {1, 2, 3, 4, 6, 8};
-        static const int force_sk = [] { const char* e = getenv("ST_GEMM_SPLITK"); return e ? atoi(e) : -1; }();     // 0/1: never split
+        static const int force_sk = dev_env_int("ST_GEMM_SPLITK", -1);     // 0/1: never split
         const int nk = a.K / KB;
         const long ncols = (a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N;
         const bool can_split = a.partial && !a.ln_c && force_sk != 0 && force_sk != 1;
@@ -1426,12 +1442,12 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
         GemmArgs b = a;
 #ifdef ST_DEV_CONFIGS
         {   // dev knob: override only the small-problem class (fewer than 150 tiles of 128x128)
-            static const int small_cfg = [] { const char* e = getenv("ST_GEMM_SMALL_CFG"); return e ? atoi(e) : -1; }();
+            static const int small_cfg = dev_env_int("ST_GEMM_SMALL_CFG", -1);
             if (small_cfg >= 0 && small_cfg < CFG_COUNT && tiles(128, 128) < 150 && sk == 1) cfg = small_cfg;
         }
 #endif
         {   // developer overrides: ST_GEMM_FORCE=<cfg id> (tile), ST_GEMM_FUSEK=<n> (K split with that tile)
-            static const int env_fk = [] { const char* e = getenv("ST_GEMM_FUSEK"); return e ? atoi(e) : -1; }();
+            static const int env_fk = dev_env_int("ST_GEMM_FUSEK", -1);
             int force_fk = env_fk;
 #ifdef ST_DEV_CONFIGS
             if (g_dbg_cfg >= 0) force_fk = g_dbg_fusek;
@@ -1498,12 +1514,12 @@ static unsigned long long* g_probe = nullptr;
 extern "C" void st_debug_set_probe(void* p) { g_probe = (unsigned long long*)p; }
 #endif
 
-// Host hint: the weights the NEXT st_linear / st_ln_linear / st_conv2d launch of this thread will read; the launch
-// that follows the hint touches them during its epilogue and clears the hint.
-static thread_local const void* g_next_w = nullptr;
-static thread_local size_t g_next_bytes = 0;
-extern "C" void st_hint_next_weights(const void* p, size_t bytes) { g_next_w = p; g_next_bytes = bytes; }
-static void take_hint(GemmArgs& a) { a.next_w = g_next_w; a.next_bytes = g_next_bytes; g_next_w = nullptr; g_next_bytes = 0; }
+// `next_weights` (optional argument of the three GEMM-shaped entry points): the weight matrix the launch AFTER this one
+// will read; this launch touches it (one dword per 128-byte line, spread over its blocks) so it waits in the memory-side cache.
+static void take_hint(GemmArgs& a, const void* next_w, size_t next_bytes) {
+    a.next_w = next_bytes ? next_w : nullptr;
+    a.next_bytes = next_w ? next_bytes : 0;
+}
 
 static int check_epilogue(const char* who, const GemmArgs& a) {
     ST_REQUIRE(!(a.epi & ST_EPI_BIAS) || a.bias, "%s: ST_EPI_BIAS without bias pointer", who);
@@ -1516,7 +1532,7 @@ static int check_epilogue(const char* who, const GemmArgs& a) {
 extern "C" int st_linear(const void* x, const void* W, const void* bias, const void* residual, const void* rowbias, void* y,
                          int M, int N, int K, long lda, long ldc, long ldr, int rows_per_batch, int epilogue, int dtype,
                          void* workspace, size_t workspace_bytes, float* row_stats, int row_stats_capacity,
-                         int* row_stats_chunks, void* stream) {
+                         int* row_stats_chunks, const void* next_weights, size_t next_weights_bytes, void* stream) {
     ST_REQUIRE(x && W && y, "linear: null pointer");
     ST_REQUIRE(M > 0 && N > 0 && K > 0, "linear: bad shape M=%d N=%d K=%d", M, N, K);
     const int vec = dtype == ST_BF16 ? 8 : 4;
@@ -1533,7 +1549,7 @@ extern "C" int st_linear(const void* x, const void* W, const void* bias, const v
 #ifdef ST_PROBE
     a.probe = g_probe;
 #endif
-    take_hint(a);
+    take_hint(a, next_weights, next_weights_bytes);
     if (int e = check_epilogue("linear", a)) return e;
     hipStream_t st = (hipStream_t)stream;
     return dtype == ST_BF16 ? gemm_dispatch<bf16, false>(a, st) : gemm_dispatch<float, false>(a, st);
@@ -1542,7 +1558,7 @@ extern "C" int st_linear(const void* x, const void* W, const void* bias, const v
 // LayerNorm folded into the following Linear (or GEGLU projection): see GemmArgs::ln_c.
 extern "C" int st_ln_linear(const void* x, const float* row_stats, int row_stats_chunks, const void* Wg, const float* c,
                             const float* d, void* y, int M, int N, int K, long lda, long ldc, float eps, int epilogue,
-                            int dtype, void* stream) {
+                            int dtype, const void* next_weights, size_t next_weights_bytes, void* stream) {
     ST_REQUIRE(x && Wg && c && d && y && row_stats, "ln_linear: null pointer");
     ST_REQUIRE(row_stats_chunks > 0, "ln_linear: the producer emitted no row statistics");
     ST_REQUIRE(M > 0 && N > 0 && K > 0, "ln_linear: bad shape M=%d N=%d K=%d", M, N, K);
@@ -1555,14 +1571,14 @@ extern "C" int st_ln_linear(const void* x, const float* row_stats, int row_stats
     GemmArgs a = {};
     a.A = x; a.W = Wg; a.C = y; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.epi = epilogue;
     a.ln_c = c; a.ln_d = d; a.ln_eps = eps; a.splitk = 1; a.ln_stats = row_stats; a.ln_chunks = row_stats_chunks;
-    take_hint(a);
+    take_hint(a, next_weights, next_weights_bytes);
     hipStream_t st = (hipStream_t)stream;
     return dtype == ST_BF16 ? gemm_dispatch<bf16, false>(a, st) : gemm_dispatch<float, false>(a, st);
 }
 
 // ---- host side of conv_halo_kernel --------------------------------------------------------------
 static bool conv_halo_applies(const GemmArgs& a, int R, int ups) {
-    static const bool off = [] { const char* e = getenv("ST_CONV_HALO"); return e && atoi(e) == 0; }();
+    static const bool off = dev_env_int("ST_CONV_HALO", 1) == 0;
     if (off) return false;
     if (R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1) return false;
     if (a.Cin % 64 != 0 || a.N % 4 != 0 || a.N < 64) return false;
@@ -1597,7 +1613,7 @@ static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
     // K split over channel slices: aim at one round of ~240 blocks; a slice keeps at least two channel slices
     int sk = 1;
     if (a.partial && tiles < 200) {
-        static const int target = [] { const char* e = getenv("ST_HALO_BLOCKS"); return e ? atoi(e) : 240; }();      // (developer knob)
+        static const int target = dev_env_int("ST_HALO_BLOCKS", 240);
         sk = (target + tiles / 2) / tiles;
         if (sk > ncs / 2) sk = ncs / 2;
         if (sk < 1) sk = 1;
@@ -1709,7 +1725,8 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GemmArgs p, int R,
 
 extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const void* residual, const void* rowbias, void* y,
                          int N, int Hin, int Win, int Cin, int Cout, int R, int S, int stride, int pad, int upsample2x,
-                         int epilogue, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+                         int epilogue, int dtype, void* workspace, size_t workspace_bytes,
+                         const void* next_weights, size_t next_weights_bytes, void* stream) {
     ST_REQUIRE(x && W && y, "conv2d: null pointer");
     ST_REQUIRE(N > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0,
                "conv2d: bad geometry");
@@ -1721,7 +1738,7 @@ extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const v
     a.A = x; a.W = W; a.bias = bias; a.residual = residual; a.rowbias = rowbias; a.C = y;
     a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.S = S; a.stride = stride; a.pad = pad; a.ups = upsample2x ? 1 : 0;
     {
-        static const int korder_env = [] { const char* e = getenv("ST_CONV_KORDER"); return e ? atoi(e) : -1; }();
+        static const int korder_env = dev_env_int("ST_CONV_KORDER", -1);
         a.R_ = R; a.korder = korder_env >= 0 ? korder_env : 0;
     }
     a.Hout = (He + 2 * pad - R) / stride + 1;
@@ -1730,7 +1747,7 @@ extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const v
     a.M = N * a.Hout * a.Wout; a.N = Cout; a.K = R * S * Cin;
     a.lda = 0; a.ldc = Cout; a.ldr = Cout; a.rows_per_batch = a.Hout * a.Wout; a.epi = epilogue;
     a.splitk = 1; a.partial = (float*)workspace; a.partial_bytes = workspace ? workspace_bytes : 0;
-    take_hint(a);
+    take_hint(a, next_weights, next_weights_bytes);
     if (int e = check_epilogue("conv2d", a)) return e;
     hipStream_t st = (hipStream_t)stream;
     const int kb = dtype == ST_BF16 ? 64 : 32;

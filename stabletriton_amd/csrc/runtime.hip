@@ -19,7 +19,7 @@ int st_check_launch(const char* what) {
 }
 
 extern "C" const char* st_last_error(void) { return g_err; }
-extern "C" int st_abi_version(void) { return 5; }
+extern "C" int st_abi_version(void) { return 6; }
 
 // ---- Euler-discrete update ---------------------------------------------------
 template <typename T>
@@ -93,4 +93,23 @@ extern "C" int st_timestep_features(const float* t, long t_stride, const int* st
     else
         return st_fail("timestep_features: unsupported dtype %d", dtype);
     return st_check_launch("timestep_features");
+}
+
+// ---- the reference's own timestep operator (optimizers/replace_timesteps.py:33-40 -> kernels/timestep.py:13-45):
+// elementwise over an already broadcast tensor x of shape (..., half):
+//   sin_out[i] = sin(x[i] * f_j), cos_out[i] = cos(x[i] * f_j),  j = i % half,  f_j = exp(-ln(1e4) * j / half)
+__global__ void timestep_sincos_kernel(const float* __restrict__ x, float* __restrict__ s, float* __restrict__ c, long n, int half) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int j = (int)(i % half);
+    const float e = (-9.210340371976184f * (float)j) / (float)half;
+    const float a = x[i] * expf(e);
+    s[i] = sinf(a);
+    c[i] = cosf(a);
+}
+
+extern "C" int st_timestep_sincos(const float* x, float* sin_out, float* cos_out, long n, int half, void* stream) {
+    ST_REQUIRE(x && sin_out && cos_out && n > 0 && half > 0, "timestep_sincos: bad arguments");
+    hipLaunchKernelGGL(timestep_sincos_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, sin_out, cos_out, n, half);
+    return st_check_launch("timestep_sincos");
 }

@@ -1,52 +1,168 @@
-"""Host hooks: drop the compiled UNet into a Diffusers SDXL pipeline.
+"""Host hooks: drop the compiled UNet into the call sites that drive it.
 
-Reference call site: implementations/Diffusers/load_sdxl_pipeline.py:24-35 -
-build the minimal UNet, load the pipeline's state_dict, optimize_model, re-attach
-the three `config` attributes the pipeline reads (lost by fx tracing), assign
-`pipe.unet`.  The pipeline object is duck-typed (diffusers is not a dependency).
-The reference's ComfyUI hook is an empty file (implementations/ComfyUI/example.py);
-`patch_comfy_model` below is the minimal equivalent: it swaps the callable a
-ComfyUI-style model patcher invokes for its diffusion model.
+Diffusers - reference call site implementations/Diffusers/load_sdxl_pipeline.py:17-46: an fp16 SDXL pipeline whose
+`pipe.unet` is replaced by the compiled module with three `config` attributes re-attached.  The pipeline
+(diffusers 0.21.2, third party) then calls, once per step and with classifier-free guidance (batch 2):
+
+    unet(latent_model_input, t, encoder_hidden_states=prompt_embeds, cross_attention_kwargs=None,
+         added_cond_kwargs={"text_embeds": ..., "time_ids": ...}, return_dict=False)[0]
+
+`DiffusersUNet` answers exactly that call: tensors arrive in the pipeline's dtype (fp16) and are cast to the compute
+dtype of the HIP kernels (bf16, or fp32 for strict parity) at this boundary, the result goes back in the caller's
+dtype.  The text-context K/V projections (140 GEMMs, step-invariant) are evaluated once per prompt - the cache is keyed
+on the identity and version of `encoder_hidden_states` - and every step replays ONE captured hipGraph.
+
+ComfyUI - the reference's hook is an empty file (implementations/ComfyUI/example.py), so the contract here is ComfyUI's
+own `diffusion_model.forward(x, timesteps, context, y, control, transformer_options, **kw)`: `y` is the ready-made
+2816-wide vector (pooled text embedding | Fourier features of the six size/crop ids), timesteps has one entry per row.
+`ComfyUNet` wraps a module compiled from `UNetWithLabelVector` (same weights, `y` instead of added_cond_kwargs).
+
+Both packages are duck-typed (neither is a dependency).
 """
 from __future__ import annotations
 
+from typing import Dict, Optional
+
 import torch
+from torch import nn
 
 from .optimization import optimize_model
-from .unet import SDXL_BASE, UNet2DConditionModel, UNetSpec, make_config
+from .optimizers.graphs import make_dynamic_graphed_callable
+from .unet import SDXL_BASE, UNet2DConditionModel, UNetSpec, UNetWithLabelVector, make_config
+
+
+class _HoistedUNet(nn.Module):
+    """Shared by both adapters: dtype casts at the boundary, per-prompt context cache, one captured graph per input shape."""
+
+    def __init__(self, compiled, compute_dtype: torch.dtype, cuda_graph: bool = True):
+        super().__init__()
+        if not hasattr(compiled, "forward_with_context"):
+            raise ValueError("expected a module from optimize_model(..., cuda_graph=False): the adapter captures its own graphs")
+        self.compiled = compiled
+        self.compute_dtype = compute_dtype
+        self.cuda_graph = cuda_graph
+        self._ctx: Dict[tuple, tuple] = {}        # ehs shape -> static context tensors (read by the captured graphs)
+        self._ctx_key = None
+        self._steps: Dict[tuple, object] = {}     # ehs shape -> (graphed) step function
+
+    def refresh_weights(self) -> int:
+        """Re-derive fused / folded weight buffers after an in-place weight update (also done at every new prompt)."""
+        return self.compiled.exec_context.refresh_derived(full=True)
+
+    def _context_for(self, ehs: torch.Tensor) -> tuple:
+        key = (ehs.data_ptr(), ehs._version, tuple(ehs.shape), ehs.dtype)
+        shape = tuple(ehs.shape)
+        if key != self._ctx_key or shape not in self._ctx:
+            self.refresh_weights()
+            with torch.no_grad():
+                new = self.compiled.precompute_context(ehs.to(self.compute_dtype))
+            old = self._ctx.get(shape)
+            if old is None:
+                self._ctx[shape] = tuple(t.clone() for t in new)
+            else:
+                for dst, src in zip(old, new):
+                    dst.copy_(src)
+            self._ctx_key = key
+        return self._ctx[shape]
+
+    def _step_fn(self, shape: tuple):
+        fn = self._steps.get(shape)
+        if fn is None:
+            ctx = self._ctx[shape]                 # closed over: the graph reads these buffers in place
+
+            def step(sample, timesteps, cond):
+                return self.compiled.forward_with_context(sample, timesteps, ctx, cond)[0]
+
+            fn = make_dynamic_graphed_callable(step) if self.cuda_graph else step
+            self._steps[shape] = fn
+        return fn
+
+    def _run(self, sample, timesteps, ehs, cond):
+        io_dtype = sample.dtype
+        dev = sample.device
+        self._context_for(ehs)
+        if not torch.is_tensor(timesteps):
+            timesteps = torch.tensor(float(timesteps), dtype=torch.float32)
+        timesteps = timesteps.to(device=dev, dtype=torch.float32)
+        if timesteps.dim() > 1 or (timesteps.dim() == 1 and timesteps.numel() not in (1, sample.shape[0])):
+            raise ValueError(f"timesteps of shape {tuple(timesteps.shape)} do not match batch {sample.shape[0]}")
+        with torch.no_grad():
+            out = self._step_fn(tuple(ehs.shape))(sample.to(self.compute_dtype), timesteps, cond)
+        return out.to(io_dtype)
+
+
+class DiffusersUNet(_HoistedUNet):
+    """`pipe.unet` replacement (duck-typed `UNet2DConditionModel.forward` of diffusers 0.21.2)."""
+
+    def __init__(self, compiled, spec: UNetSpec = SDXL_BASE, compute_dtype: torch.dtype = torch.bfloat16, cuda_graph: bool = True):
+        super().__init__(compiled, compute_dtype, cuda_graph)
+        self.config = make_config(spec)            # what the pipeline reads (load_sdxl_pipeline.py:29-34)
+
+    @property
+    def dtype(self):
+        return self.compute_dtype
+
+    def forward(self, sample, timestep, encoder_hidden_states=None, class_labels=None, timestep_cond=None,
+                attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None, return_dict: bool = False, **ignored):
+        if encoder_hidden_states is None or added_cond_kwargs is None:
+            raise ValueError("the SDXL UNet needs encoder_hidden_states and added_cond_kwargs{text_embeds, time_ids}")
+        for name, val in (("class_labels", class_labels), ("timestep_cond", timestep_cond), ("attention_mask", attention_mask)):
+            if val is not None:
+                raise NotImplementedError(f"{name} is not part of the SDXL-base UNet path")
+        if cross_attention_kwargs:
+            raise NotImplementedError("cross_attention_kwargs (attention processors / LoRA scale) are not supported: merge LoRA weights in place")
+        cd = self.compute_dtype
+        cond = {"text_embeds": added_cond_kwargs["text_embeds"].to(cd), "time_ids": added_cond_kwargs["time_ids"].to(cd)}
+        out = self._run(sample, timestep, encoder_hidden_states, cond)
+        if return_dict:
+            from types import SimpleNamespace
+            return SimpleNamespace(sample=out)
+        return [out]                                # the pipeline takes [0] (reference unet_pt.py:542 returns a list)
 
 
 def compile_unet_from_state_dict(state_dict, spec: UNetSpec = SDXL_BASE, dtype=torch.bfloat16, device="cuda",
-                                 cuda_graph: bool = True):
+                                 cuda_graph: bool = True) -> DiffusersUNet:
+    """Build the UNet, load a Diffusers-keyed state_dict (any float dtype), compile, wrap for the pipeline."""
     with torch.device("meta"):
         model = UNet2DConditionModel(spec)
     model = model.to_empty(device=device).to(dtype)
     model.load_state_dict({k: v.to(device=device, dtype=dtype) for k, v in state_dict.items()})
-    compiled = optimize_model(model, cuda_graph=cuda_graph)
-    compiled.config = make_config(spec)
-    return compiled
+    compiled = optimize_model(model, cuda_graph=False)
+    return DiffusersUNet(compiled, spec, dtype, cuda_graph)
 
 
 def attach_to_diffusers(pipe, spec: UNetSpec = SDXL_BASE, dtype=torch.bfloat16, cuda_graph: bool = True):
-    """`pipe.unet = compiled UNet` (same weights), returns the pipeline."""
+    """`pipe.unet = compiled UNet` (same weights; the counterpart of load_sdxl_pipeline.py:24-35), returns the pipeline."""
     device = next(pipe.unet.parameters()).device
     pipe.unet = compile_unet_from_state_dict(pipe.unet.state_dict(), spec, dtype, device, cuda_graph)
     return pipe
 
 
-class _ComfyAdapter(torch.nn.Module):
-    """Callable with the Diffusers-style signature backing a ComfyUI-style wrapper
-    `apply_model(x, t, c_crossattn=..., text_embeds=..., time_ids=...)`."""
+class ComfyUNet(_HoistedUNet):
+    """`diffusion_model` replacement with ComfyUI's calling convention."""
 
-    def __init__(self, compiled):
-        super().__init__()
-        self.compiled = compiled
+    def forward(self, x, timesteps=None, context=None, y=None, control=None, transformer_options: Optional[dict] = None, **kwargs):
+        if timesteps is None or context is None or y is None:
+            raise ValueError("ComfyUNet needs timesteps, context (text states) and y (pooled text | size/crop features)")
+        if control is not None:
+            raise NotImplementedError("ControlNet residuals (`control`) are not supported by the compiled UNet")
+        patches = (transformer_options or {}).get("patches") or (transformer_options or {}).get("patches_replace")
+        if patches:
+            raise NotImplementedError("transformer_options patches are not supported by the compiled UNet")
+        if y.shape[0] != x.shape[0] or context.shape[0] != x.shape[0]:
+            raise ValueError("x, context and y must share the batch dimension")
+        return self._run(x, timesteps, context, y.to(self.compute_dtype))
 
-    def forward(self, x, timesteps, context, text_embeds, time_ids, **ignored):
-        t = timesteps.reshape(-1)[0] if timesteps.numel() > 1 else timesteps.reshape(())
-        return self.compiled(x, t, context, {"text_embeds": text_embeds, "time_ids": time_ids})[0]
+
+def compile_comfy_unet(unet: UNet2DConditionModel, cuda_graph: bool = True) -> ComfyUNet:
+    """Compile the `y`-vector entry of a UNet (weights shared with `unet`)."""
+    dtype = next(unet.parameters()).dtype
+    compiled = optimize_model(UNetWithLabelVector(unet), cuda_graph=False)
+    return ComfyUNet(compiled, dtype, cuda_graph)
 
 
-def patch_comfy_model(model_patcher, compiled) -> None:
-    """Replace `model_patcher.model.diffusion_model` (duck-typed) with the compiled UNet."""
-    model_patcher.model.diffusion_model = _ComfyAdapter(compiled)
+def patch_comfy_model(model_patcher, unet: UNet2DConditionModel, cuda_graph: bool = True) -> ComfyUNet:
+    """Replace `model_patcher.model.diffusion_model` (duck-typed ComfyUI ModelPatcher) with the compiled UNet."""
+    adapter = compile_comfy_unet(unet, cuda_graph)
+    model_patcher.model.diffusion_model = adapter
+    return adapter

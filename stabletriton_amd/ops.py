@@ -9,14 +9,13 @@ launch goes to torch's current stream, so the ops are capturable.
 from __future__ import annotations
 
 import os
+import threading
 from typing import Optional
 
 import torch
 
 from . import _C
 from ._C import BackendError
-
-_workspaces = {}
 
 # Optional per-launch census used by bench.py's roofline leg: when a list is
 # installed, every launcher appends (family, flops, bytes, start_event, end_event)
@@ -51,77 +50,187 @@ def _label(text: str) -> None:
         _tag = text
 
 
-# ---- next-weights hints ------------------------------------------------------------------------
-# Every denoise step launches the same GEMMs over the same weights in the same order, and every one of
-# them finds its weights cold (5 GB of weights stream through per step).  The first step after
-# `weight_plan_begin()` records the order; later steps tell each launch which weights the launch after
-# it will read (st_hint_next_weights), and that launch touches them during its epilogue.
-_plan = []           # [(data_ptr, nbytes)] in launch order
-_plan_pos = 0
-_plan_state = "off"  # off | record | replay
-
-
-def weight_plan_begin() -> None:
-    """Call at the start of every step of a loop that repeats the same launches."""
-    global _plan_pos, _plan_state
-    if os.environ.get("ST_NO_WEIGHT_HINTS"):
-        _plan_state = "off"
-        return
-    if _plan_state == "off":
-        _plan_state = "record"
-        _plan.clear()
-    elif _plan_state == "record" and _plan_pos > 0:
-        _plan_state = "replay"
-    _plan_pos = 0
-
-
-def weight_plan_reset() -> None:
-    global _plan_state, _plan_pos
-    _plan_state, _plan_pos = "off", 0
-    _plan.clear()
-
-
-def _hint(lib, w: torch.Tensor) -> None:
-    """Called by the GEMM launchers right before their launch with the weights they are about to read."""
-    global _plan_pos, _plan_state
-    if _plan_state == "off":
-        return
-    me = (w.data_ptr(), w.numel() * w.element_size())
-    if _plan_state == "record":
-        _plan.append(me)
-        _plan_pos += 1
-        return
-    i = _plan_pos
-    if i >= len(_plan) or _plan[i] != me:            # the launch sequence changed: stop hinting
-        weight_plan_reset()
-        return
-    nxt = _plan[(i + 1) % len(_plan)]
-    lib.st_hint_next_weights(nxt[0], nxt[1])
-    _plan_pos += 1
-
-
-def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    key = (device.type, device.index)
-    ws = _workspaces.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)      # hand-off words start at zero
-        _workspaces[key] = ws
-    return ws
-
-
-# split-K scratch for st_linear / st_conv2d: one fixed-size slab per device, allocated once and
-# never replaced (captured graphs keep its address); problems that would need more run unsplit.
+# ---- execution context: the mutable host state of one compiled module ------------------------------
+# split-K scratch for st_linear / st_conv2d: a fixed-size slab, allocated once per context and never
+# replaced (captured graphs keep its address); problems that would need more run unsplit.  Concurrent
+# launches must not share one (the arrival counters), so every compiled module / stream has its own.
 GEMM_WORKSPACE_BYTES = 192 << 20
-_gemm_ws = {}
+
+
+class WeightPlan:
+    """Next-weights hints.  Every denoise step launches the same GEMMs over the same weights in the same
+    order, and every one of them finds its weights cold (5 GB of weights stream through per step).  The
+    first pass after `begin()` records the order; later passes tell each launch which weights the launch
+    after it reads (the `next_weights` argument of st_linear / st_ln_linear / st_conv2d), and that launch
+    touches them.  Entries hold the tensors themselves, so a hinted buffer cannot be freed under a
+    captured graph that still touches it."""
+
+    def __init__(self):
+        self.entries = []            # weight tensors in launch order (strong references)
+        self.pos = 0
+        self.state = "off"           # off | record | replay
+
+    def begin(self) -> None:
+        if self.state == "off":
+            self.state = "record"
+            self.entries.clear()
+        elif self.state == "record" and self.pos > 0:
+            self.state = "replay"
+        self.pos = 0
+
+    def reset(self) -> None:
+        self.state, self.pos = "off", 0
+        self.entries.clear()
+
+    def next_after(self, w: torch.Tensor):
+        """Called by the GEMM launchers with the weights they are about to read; returns the tensor the
+        following launch reads (or None)."""
+        if self.state == "off":
+            return None
+        if self.state == "record":
+            self.entries.append(w)
+            self.pos += 1
+            return None
+        i = self.pos
+        cur = self.entries[i] if i < len(self.entries) else None
+        if cur is None or cur.data_ptr() != w.data_ptr() or cur.numel() != w.numel():
+            self.reset()             # the launch sequence changed: stop hinting
+            return None
+        self.pos += 1
+        return self.entries[(i + 1) % len(self.entries)]
+
+
+class DerivedWeights:
+    """A weight buffer computed from module parameters (row-concatenated q|k|v, gamma-folded LayerNorm
+    projections).  `refresh()` recomputes it IN PLACE when a source parameter changed, so addresses held
+    by captured graphs stay valid and in-place weight updates (LoRA merges) become visible."""
+
+    def __init__(self, sources, compute):
+        self.sources = list(sources)
+        self.compute = compute
+        self.versions = self._versions()
+        self.stamp = self._stamp()
+        self.value = compute()
+
+    def _versions(self):
+        return [t._version for t in self.sources]
+
+    def _stamp(self):
+        return tuple((t.data_ptr(), t.dtype) for t in self.sources)
+
+    def refresh(self, full: bool = True) -> bool:
+        """`full` also compares storage addresses (`param.data = ...` swaps); the quick form only looks at
+        the in-place version counters (copy_/add_/load_state_dict), which is what a per-replay check can afford."""
+        ver = self._versions()
+        st = self._stamp() if full else self.stamp
+        if ver == self.versions and st == self.stamp:
+            return False
+        self.versions = ver
+        new = self.compute()
+        for dst, src in zip(self.value, new):
+            if dst is not None:
+                dst.copy_(src)
+        self.stamp = st
+        return True
+
+
+class ExecContext:
+    """Host state owned by ONE compiled module (or DenoiseLoop): its split-K workspace, its weight plan
+    and its derived weight buffers.  `with ctx:` makes it current for the calling thread.  Launchers called
+    outside any context share one default context per device (no weight plan): callers that launch from
+    several streams at once give each stream its own ExecContext."""
+
+    def __init__(self, hints: bool = True):
+        self.plan = WeightPlan() if hints and not os.environ.get("ST_NO_WEIGHT_HINTS") else None
+        self.hinting = False         # True only inside step(): one-off passes (context / time tables) stay out of the plan
+        self._ws = {}
+        self.derived = {}
+
+    def gemm_workspace(self, device: torch.device) -> torch.Tensor:
+        key = (device.type, device.index)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = torch.zeros(GEMM_WORKSPACE_BYTES, dtype=torch.uint8, device=device)      # the arrival counters must start at zero
+            self._ws[key] = ws
+        return ws
+
+    def derived_weights(self, key, sources, compute) -> "DerivedWeights":
+        """The buffer derived from `sources` (parameters), built on first use.  Outside graph capture a
+        stale buffer is refreshed on the spot; under a captured graph the owner calls refresh_derived()."""
+        d = self.derived.get(key)
+        if d is None or len(d.sources) != len(sources) or any(a is not b for a, b in zip(d.sources, sources)):
+            d = self.derived[key] = DerivedWeights(sources, compute)      # first use (or the key's modules were replaced)
+        elif sources[0].device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            d.refresh()
+        return d
+
+    def refresh_derived(self, full: bool = False) -> int:
+        """Re-derive (in place) every buffer whose source parameters changed; returns how many did.  Captured
+        graphs read the derived buffers by address and never re-run the wrappers that build them, so their owners
+        call this before a replay (GraphedCallable: quick check every call; DenoiseLoop / hooks: full check per prompt)."""
+        return sum(1 for d in self.derived.values() if d.refresh(full))
+
+    def step(self) -> "_StepScope":
+        """`with ctx.step():` around every pass of a loop that repeats the same launches in the same order
+        (one UNet evaluation): makes the context current and lets each launch warm the next one's weights."""
+        return _StepScope(self)
+
+    def __enter__(self):
+        stack = _tls.__dict__.setdefault("stack", [])
+        stack.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        _tls.stack.pop()
+        return False
+
+
+class _StepScope:
+    def __init__(self, ctx: ExecContext):
+        self.ctx = ctx
+
+    def __enter__(self):
+        self.ctx.__enter__()
+        self.was = self.ctx.hinting
+        self.ctx.hinting = True
+        if self.ctx.plan is not None and not self.was:
+            self.ctx.plan.begin()
+        return self.ctx
+
+    def __exit__(self, *exc):
+        self.ctx.hinting = self.was
+        return self.ctx.__exit__(*exc)
+
+
+_tls = threading.local()
+_default_ctx = {}
+_default_lock = threading.Lock()
+
+
+def current_context(device: Optional[torch.device] = None) -> ExecContext:
+    stack = getattr(_tls, "stack", None)
+    if stack:
+        return stack[-1]
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    key = (dev.type, dev.index)
+    with _default_lock:
+        ctx = _default_ctx.get(key)
+        if ctx is None:
+            ctx = _default_ctx[key] = ExecContext(hints=False)
+    return ctx
+
+
+def _next_weights(w: torch.Tensor):
+    """(pointer, bytes) of the weights the launch after this one reads, from the current context's plan."""
+    ctx = current_context(w.device)
+    nxt = ctx.plan.next_after(w) if (ctx.plan is not None and ctx.hinting) else None
+    if nxt is None:
+        return None, 0
+    return nxt.data_ptr(), nxt.numel() * nxt.element_size()
 
 
 def _gemm_workspace(device: torch.device) -> torch.Tensor:
-    key = (device.type, device.index)
-    ws = _gemm_ws.get(key)
-    if ws is None:
-        ws = torch.zeros(GEMM_WORKSPACE_BYTES, dtype=torch.uint8, device=device)      # the arrival counters must start at zero
-        _gemm_ws[key] = ws
-    return ws
+    return current_context(device).gemm_workspace(device)
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -162,7 +271,9 @@ def group_norm(x: torch.Tensor, num_groups: int, weight: torch.Tensor, bias: tor
     y = torch.empty_like(x)                     # preserve_format keeps NHWC strides
     w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
     b = bias if bias.dtype == x.dtype else bias.to(x.dtype)
-    ws = _workspace(x.device, lib.st_group_norm_workspace_bytes(N, Cc, HW, num_groups))
+    # scratch for the partial statistics: allocated per call from torch's caching allocator (stream-ordered; under
+    # graph capture it belongs to the graph's private pool, so replays never alias a buffer somebody else owns)
+    ws = torch.empty(lib.st_group_norm_workspace_bytes(N, Cc, HW, num_groups), dtype=torch.uint8, device=x.device)
     _label(f"N={N} C={Cc} HW={HW} silu={int(bool(silu))}")
     _C.check(_timed("group_norm", 0.0, 2.0 * x.numel() * x.element_size(), lib.st_group_norm, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups,
                                float(eps), int(bool(silu)), layout, _C.dtype_code(x.dtype), ws.data_ptr(),
@@ -259,13 +370,13 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         cap = min(STATS_MAX_CHUNKS, (N + 63) // 64)
         stats = torch.empty((M, cap, 2), dtype=torch.float32, device=x.device)
         chunks = ctypes.c_int(0)
-    _hint(lib, w)
+    nxt_p, nxt_b = _next_weights(w)
     _label(f"M={M} N={N} K={K} epi={epi}{' stats' if emit_stats else ''}")
     _C.check(_timed("linear", 2.0 * M * w.shape[0] * K, float((M * K + w.numel() + M * N) * x.element_size()),
                     lib.st_linear, x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
                     lda, N, ldr, 0, epi, _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(),
                     _ptr(stats), 0 if stats is None else stats.shape[1],
-                    None if chunks is None else ctypes.byref(chunks), _C.stream_ptr()), "linear")
+                    None if chunks is None else ctypes.byref(chunks), nxt_p, nxt_b, _C.stream_ptr()), "linear")
     if emit_stats:
         if chunks.value <= 0:
             raise BackendError("linear: this shape cannot emit LayerNorm row statistics (K must be a multiple of the K tile)")
@@ -287,12 +398,12 @@ def ln_linear(x: torch.Tensor, stats: "RowStats", w_folded: torch.Tensor, c: tor
     x2, M, lda = _rows2d(x)
     N = w_folded.shape[0] // 2 if geglu else w_folded.shape[0]
     out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
-    _hint(lib, w_folded)
+    nxt_p, nxt_b = _next_weights(w_folded)
     _label(f"M={M} N={N} K={K} ln{' geglu' if geglu else ''}")
     _C.check(_timed("linear", 2.0 * M * w_folded.shape[0] * K, float((M * K + w_folded.numel() + M * N) * x.element_size()),
                     lib.st_ln_linear, x2.data_ptr(), stats.buf.data_ptr(), stats.chunks, w_folded.data_ptr(),
                     c.data_ptr(), d.data_ptr(), out.data_ptr(), M, N, K,
-                    lda, N, float(eps), _C.EPI_GEGLU if geglu else 0, _C.dtype_code(x.dtype), _C.stream_ptr()), "ln_linear")
+                    lda, N, float(eps), _C.EPI_GEGLU if geglu else 0, _C.dtype_code(x.dtype), nxt_p, nxt_b, _C.stream_ptr()), "ln_linear")
     return out
 
 
@@ -375,12 +486,12 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
             residual = residual.contiguous(memory_format=torch.channels_last)
         epi |= _C.EPI_RESIDUAL
     gws = _gemm_workspace(x.device)
-    _hint(lib, w)
+    nxt_p, nxt_b = _next_weights(w)
     _label(f"Cin={Cin} H={H} Cout={Cout} k={R} s={stride} ups={int(upsample2x)} epi={epi}")
     _C.check(_timed("conv2d", 2.0 * N * Ho * Wo * Cout * R * S * Cin,
                     float((x.numel() + w.numel() + out.numel()) * x.element_size()), lib.st_conv2d, x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(rowbias), out.data_ptr(),
                            N, H, W, Cin, Cout, R, S, stride, padding, int(upsample2x), epi,
-                           _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(), _C.stream_ptr()), "conv2d")
+                           _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(), nxt_p, nxt_b, _C.stream_ptr()), "conv2d")
     return out
 
 
@@ -396,6 +507,18 @@ def timestep_features(t: torch.Tensor, dim: int, dtype: torch.dtype, step: Optio
     _C.check(lib.st_timestep_features(t32.data_ptr(), t_stride, _ptr(step), out.data_ptr(), nb, dim,
                                       _C.dtype_code(dtype), _C.stream_ptr()), "timestep_features")
     return out
+
+
+def timestep_sincos(x: torch.Tensor):
+    """The reference's timestep operator (kernels/timestep.py:13-45): x is (..., half), already broadcast;
+    returns (sin(x*f_j), cos(x*f_j)) with f_j = exp(-ln(1e4) * j / half) along the last dimension."""
+    _C.require_device(x)
+    lib = _C.load()
+    x32 = x.float().contiguous()
+    s, c = torch.empty_like(x32), torch.empty_like(x32)
+    _C.check(lib.st_timestep_sincos(x32.data_ptr(), s.data_ptr(), c.data_ptr(), x32.numel(), x32.shape[-1], _C.stream_ptr()),
+             "timestep_sincos")
+    return s, c
 
 
 def euler_step(latent: torch.Tensor, eps: torch.Tensor, next_in: torch.Tensor, dsigma: torch.Tensor,

@@ -72,14 +72,23 @@ def optimize_model(model: nn.Module, cuda_graph: bool = True, fuse: bool = True)
     _C.load()                                  # fail now, loudly, if the HIP library is missing
     model = model.eval().to(memory_format=torch.channels_last)      # conv weights -> (Cout,R,S,Cin) strides
     gm = replace_backend(fx.symbolic_trace(model), fuse=fuse)
-    if fuse:
-        _install_context_split(gm)
+    # the compiled module owns its mutable host state (split-K workspace, next-weights plan, derived weight buffers):
+    # two compiled modules, or two streams each driving their own, never share any (ops.ExecContext)
+    gm.exec_context = ops.ExecContext()
+    if not (fuse and _install_context_split(gm)):
+        plain = gm.forward
+
+        def forward(*args, **kwargs):
+            with gm.exec_context.step():
+                return plain(*args, **kwargs)
+
+        gm.forward = forward
     if cuda_graph:
-        gm.forward = make_dynamic_graphed_callable(gm.forward)
+        gm.forward = make_dynamic_graphed_callable(gm.forward, before_replay=gm.exec_context.refresh_derived)
     return gm
 
 
-def _install_context_split(gm: fx.GraphModule) -> None:
+def _install_context_split(gm: fx.GraphModule) -> bool:
     """Hoist the text-context projections (step-invariant) out of the per-step graph.
 
     `gm(sample, timesteps, encoder_hidden_states, added_cond_kwargs)` keeps working and stays
@@ -88,10 +97,13 @@ def _install_context_split(gm: fx.GraphModule) -> None:
     per step (stabletriton_amd/pipeline.py)."""
     names = [n.target for n in gm.graph.nodes if n.op == "placeholder"]
     if "encoder_hidden_states" not in names:
-        return
+        return False
     context_module = split_context(gm, "encoder_hidden_states")
     if context_module is None:
-        return
+        return False
+    if getattr(gm, "exec_context", None) is None:
+        gm.exec_context = ops.ExecContext()
+    ectx = gm.exec_context
     gm.rewrite_stats["context_outputs"] = len(
         [n for n in context_module.graph.nodes if n.op == "output"][0].args[0])
     gm.context_module = context_module
@@ -99,41 +111,45 @@ def _install_context_split(gm: fx.GraphModule) -> None:
     # depends only on the timestep and the added conditioning: a loop evaluates it once per schedule
     # entry and feeds the per-step row back in (pipeline.DenoiseLoop).
     time_module = None
-    if "timesteps" in names and "added_cond_kwargs" in names:
-        time_module = split_region(gm, ("timesteps", "added_cond_kwargs"), "time_cache", meta_sources=("sample",),
+    cond_arg = "added_cond_kwargs" if "added_cond_kwargs" in names else ("y" if "y" in names else None)
+    if "timesteps" in names and cond_arg is not None:
+        time_module = split_region(gm, ("timesteps", cond_arg), "time_cache", meta_sources=("sample",),
                                    stop_at_slices=True, class_name="TimeModule")
     core = gm.forward     # generated: (sample, timesteps, ehs, context_cache, added_cond_kwargs[, time_cache], **kw)
 
     def precompute_context(encoder_hidden_states):
-        return context_module(encoder_hidden_states)
+        with ectx:
+            return context_module(encoder_hidden_states)
 
     if time_module is None:
         def forward_with_context(sample, timesteps, context_cache, added_cond_kwargs, **kwargs):
-            ops.weight_plan_begin()
-            return core(sample, timesteps, None, context_cache, added_cond_kwargs, **kwargs)
+            with ectx.step():
+                return core(sample, timesteps, None, context_cache, added_cond_kwargs, **kwargs)
     else:
         gm.time_module = time_module
         gm.rewrite_stats["time_outputs"] = len([n for n in time_module.graph.nodes if n.op == "output"][0].args[0])
 
         def precompute_time(sample, timesteps, added_cond_kwargs):
             """Time-path tensors of one schedule entry (`sample` is read for its batch size and dtype only)."""
-            return time_module(sample, timesteps, added_cond_kwargs)
+            with ectx:
+                return time_module(sample, timesteps, added_cond_kwargs)
 
         def forward_with_context(sample, timesteps, context_cache, added_cond_kwargs, time_cache=None, **kwargs):
-            ops.weight_plan_begin()       # one call = one pass over the same GEMMs: lets each launch warm the next one's weights
             if time_cache is None:
-                time_cache = time_module(sample, timesteps, added_cond_kwargs)
-            return core(sample, timesteps, None, context_cache, added_cond_kwargs, time_cache, **kwargs)
+                time_cache = precompute_time(sample, timesteps, added_cond_kwargs)
+            with ectx.step():             # one pass over the same GEMMs in the same order: each launch warms the next one's weights
+                return core(sample, timesteps, None, context_cache, added_cond_kwargs, time_cache, **kwargs)
 
         gm.precompute_time = precompute_time
 
     def forward(sample, timesteps, encoder_hidden_states, added_cond_kwargs, **kwargs):
-        ctx = context_module(encoder_hidden_states)          # (outside the per-step weight plan: a loop evaluates it once)
+        ctx = precompute_context(encoder_hidden_states)      # (outside the per-step weight plan: a loop evaluates it once)
         return forward_with_context(sample, timesteps, ctx, added_cond_kwargs, **kwargs)
 
     gm.precompute_context = precompute_context
     gm.forward_with_context = forward_with_context
     gm.forward = forward
+    return True
 
 
 compile = optimize_model

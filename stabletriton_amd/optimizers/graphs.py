@@ -79,7 +79,8 @@ def _first_device(obj: Any):
 class GraphedCallable:
     """One captured forward: static inputs -> hipGraph -> static outputs."""
 
-    def __init__(self, fn: Callable, args, kwargs, warmup: int = 2):
+    def __init__(self, fn: Callable, args, kwargs, warmup: int = 2, before_replay: Callable = None):
+        self.before_replay = before_replay
         dev = _first_device((args, kwargs))
         if dev is None:
             raise RuntimeError("hipGraph capture needs at least one GPU tensor argument")
@@ -105,12 +106,14 @@ class GraphedCallable:
 
     def __call__(self, *args, **kwargs):
         with self.lock:
+            if self.before_replay is not None:
+                self.before_replay()      # e.g. re-derive weight buffers whose source parameters were updated in place
             tree_copy_(self.static_in, (args, kwargs))
             self.graph.replay()
             return tree_map(torch.clone, self.static_out)
 
 
-def make_dynamic_graphed_callable(fn: Callable, warmup: int = 2) -> Callable:
+def make_dynamic_graphed_callable(fn: Callable, warmup: int = 2, before_replay: Callable = None) -> Callable:
     lock = threading.Lock()
     cache = {}
 
@@ -123,7 +126,7 @@ def make_dynamic_graphed_callable(fn: Callable, warmup: int = 2) -> Callable:
                 entry = cache.get(key)
                 if entry is None:
                     logger.info("capturing hipGraph for %s", getattr(fn, "__name__", type(fn).__name__))
-                    entry = GraphedCallable(fn, args, kwargs, warmup)
+                    entry = GraphedCallable(fn, args, kwargs, warmup, before_replay)
                     cache[key] = entry
         return entry(*args, **kwargs)
 

@@ -1,4 +1,4 @@
-"""Sinusoidal timestep embedding -> `timestep_wrapper` (one small kernel).
+"""Sinusoidal timestep embedding -> `timestep_embedding_wrapper` (one small kernel).
 
 Counterpart of reference optimizers/replace_timesteps.py:43-58, whose pattern
 never matches the real UNet (0 sites).  This pass matches by
@@ -10,7 +10,7 @@ import operator
 import torch
 from torch import fx
 
-from .wrappers import timestep_wrapper
+from .wrappers import timestep_embedding_wrapper
 
 
 def _find_arange_half(n: fx.Node, depth: int = 0):
@@ -54,7 +54,7 @@ def fuse_timesteps(gm: fx.GraphModule) -> int:
             continue
         t = tg.args[0]
         with gm.graph.inserting_before(n):
-            new = gm.graph.call_function(timestep_wrapper, (t, 2 * half))
+            new = gm.graph.call_function(timestep_embedding_wrapper, (t, 2 * half))
         n.replace_all_uses_with(new)
         count += 1
     if count:

@@ -56,12 +56,20 @@ def linear_wrapper(v: torch.Tensor, linear: nn.Linear, activation: bool, emit_st
     return linear_wrapper_functional(v, linear.weight, linear.bias, activation, emit_stats)
 
 
-def timestep_wrapper(t: torch.Tensor, dim: int) -> torch.Tensor:
-    """cos|sin features of a 1-D fp32 timestep tensor, (len(t), dim) fp32."""
-    return ops.timestep_features(t, dim, torch.float32)
+def timestep_wrapper(x: torch.Tensor):
+    """The reference's leaf of the same name (optimizers/replace_timesteps.py:33-37 -> kernels/timestep.py:13-45):
+    x is the timestep tensor already broadcast to (..., half); returns (sin, cos) of x * f_j elementwise,
+    f_j = exp(-ln(1e4) * j / half) along the last dimension."""
+    return ops.timestep_sincos(x)
 
 
 # ---- additions -------------------------------------------------------------------------------
+def timestep_embedding_wrapper(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """cos|sin features of a 1-D fp32 timestep tensor, (len(t), dim) fp32: the whole sinusoidal sub-graph of
+    unet_pt.py:22-36 as one launch (the reference's fuse_timesteps pass matches 0 sites of the real UNet)."""
+    return ops.timestep_features(t, dim, torch.float32)
+
+
 def conv2d_wrapper(v: torch.Tensor, conv: nn.Conv2d, upsample2x: bool = False,
                    rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     s, p = conv.stride, conv.padding
@@ -80,32 +88,29 @@ def linear_residual_wrapper(v: torch.Tensor, linear: nn.Linear, residual: torch.
 
 
 for _name in ("attention_wrapper", "geglu_triton", "group_norm_wrapper", "layer_norm_wrapper", "linear_wrapper",
-              "linear_wrapper_functional", "timestep_wrapper", "conv2d_wrapper", "linear_geglu_wrapper",
+              "linear_wrapper_functional", "timestep_wrapper", "timestep_embedding_wrapper", "conv2d_wrapper", "linear_geglu_wrapper",
               "linear_residual_wrapper"):
     torch.fx.wrap(_name)
 
 
 # ---- fused projections sharing one input (q|k|v of self-attention, k|v of cross-attention) ----
-_cat_weights = {}
-
-
 def _cat_weight(linears):
-    """Row-concatenated weight (and bias) of several nn.Linear with the same in_features; rebuilt
-    whenever one of the source parameters changes (weight swaps / LoRA merges stay visible)."""
-    key = tuple(id(l) for l in linears)
-    stamp = tuple((l.weight.data_ptr(), l.weight._version, l.weight.dtype,
-                   None if l.bias is None else (l.bias.data_ptr(), l.bias._version)) for l in linears)
-    hit = _cat_weights.get(key)
-    if hit is None or hit[0] != stamp:
+    """Row-concatenated weight (and bias) of several nn.Linear with the same in_features.  The buffer is owned
+    by the current execution context (the compiled module) and is refreshed IN PLACE when a source parameter
+    changes, so weight swaps / LoRA merges stay visible and addresses captured in hipGraphs stay valid."""
+    sources = [l.weight for l in linears] + [l.bias for l in linears if l.bias is not None]
+
+    def compute():
         w = torch.cat([l.weight.detach() for l in linears], dim=0).contiguous()
         if all(l.bias is None for l in linears):
             b = None
         else:
             b = torch.cat([l.bias.detach() if l.bias is not None else
                            torch.zeros(l.out_features, dtype=l.weight.dtype, device=l.weight.device) for l in linears])
-        hit = (stamp, w, b)
-        _cat_weights[key] = hit
-    return hit[1], hit[2]
+        return (w, b)
+
+    key = ("cat",) + tuple(id(l) for l in linears)
+    return ops.current_context(linears[0].weight.device).derived_weights(key, sources, compute).value
 
 
 def linear_cat_wrapper(v: torch.Tensor, linears) -> torch.Tensor:
@@ -118,25 +123,21 @@ torch.fx.wrap("linear_cat_wrapper")
 
 
 # ---- LayerNorm folded into the projection(s) that consume it ---------------------------------
-_ln_folds = {}
-
-
 def _ln_fold(layernorm: nn.LayerNorm, linears):
-    key = (id(layernorm),) + tuple(id(l) for l in linears)
-    params = [layernorm.weight, layernorm.bias] + [l.weight for l in linears] + [l.bias for l in linears if l.bias is not None]
-    stamp = tuple((t.data_ptr(), t._version, t.dtype) for t in params)
-    hit = _ln_folds.get(key)
-    if hit is None or hit[0] != stamp:
-        with torch.no_grad():
-            w = torch.cat([l.weight.detach() for l in linears], dim=0) if len(linears) > 1 else linears[0].weight.detach()
-            if all(l.bias is None for l in linears):
-                b = None
-            else:
-                b = torch.cat([l.bias.detach().float() if l.bias is not None else
-                               torch.zeros(l.out_features, dtype=torch.float32, device=w.device) for l in linears])
-            hit = (stamp,) + ops.fold_layer_norm(layernorm.weight.detach(), layernorm.bias.detach(), w, b)
-        _ln_folds[key] = hit
-    return hit[1], hit[2], hit[3]
+    sources = [layernorm.weight, layernorm.bias] + [l.weight for l in linears] + [l.bias for l in linears if l.bias is not None]
+
+    @torch.no_grad()
+    def compute():
+        w = torch.cat([l.weight.detach() for l in linears], dim=0) if len(linears) > 1 else linears[0].weight.detach()
+        if all(l.bias is None for l in linears):
+            b = None
+        else:
+            b = torch.cat([l.bias.detach().float() if l.bias is not None else
+                           torch.zeros(l.out_features, dtype=torch.float32, device=w.device) for l in linears])
+        return ops.fold_layer_norm(layernorm.weight.detach(), layernorm.bias.detach(), w, b)
+
+    key = ("ln", id(layernorm)) + tuple(id(l) for l in linears)
+    return ops.current_context(layernorm.weight.device).derived_weights(key, sources, compute).value
 
 
 def ln_linear_wrapper(v: torch.Tensor, stats, layernorm: nn.LayerNorm, linears, geglu: bool = False) -> torch.Tensor:

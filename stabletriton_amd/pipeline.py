@@ -57,6 +57,7 @@ class DenoiseLoop:
         self.ehs.copy_(encoder_hidden_states)
         self.text_embeds.copy_(text_embeds)
         self.time_ids.copy_(time_ids)
+        self.refresh_weights()
         if self._split:
             with torch.no_grad():
                 new = self.unet.precompute_context(self.ehs)
@@ -66,14 +67,26 @@ class DenoiseLoop:
                 for dst, src in zip(self.ctx, new):
                     dst.copy_(src)
         if self._tsplit:
+            # every schedule entry in ONE pass: the time path sees n_steps * batch rows (row s*B + b = step s, sample b),
+            # so its GEMMs run once with M = n_steps * batch instead of n_steps times with M = batch
+            n, b = self.n_steps, self.ehs.shape[0]
             with torch.no_grad():
-                rows = [self.unet.precompute_time(self.x_in, self.timesteps[i], self._cond()) for i in range(self.n_steps)]
-                new = tuple(torch.stack([r[j] for r in rows]) for j in range(len(rows[0])))
+                rows = self.x_in.new_empty((n * b, 1, 1, 1))                       # read for its batch size and dtype only
+                cond = {"text_embeds": self.text_embeds.repeat(n, 1), "time_ids": self.time_ids.repeat(n, 1)}
+                out = self.unet.precompute_time(rows, self.timesteps.repeat_interleave(b), cond)
+                new = tuple(o.reshape(n, b, *o.shape[1:]) for o in out)
             if self.time_tables is None:
-                self.time_tables = new
+                self.time_tables = tuple(t.clone() for t in new)
             else:
                 for dst, src in zip(self.time_tables, new):
                     dst.copy_(src)
+
+    def refresh_weights(self) -> int:
+        """Captured graphs read derived weight buffers (fused q|k|v, LayerNorm-folded projections) by address: after an
+        in-place weight update (LoRA merge) re-derive them in place.  Called per prompt; call it yourself after updating
+        weights between two runs of the same prompt."""
+        ectx = getattr(self.unet, "exec_context", None)
+        return ectx.refresh_derived(full=True) if ectx is not None else 0
 
     def set_noise(self, latent_unit: torch.Tensor) -> None:
         """latent_unit ~ N(0,1); scaled by the scheduler's init sigma (fp32 state)."""

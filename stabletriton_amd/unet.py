@@ -303,13 +303,16 @@ class UNet2DConditionModel(nn.Module):
         self.conv_out = nn.Conv2d(w[0], spec.out_channels, 3, padding=1)
 
     def forward(self, sample, timesteps, encoder_hidden_states, added_cond_kwargs, **kwargs):
-        timesteps = timesteps.expand(sample.shape[0])
-        emb = self.time_embedding(self.time_proj(timesteps).to(dtype=sample.dtype))
         text_embeds = added_cond_kwargs.get("text_embeds")
         time_ids = added_cond_kwargs.get("time_ids")
         tid = self.add_time_proj(time_ids.flatten()).reshape((text_embeds.shape[0], -1))
-        add = torch.concat([text_embeds, tid], dim=-1).to(emb.dtype)
-        emb = emb + self.add_embedding(add)
+        return self.denoise(sample, timesteps, encoder_hidden_states, torch.concat([text_embeds, tid], dim=-1))
+
+    def denoise(self, sample, timesteps, encoder_hidden_states, add):
+        """`add` = pooled text embedding | Fourier features of the size/crop ids, (B, add_in_dim)."""
+        timesteps = timesteps.expand(sample.shape[0])
+        emb = self.time_embedding(self.time_proj(timesteps).to(dtype=sample.dtype))
+        emb = emb + self.add_embedding(add.to(emb.dtype))
 
         x = self.conv_in(sample)
         skips = [x]
@@ -320,6 +323,19 @@ class UNet2DConditionModel(nn.Module):
             x = blk.decode(x, emb, encoder_hidden_states, skips)
         x = self.conv_out(self.conv_act(self.conv_norm_out(x)))
         return [x]
+
+
+class UNetWithLabelVector(nn.Module):
+    """The same network entered the way ComfyUI calls an SDXL UNet: `y` is the ready-made (B, add_in_dim) vector
+    (pooled text embedding | Fourier features of the six size/crop ids, each through the 256-wide cos|sin embedder -
+    exactly the `add` vector the Diffusers form builds from added_cond_kwargs).  Shares its weights with `unet`."""
+
+    def __init__(self, unet: "UNet2DConditionModel"):
+        super().__init__()
+        self.unet = unet
+
+    def forward(self, sample, timesteps, encoder_hidden_states, y, **kwargs):
+        return self.unet.denoise(sample, timesteps, encoder_hidden_states, y)
 
 
 def make_config(spec: UNetSpec):

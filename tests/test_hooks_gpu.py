@@ -1,0 +1,207 @@
+"""The host hooks at the reference's real call sites.
+
+Diffusers: a duck-typed pipeline that drives `pipe.unet` exactly like the reference's script does through
+diffusers 0.21.2 (implementations/Diffusers/load_sdxl_pipeline.py:17-46): fp16 tensors, classifier-free guidance
+(UNet batch 2), keyword arguments `encoder_hidden_states= / cross_attention_kwargs=None / added_cond_kwargs= /
+return_dict=False`, 50 timesteps, result `[0]` in the caller's dtype.  Checked against the oracle running the same
+loop (golden F3-cfg generated from the reference UNet for SDXL-base; the oracle itself for the small network).
+ComfyUI: `diffusion_model(x, timesteps, context, y, control, transformer_options)` with per-row timesteps.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as orc
+from stabletriton_amd import hooks, synth
+from stabletriton_amd.optimization import optimize_model
+from stabletriton_amd.scheduler import euler_discrete_tables
+from stabletriton_amd.unet import SDXL_BASE, TINY, UNet2DConditionModel
+from tests.util import golden
+
+pytestmark = pytest.mark.gpu
+ABS_TOL_STRICT = 1e-3
+# Classifier-free guidance forms eps = eps_neg + g (eps_pos - eps_neg) = 5 eps_pos - 4 eps_neg at g = 5: whatever separates two
+# fp32 implementations of the UNet (summation order: 1e-5 per step, tests/test_unet_gpu.py F1) enters the latent nine times
+# larger, fifty times over.  Without guidance the 50-step final latent agrees to 6e-5 (F3, bound 1e-3); with it the measured
+# deviation is 1.0e-3 on a latent of magnitude 51 (2e-5 relative), so this protocol is gated at 2e-3 and the value is printed.
+ABS_TOL_STRICT_CFG = 2e-3
+
+
+class StubPipeline:
+    """The denoising loop of diffusers' StableDiffusionXLPipeline.__call__ (0.21.2), reduced to what touches the UNet."""
+
+    def __init__(self, unet, dtype, device, tables, guidance_scale):
+        self.unet, self.dtype, self.device, self.tables, self.g = unet, dtype, device, tables, guidance_scale
+        assert unet.config.in_channels == 4 and unet.config.addition_time_embed_dim > 0 and unet.config.sample_size > 0
+
+    @torch.no_grad()
+    def __call__(self, latent_unit, prompt_embeds, text_embeds, time_ids, state_dtype=None):
+        t = self.tables
+        state_dtype = state_dtype or self.dtype
+        latents = (latent_unit.to(self.device, torch.float32) * t.init_noise_sigma).to(state_dtype)
+        timesteps = torch.tensor(t.timesteps, device=self.device)                    # scheduler.timesteps (on the device)
+        in_scale, dsigma = t.in_scale(), t.dsigma()
+        added = {"text_embeds": text_embeds.to(self.device, self.dtype), "time_ids": time_ids.to(self.device, self.dtype)}
+        prompt_embeds = prompt_embeds.to(self.device, self.dtype)
+        for i, ts in enumerate(timesteps):                                            # ts: 0-dim device tensor
+            latent_model_input = torch.cat([latents] * 2)
+            latent_model_input = (latent_model_input.float() * float(in_scale[i])).to(self.dtype)     # scheduler.scale_model_input
+            noise_pred = self.unet(latent_model_input, ts, encoder_hidden_states=prompt_embeds, cross_attention_kwargs=None,
+                                   added_cond_kwargs=added, return_dict=False)[0]
+            assert noise_pred.dtype == self.dtype and noise_pred.shape == latent_model_input.shape
+            uncond, text = noise_pred.chunk(2)
+            noise_pred = uncond + self.g * (text - uncond)
+            latents = (latents.float() + noise_pred.float() * float(dsigma[i])).to(state_dtype)     # scheduler.step
+        return latents.float().cpu()
+
+
+def _tiny(dtype, dev):
+    m = UNet2DConditionModel(TINY).eval().requires_grad_(False).to(dev, dtype)
+    synth.fill_module_(m, 0)
+    return m
+
+
+@pytest.mark.parametrize("io_dtype,compute,tol", [(torch.float32, torch.float32, ABS_TOL_STRICT), (torch.float16, torch.bfloat16, None)])
+def test_diffusers_callsite_tiny(gpu, io_dtype, compute, tol):
+    tables = euler_discrete_tables(10)
+    m = _tiny(compute, gpu)
+    unet = hooks.compile_unet_from_state_dict(m.state_dict(), TINY, compute, gpu)
+    x = synth.denoise_inputs(2, 16, 1234, cross_dim=TINY.cross_dim, pooled_dim=TINY.pooled_dim)
+    pipe = StubPipeline(unet, io_dtype, gpu, tables, 5.0)
+    out = pipe(x["latent"][:1], x["encoder_hidden_states"], x["text_embeds"], x["time_ids"], state_dtype=torch.float32)
+    again = pipe(x["latent"][:1], x["encoder_hidden_states"], x["text_embeds"], x["time_ids"], state_dtype=torch.float32)
+    assert torch.equal(out, again)                               # second image: replays of the captured graph, cached context
+    sd = {k: v.float().cpu() for k, v in m.state_dict().items()}
+    xr = {k: v.to(io_dtype).float() for k, v in x.items()}
+    ref = orc.euler_denoise_cfg(
+        lambda xi, t: orc.unet_forward(sd, xi, t, xr["encoder_hidden_states"], xr["text_embeds"], xr["time_ids"]),
+        x["latent"][:1], tables, 5.0)
+    err = float((out - ref).abs().max())
+    print(f"tiny CFG 10-step call site, io {io_dtype} compute {compute}: max abs err {err:.2e} (|ref| max {float(ref.abs().max()):.2f})")
+    if tol is not None:
+        assert err <= tol
+    else:
+        assert err <= 0.05 * float(ref.abs().max())
+
+
+def test_diffusers_callsite_sdxl_fp32(gpu, sdxl_fp32):
+    """SDXL-base, the reference protocol (CFG batch 2, 50 steps), strict mode: north_star bound on the final latent."""
+    g = golden("f3_cfg50_latent64")
+    x = synth.denoise_inputs(2, 64, 1234)
+    unet = hooks.DiffusersUNet(sdxl_fp32, SDXL_BASE, torch.float32)
+    pipe = StubPipeline(unet, torch.float32, gpu, euler_discrete_tables(50), float(g["guidance_scale"]))
+    out = pipe(x["latent"][:1], x["encoder_hidden_states"], x["text_embeds"], x["time_ids"])
+    ref = torch.from_numpy(g["final"])
+    err = float((out - ref).abs().max())
+    print(f"F3-cfg fp32 call site: max abs err on final latent {err:.2e} (|ref| max {float(ref.abs().max()):.2f})")
+    assert err <= ABS_TOL_STRICT_CFG
+
+
+def test_diffusers_callsite_sdxl_fp16_pipeline(gpu, sdxl_bf16):
+    """The actual call shape: an fp16 pipeline around bf16 kernels.  Deviation reported and bounded."""
+    g = golden("f3_cfg50_latent64")
+    x = synth.denoise_inputs(2, 64, 1234)
+    unet = hooks.DiffusersUNet(sdxl_bf16, SDXL_BASE, torch.bfloat16)
+    pipe = StubPipeline(unet, torch.float16, gpu, euler_discrete_tables(50), float(g["guidance_scale"]))
+    out = pipe(x["latent"][:1], x["encoder_hidden_states"], x["text_embeds"], x["time_ids"])
+    ref = torch.from_numpy(g["final"])
+    rms = float((out - ref).pow(2).mean().sqrt())
+    ref_rms = float(ref.pow(2).mean().sqrt())
+    print(f"F3-cfg fp16 pipeline / bf16 kernels: final latent rms err {rms:.2e} = {100 * rms / ref_rms:.2f} % of rms {ref_rms:.2f}, "
+          f"max abs {float((out - ref).abs().max()):.2e}")
+    assert torch.isfinite(out).all()
+    assert rms <= 0.045 * ref_rms          # measured 2.9 % (fp16 latent state, guidance x9): 1.5x headroom
+
+
+def test_diffusers_hook_rejects_unsupported(gpu):
+    m = _tiny(torch.float32, gpu)
+    unet = hooks.compile_unet_from_state_dict(m.state_dict(), TINY, torch.float32, gpu, cuda_graph=False)
+    x = synth.denoise_inputs(1, 16, 1234, cross_dim=TINY.cross_dim, pooled_dim=TINY.pooled_dim)
+    xg = {k: v.to(gpu) for k, v in x.items()}
+    cond = {"text_embeds": xg["text_embeds"], "time_ids": xg["time_ids"]}
+    with pytest.raises(NotImplementedError):
+        unet(xg["latent"], 10.0, encoder_hidden_states=xg["encoder_hidden_states"], added_cond_kwargs=cond, cross_attention_kwargs={"scale": 0.5})
+    with pytest.raises(NotImplementedError):
+        unet(xg["latent"], 10.0, encoder_hidden_states=xg["encoder_hidden_states"], added_cond_kwargs=cond, timestep_cond=xg["text_embeds"])
+    out = unet(xg["latent"], 10.0, encoder_hidden_states=xg["encoder_hidden_states"], added_cond_kwargs=cond, return_dict=True)
+    assert out.sample.shape == xg["latent"].shape
+
+
+def test_weight_update_is_seen_by_captured_graphs(gpu):
+    """In-place weight updates (LoRA merge) reach the fused q|k|v / LayerNorm-folded buffers the captured graphs read."""
+    m = _tiny(torch.float32, gpu)
+    unet = hooks.compile_unet_from_state_dict(m.state_dict(), TINY, torch.float32, gpu)
+    inner = unet.compiled                                  # the compiled module owns a copy of the weights
+    x = synth.denoise_inputs(1, 16, 1234, cross_dim=TINY.cross_dim, pooled_dim=TINY.pooled_dim)
+    xg = {k: v.to(gpu) for k, v in x.items()}
+    cond = {"text_embeds": xg["text_embeds"], "time_ids": xg["time_ids"]}
+    call = lambda: unet(xg["latent"], torch.tensor(300.0), encoder_hidden_states=xg["encoder_hidden_states"], added_cond_kwargs=cond)[0].clone()
+    before = call()
+    assert torch.equal(before, call())
+    with torch.no_grad():
+        for name, p in inner.named_parameters():
+            if name.endswith("attn1.to_q.weight") or name.endswith("norm3.weight") or name.endswith("attn2.to_v.weight"):
+                p.mul_(1.25)
+    assert unet.refresh_weights() > 0
+    xg["encoder_hidden_states"].add_(0)                    # same prompt tensor, new version: the context cache re-evaluates
+    after = call()
+    assert not torch.equal(before, after)
+    sd = {k: v.float().cpu() for k, v in inner.state_dict().items()}
+    ref = orc.unet_forward(sd, x["latent"], torch.tensor(300.0), x["encoder_hidden_states"], x["text_embeds"], x["time_ids"])
+    err = float((after.cpu() - ref).abs().max())
+    print(f"after in-place weight update: max abs err vs oracle with the updated weights {err:.2e}")
+    assert err <= ABS_TOL_STRICT
+
+
+# ------------------------------------------------------------------------------------------------ ComfyUI
+def _label_vector(spec, text_embeds, time_ids):
+    """What ComfyUI hands the SDXL UNet as `y`: pooled text | cos|sin features (256 each) of the six size/crop ids."""
+    b = text_embeds.shape[0]
+    return torch.cat([text_embeds, orc.timestep_features(time_ids.flatten(), spec.add_time_proj_dim).reshape(b, -1)], dim=-1)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, ABS_TOL_STRICT), (torch.bfloat16, 0.1)])
+def test_comfy_callsite_tiny(gpu, dtype, tol):
+    m = _tiny(dtype, gpu)
+
+    class Patcher:                                         # duck-typed ModelPatcher: .model.diffusion_model
+        class model:
+            diffusion_model = None
+    adapter = hooks.patch_comfy_model(Patcher, m)
+    assert Patcher.model.diffusion_model is adapter
+    x = synth.denoise_inputs(3, 16, 1234, cross_dim=TINY.cross_dim, pooled_dim=TINY.pooled_dim)
+    xr = {k: v.to(dtype).float() for k, v in x.items()}
+    tvec = torch.tensor([801.0, 400.0, 12.0])              # one timestep per row
+    y = _label_vector(TINY, xr["text_embeds"], xr["time_ids"])
+    out = adapter(x["latent"].to(gpu, dtype), timesteps=tvec.to(gpu), context=x["encoder_hidden_states"].to(gpu, dtype),
+                  y=y.to(gpu, dtype), control=None, transformer_options={})
+    assert out.dtype == dtype
+    sd = {k: v.float().cpu() for k, v in m.state_dict().items()}
+    ref = orc.unet_forward(sd, xr["latent"], tvec, xr["encoder_hidden_states"], xr["text_embeds"], xr["time_ids"])
+    err = float((out.float().cpu() - ref).abs().max())
+    print(f"comfy call site {dtype}: per-row timesteps, max abs err {err:.2e}")
+    assert err <= tol
+    with pytest.raises(NotImplementedError):
+        adapter(x["latent"].to(gpu, dtype), timesteps=tvec.to(gpu), context=x["encoder_hidden_states"].to(gpu, dtype), y=y.to(gpu, dtype),
+                control={"output": []})
+    with pytest.raises(NotImplementedError):
+        adapter(x["latent"].to(gpu, dtype), timesteps=tvec.to(gpu), context=x["encoder_hidden_states"].to(gpu, dtype), y=y.to(gpu, dtype),
+                transformer_options={"patches": {"attn1_patch": [object()]}})
+    with pytest.raises(ValueError):
+        adapter(x["latent"].to(gpu, dtype), timesteps=tvec[:2].to(gpu), context=x["encoder_hidden_states"].to(gpu, dtype), y=y.to(gpu, dtype))
+
+
+def test_comfy_callsite_sdxl_b4_per_row_timesteps(gpu, sdxl_fp32_pair):
+    """BASELINE config #3 rows (batch 4, 77-token conditioning) through the ComfyUI entry with one timestep per row,
+    against the reference UNet's own output (golden F1-b4 `out_tvec`)."""
+    g = golden("f1_unet_step_latent64_b4")
+    model, _ = sdxl_fp32_pair
+    adapter = hooks.compile_comfy_unet(model, cuda_graph=False)
+    x = synth.denoise_inputs(4, 64, 1234)
+    y = _label_vector(SDXL_BASE, x["text_embeds"], x["time_ids"])
+    out = adapter(x["latent"].to(gpu), timesteps=torch.from_numpy(g["timesteps_vec"]).to(gpu), context=x["encoder_hidden_states"].to(gpu),
+                  y=y.to(gpu))
+    ref = torch.from_numpy(g["out_tvec"])
+    err = float((out.cpu() - ref).abs().max())
+    print(f"F1-b4 per-row timesteps via the ComfyUI entry, fp32: max abs err {err:.2e} (|ref| max {float(ref.abs().max()):.2f})")
+    assert err <= ABS_TOL_STRICT

@@ -62,7 +62,7 @@ def test_pass_counts_match_reference_probe_on_sdxl():
     _install_context_split(gm)
     assert gm.rewrite_stats["context_outputs"] == 140 and gm.rewrite_stats["time_outputs"] == 1
     # no M=batch GEMM is left in the per-step graph: the whole time path lives in gm.time_module
-    assert not [n for n in gm.graph.nodes if n.op == "call_function" and getattr(n.target, "__name__", "") == "timestep_wrapper"]
+    assert not [n for n in gm.graph.nodes if n.op == "call_function" and getattr(n.target, "__name__", "") in ("timestep_wrapper", "timestep_embedding_wrapper")]
     assert len([n for n in gm.time_module.graph.nodes if n.op == "call_function"
                 and getattr(n.target, "__name__", "") in ("linear_wrapper", "linear_cat_wrapper")]) == 4
     left = [n for n in gm.graph.nodes if n.op == "call_module"]

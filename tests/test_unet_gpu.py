@@ -168,21 +168,7 @@ def test_f2_golden_ops(gpu, dtype, tol):
 
 
 # ---------------------------------------------------------------------------------- SDXL-base, reference goldens
-@pytest.fixture(scope="module")
-def sdxl_fp32(gpu):
-    m, gm = build(SDXL_BASE, torch.float32, gpu, graph=False)
-    yield gm
-    del m, gm
-    torch.cuda.empty_cache()
-
-
-@pytest.fixture(scope="module")
-def sdxl_bf16(gpu):
-    m, gm = build(SDXL_BASE, torch.bfloat16, gpu, graph=False)
-    yield gm
-    del m, gm
-    torch.cuda.empty_cache()
-
+# (the SDXL-base fixtures `sdxl_fp32` / `sdxl_bf16` live in conftest.py: one build per session, shared with test_hooks_gpu.py)
 
 def _sdxl_step(gm, dtype, dev, hw):
     x = synth.denoise_inputs(1, hw, 1234)
@@ -207,7 +193,8 @@ def test_sdxl_f1_step_bf16(gpu, sdxl_bf16):
     err = float((out - ref).abs().max())
     print(f"F1 bf16: max abs err {err:.2e}, rms err {float((out - ref).pow(2).mean().sqrt()):.2e} "
           f"(|ref| max {float(ref.abs().max()):.2f}, rms {float(ref.pow(2).mean().sqrt()):.2f})")
-    assert err <= 0.1          # bf16 storage: ~2 decimal digits through ~600 dependent ops
+    # bf16 storage: ~2 decimal digits through ~600 dependent ops; bounds = 1.5x the measured 6.5e-2 / 1.8e-2
+    assert err <= 0.1 and float((out - ref).pow(2).mean().sqrt()) <= 0.027
 
 
 def _sdxl_loop(gm, dtype, dev, hw, mode="loop"):
@@ -238,4 +225,133 @@ def test_sdxl_f3_euler50_bf16(gpu, sdxl_bf16, hw):
     print(f"F3 latent{hw} bf16: final latent max abs err {err:.2e}, rms {rms:.2e} "
           f"(|ref| max {float(ref.abs().max()):.2f}, rms {float(ref.pow(2).mean().sqrt()):.2f})")
     assert torch.isfinite(out).all()
-    assert rms <= 0.05 * float(ref.pow(2).mean().sqrt())      # bf16 mode: reported, loosely bounded
+    assert rms <= 0.0075 * float(ref.pow(2).mean().sqrt())    # bf16 mode: reported; bound = 1.5x the measured 0.5 % of the latent rms
+
+
+# ---------------------------------------------------------------------------------- BASELINE config #3: batch > 1 on SDXL-base
+def _sdxl_step_b4(gm, dtype, dev, t):
+    x = synth.denoise_inputs(4, 64, 1234)
+    xg = {k: v.to(dev, dtype) for k, v in x.items()}
+    with torch.no_grad():
+        return gm(xg["latent"], t.to(dev), xg["encoder_hidden_states"],
+                  {"text_embeds": xg["text_embeds"], "time_ids": xg["time_ids"]})[0].float().cpu()
+
+
+def test_sdxl_f1_b4_step_fp32(gpu, sdxl_fp32):
+    """bs=4, 77-token text conditioning distinct per row, vs the reference's own batch-4 output; scalar and per-row timesteps."""
+    g = golden("f1_unet_step_latent64_b4")
+    for key, t in (("out", torch.tensor(float(g["timestep"]))), ("out_tvec", torch.from_numpy(g["timesteps_vec"]))):
+        ref = torch.from_numpy(g[key])
+        out = _sdxl_step_b4(sdxl_fp32, torch.float32, gpu, t)
+        err = float((out - ref).abs().max())
+        print(f"F1-b4 {key} fp32: max abs err {err:.2e} (|ref| max {float(ref.abs().max()):.2f})")
+        assert err <= ABS_TOL_STRICT
+
+
+def test_sdxl_f1_b4_step_bf16(gpu, sdxl_bf16):
+    g = golden("f1_unet_step_latent64_b4")
+    ref = torch.from_numpy(g["out"])
+    out = _sdxl_step_b4(sdxl_bf16, torch.bfloat16, gpu, torch.tensor(float(g["timestep"])))
+    err, rms = float((out - ref).abs().max()), float((out - ref).pow(2).mean().sqrt())
+    print(f"F1-b4 bf16: max abs err {err:.2e}, rms err {rms:.2e} (|ref| max {float(ref.abs().max()):.2f}, rms {float(ref.pow(2).mean().sqrt()):.2f})")
+    assert err <= 0.1 and rms <= 0.03                 # measured 6.5e-2 / 1.8e-2 at bs=1: ~1.5x headroom
+
+
+def _sdxl_loop_batch(gm, dtype, dev, hw, batch, mode, steps=None):
+    x = synth.denoise_inputs(batch, hw, 1234)
+    loop = DenoiseLoop(gm, batch, hw, dtype, dev, euler_discrete_tables(50), mode=mode)
+    loop.set_conditioning(x["encoder_hidden_states"].to(dev, dtype), x["text_embeds"].to(dev, dtype), x["time_ids"].to(dev, dtype))
+    with torch.no_grad():
+        if steps is None:
+            return loop.denoise(x["latent"]).cpu()
+        loop.set_noise(x["latent"])
+        loop.run_steps(steps)
+        return loop.latent.contiguous(memory_format=torch.contiguous_format).clone().cpu()
+
+
+def test_sdxl_f3_b2_euler50_fp32(gpu, sdxl_fp32):
+    """Two prompts in one batch through the captured loop vs the reference UNet in the same loop (batch 2)."""
+    ref = torch.from_numpy(golden("f3_euler50_latent64_b2")["final"])
+    out = _sdxl_loop_batch(sdxl_fp32, torch.float32, gpu, 64, 2, "step")
+    err = float((out - ref).abs().max())
+    print(f"F3-b2 latent64 fp32: max abs err on final latents {err:.2e} (|ref| max {float(ref.abs().max()):.2f})")
+    assert err <= ABS_TOL_STRICT
+
+
+def test_sdxl_f3_b2_euler50_bf16(gpu, sdxl_bf16):
+    ref = torch.from_numpy(golden("f3_euler50_latent64_b2")["final"])
+    out = _sdxl_loop_batch(sdxl_bf16, torch.bfloat16, gpu, 64, 2, "loop")
+    rms, ref_rms = float((out - ref).pow(2).mean().sqrt()), float(ref.pow(2).mean().sqrt())
+    print(f"F3-b2 latent64 bf16: final latent rms err {rms:.2e} = {100 * rms / ref_rms:.2f} % of {ref_rms:.2f}")
+    assert torch.isfinite(out).all() and rms <= 0.015 * ref_rms          # measured 0.5 % at bs=1: tightened from 5 %
+
+
+@pytest.mark.parametrize("hw", [64, 128])
+def test_sdxl_loop_batch4_rows_are_independent(gpu, sdxl_fp32, hw):
+    """DenoiseLoop(batch=4) at BASELINE config #3's size: the samples of a batch never mix, so every row of a batch-4
+    run equals the batch-1 run of that prompt (a size-independent property; the bs=1 path is pinned by F1/F3).
+    Different M picks different GEMM tiles / K splits, so the comparison is to fp32 summation-order accuracy."""
+    steps = 3
+    x4 = synth.denoise_inputs(4, hw, 1234)
+    out4 = _sdxl_loop_batch(sdxl_fp32, torch.float32, gpu, hw, 4, "step", steps)
+    worst = 0.0
+    for b in (0, 3):
+        loop = DenoiseLoop(sdxl_fp32, 1, hw, torch.float32, gpu, euler_discrete_tables(50), mode="eager")
+        loop.set_conditioning(x4["encoder_hidden_states"][b:b + 1].to(gpu), x4["text_embeds"][b:b + 1].to(gpu), x4["time_ids"][b:b + 1].to(gpu))
+        with torch.no_grad():
+            loop.set_noise(x4["latent"][b:b + 1])
+            loop.run_steps(steps)
+        worst = max(worst, float((loop.latent.cpu() - out4[b:b + 1]).abs().max()))
+    print(f"batch-4 rows vs batch-1 runs, latent {hw}, {steps} steps, fp32: max abs diff {worst:.2e}")
+    assert worst <= 2e-4
+
+
+def test_sdxl_bs4_bf16_loop_graph_1024px(gpu, sdxl_bf16):
+    """BASELINE config #3 as benchmarked: bs=4, latent 128, bf16, whole loop in one hipGraph; rows match bs=1 runs."""
+    x4 = synth.denoise_inputs(4, 128, 1234)
+    out4 = _sdxl_loop_batch(sdxl_bf16, torch.bfloat16, gpu, 128, 4, "loop")
+    ref = torch.from_numpy(golden("f3_euler50_latent128")["final"])           # row 0 of the batch is NOT the bs=1 input (different draw)
+    assert torch.isfinite(out4).all() and out4.shape == (4, 4, 128, 128)
+    loop = DenoiseLoop(sdxl_bf16, 1, 128, torch.bfloat16, gpu, euler_discrete_tables(50), mode="loop")
+    loop.set_conditioning(x4["encoder_hidden_states"][1:2].to(gpu, torch.bfloat16), x4["text_embeds"][1:2].to(gpu, torch.bfloat16),
+                          x4["time_ids"][1:2].to(gpu, torch.bfloat16))
+    with torch.no_grad():
+        one = loop.denoise(x4["latent"][1:2]).cpu()
+    rms = float((one - out4[1:2]).pow(2).mean().sqrt())
+    scale = float(ref.pow(2).mean().sqrt())
+    print(f"bs=4 loop graph at 1024 px, bf16: row 1 vs its bs=1 trajectory rms diff {rms:.2e} ({100 * rms / scale:.2f} % of the latent rms)")
+    assert rms <= 0.015 * scale
+
+
+def test_two_loops_interleaved_stay_bit_identical(gpu, sdxl_bf16):
+    """Host state is owned per compiled module (ops.ExecContext): a TINY loop and an SDXL loop interleaved in one
+    process give bit for bit what each gives alone."""
+    tiny_m, tiny = build(TINY, torch.bfloat16, gpu, graph=False)
+    tables = euler_discrete_tables(10)
+    xt, xtg = tiny_inputs(torch.bfloat16, gpu, 1, 16)
+    xs = synth.denoise_inputs(1, 32, 1234)
+
+    def make():
+        a = DenoiseLoop(tiny, 1, 16, torch.bfloat16, gpu, tables, cross_dim=TINY.cross_dim, pooled_dim=TINY.pooled_dim, mode="step")
+        a.set_conditioning(xtg["encoder_hidden_states"], xtg["text_embeds"], xtg["time_ids"])
+        b = DenoiseLoop(sdxl_bf16, 1, 32, torch.bfloat16, gpu, tables, mode="step")
+        b.set_conditioning(xs["encoder_hidden_states"].to(gpu, torch.bfloat16), xs["text_embeds"].to(gpu, torch.bfloat16),
+                           xs["time_ids"].to(gpu, torch.bfloat16))
+        return a, b
+
+    with torch.no_grad():
+        a, b = make()
+        solo_a = a.denoise(xt["latent"])
+        solo_b = b.denoise(xs["latent"])
+        a, b = make()
+        a.set_noise(xt["latent"]); b.set_noise(xs["latent"])
+        sa, sb = torch.cuda.Stream(device=gpu), torch.cuda.Stream(device=gpu)
+        a.capture(); b.capture()
+        torch.cuda.synchronize()
+        for _ in range(10):                        # the two graphs replay concurrently on two streams
+            with torch.cuda.stream(sa):
+                a.run_steps(1)
+            with torch.cuda.stream(sb):
+                b.run_steps(1)
+        torch.cuda.synchronize()
+    assert torch.equal(a.latent.cpu(), solo_a.cpu()) and torch.equal(b.latent.cpu(), solo_b.cpu())
