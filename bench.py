@@ -120,9 +120,9 @@ def census(loop):
     behind a spin kernel: by the time the GPU reaches it every launch and event record is already
     in the queue, kernels run back to back as in the graph, and event deltas are device times.
 
-    Returns (families, step_ms, marker_ms): per family the summed event deltas with the cost of one
-    event record removed, the step's device time with every record removed (operator launches plus
-    the torch glue kernels between them), and the per-record cost."""
+    Returns (families, step_ms, marker_ms, glue_ms): per family the summed event deltas with the cost of one
+    event record removed (kernel-only time), the step's kernel-only time including the torch glue kernels
+    between the operator launches, the per-record cost and the glue time."""
     import torch
     from stabletriton_amd import ops
     store = []
@@ -141,7 +141,10 @@ def census(loop):
     ops.set_census(None)
     torch.cuda.synchronize()
     loop.mode = loop_mode
-    pair_ms = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
+    # cost of one event record: between two operator launches with no torch kernel in between, the gap e1(i) -> e0(i+1)
+    # is exactly one record, so the median gap is that cost in the regime it is paid in (the empty pairs bound it from below)
+    gaps = sorted(store[i][4].elapsed_time(store[i + 1][3]) for i in range(len(store) - 1))
+    pair_ms = max(gaps[len(gaps) // 2], sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2])
     fam = {}
     for name, flops, nbytes, e0, e1, _tag in store:
         f = fam.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
@@ -149,8 +152,8 @@ def census(loop):
         f["ms"] += max(e0.elapsed_time(e1) - pair_ms, 0.0)
         f["flops"] += flops
         f["bytes"] += nbytes
-    wall = store[0][3].elapsed_time(store[-1][4])
-    step_ms = wall - (2 * len(store) - 1) * pair_ms
+    glue_ms = sum(max(g - pair_ms, 0.0) for g in gaps)           # torch kernels between operator launches (cat, casts)
+    step_ms = sum(f["ms"] for f in fam.values()) + glue_ms
     if os.environ.get("ST_CENSUS_SHAPES"):           # developer view: time per (operator, shape)
         rows = {}
         for name, flops, nbytes, e0, e1, tag in store:
@@ -160,7 +163,7 @@ def census(loop):
             print(f"  {ms:7.3f} ms  x{cnt:3d}  {ms / cnt * 1e3:7.1f} us  {fl / max(ms, 1e-9) / 1e9:7.1f} TF/s  {name:16s} {tag}", file=sys.stderr)
         print(f"  census step {step_ms:.3f} ms (operators {sum(f['ms'] for f in fam.values()):.3f} ms, {len(store)} launches, "
               f"event record {pair_ms * 1e3:.2f} us)", file=sys.stderr)
-    return fam, step_ms, pair_ms
+    return fam, step_ms, pair_ms, glue_ms
 
 
 def committed_profile(name):
@@ -187,11 +190,11 @@ def committed_profile(name):
     return out, traffic, mfma_busy
 
 
-def roofline_of(name, f, scale):
-    """`scale` = graph-replay step time / census step time: a kernel in the replayed graph also pays the dependent-launch
-    boundary in front of it (rocprofv3 attributes it to the kernel), an event-bracketed one does not; the per-family times
-    are the census shares of the step the graph actually runs."""
-    ms = f["ms"] * scale
+def roofline_of(name, f, boundary_ms):
+    """`boundary_ms`: what one launch costs in the replayed graph on top of its kernel-only time - the dependent-launch
+    boundary in front of every kernel, which rocprofv3 attributes to the kernel (its trace shows back-to-back kernels with
+    no gaps) and an event-bracketed launch does not see: (graph step time - census kernel-only time) / launches."""
+    ms = f["ms"] + f["launches"] * boundary_ms
     sec = ms * 1e-3
     if BOUND[name] == "mfma":
         ach, peak, unit = f["flops"] / sec / 1e12, PEAK_BF16_TFLOPS, "TFLOP/s"
@@ -376,15 +379,16 @@ def main():
                 result["rccl"] = rccl_report(rccl_log)
         if rank == 0 and world == 1:
             if not args.no_census:
-                fam, census_ms, marker_ms = census(loop)
-                scale = ms_per_step / census_ms
-                roofs = {k: roofline_of(k, v, scale) for k, v in fam.items()}
+                fam, census_ms, marker_ms, glue_ms = census(loop)
+                n_launch = sum(f["launches"] for f in fam.values())
+                boundary_ms = max(ms_per_step - census_ms, 0.0) / n_launch
+                roofs = {k: roofline_of(k, v, boundary_ms) for k, v in fam.items()}
                 dominant = max(fam, key=lambda k: fam[k]["ms"])
                 result["roofline"] = roofs[dominant]
                 result["kernels"] = sorted(roofs.values(), key=lambda r: -r["ms_per_step"])
-                result["census"] = {"step_ms": round(census_ms, 3), "graph_step_ms": round(ms_per_step, 3),
-                                    "event_record_us": round(marker_ms * 1e3, 2),
-                                    "operator_share": round(sum(f["ms"] for f in fam.values()) / census_ms, 4)}
+                result["census"] = {"kernel_only_step_ms": round(census_ms, 3), "graph_step_ms": round(ms_per_step, 3),
+                                    "launches_per_step": n_launch, "boundary_us_per_launch": round(boundary_ms * 1e3, 3),
+                                    "torch_glue_ms": round(glue_ms, 3), "event_record_us": round(marker_ms * 1e3, 2)}
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(model, args.latent)
     if rank == 0:

@@ -488,6 +488,447 @@ __global__ __launch_bounds__(NW * 64) void attn16_bf16_kernel(const bf16* __rest
     }
 }
 
+// ---- 16-row kernel, second generation: the softmax is cut to what the VALU cannot avoid ------------
+// At D = 64 the kernel is bound by the softmax arithmetic, not by the matrix pipe (per 16 x 64 score tile a wave
+// issues 16-18 MFMAs = 290 pipe cycles, and the classic online softmax ~100 VALU instructions = 450 issue cycles).
+// What is left here per score: one v_exp_f32, half a v_max3_f32, half a v_cvt_pk_bf16_f32:
+//   * Q is pre-multiplied by scale * log2(e) once (bf16, like every MFMA operand), so scores are base-2 exponents;
+//   * the S accumulators start at -m_ref (the row's reference maximum) instead of 0: the MFMA chain delivers
+//     s - m_ref and the exponent needs no subtraction;
+//   * m_ref follows the true row maximum lazily: a tile whose scores stay below m_ref + 2^ATT_LAG keeps it (softmax is
+//     shift invariant; P <= 2^ATT_LAG is as exact in bf16 / fp32 as P <= 1); the first tile, and any tile that
+//     exceeds the lag, takes the exact path (row maximum across lanes, rescale O, shift the pending scores);
+//   * the row sums come out of the matrix pipe: a fifth "d block" of V^T that is 1 in its first row adds
+//     sum_k P[k][q] to an accumulator (two MFMAs per tile instead of sixteen VALU adds), and being an accumulator
+//     like O it is rescaled with O;
+//   * the next tile's K Q^T is issued before this tile's softmax (runs under it).
+// K/V staging (LDS-DMA ring of three tiles, one barrier per tile) is that of attn16_bf16_kernel.
+// TAG only gives the cross-attention instantiation its own kernel name (profiles split the two).
+static constexpr float ATT_LAG = 6.0f;
+
+// V^T fragments through the compiler's own transposed LDS read (it places the two 8-byte halves of an MFMA operand
+// in adjacent registers and counts the reads itself; the inline-asm form needed a v_mov per half)
+typedef __attribute__((address_space(3))) bf16x4 att_lds_bf16x4;
+__device__ __forceinline__ bf16x8 v_frag(const char* lds_base, int off_lo, int off_hi) {
+    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((att_lds_bf16x4*)(lds_base + off_lo));
+    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((att_lds_bf16x4*)(lds_base + off_hi));
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// eight probabilities -> one MFMA operand: four v_cvt_pk_bf16_f32
+__device__ __forceinline__ bf16x8 pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+    bf16x8 r;
+    r[0] = (bf16)a0; r[1] = (bf16)a1; r[2] = (bf16)a2; r[3] = (bf16)a3; r[4] = (bf16)a4; r[5] = (bf16)a5; r[6] = (bf16)a6; r[7] = (bf16)a7;
+    return r;
+}
+
+// fmaxf on MFMA outputs makes hipcc canonicalise each operand first (v_max_f32 x, x, x): one instruction instead
+__device__ __forceinline__ float att_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <int NW, int TAG>
+__global__ __launch_bounds__(NW * 64) void attn16v2_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                           const bf16* __restrict__ V, bf16* __restrict__ O,
+                                                           int T, int S, long ldq, long ldk, long ldv, long ldo, float scale_log2e) {
+    constexpr int TILE_B = ATT_KV * 128;
+    constexpr int BUF_B = 2 * TILE_B;
+    constexpr int PIECES = 16 / NW;
+    static_assert(NW <= 16 && 16 % NW == 0, "waves must divide the 16 DMA pieces of a tile");
+    __shared__ __attribute__((aligned(16))) char lds[3 * BUF_B];
+
+    const int t_ = threadIdx.x, lane = t_ & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t_ >> 6);
+    const int c16 = lane & 15, g = lane >> 4;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = (blockIdx.x * NW + wave) * 16;
+    const int qrow = min(q0 + c16, T - 1);
+
+    const bf16* Qb = Q + (size_t)b * T * ldq + (size_t)head * ATT_D;
+    const bf16* Kb = K + (size_t)b * S * ldk + (size_t)head * ATT_D;
+    const bf16* Vb = V + (size_t)b * S * ldv + (size_t)head * ATT_D;
+    const bf16* zeros = reinterpret_cast<const bf16*>(g_att_zero16);
+
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 raw = *reinterpret_cast<const bf16x8*>(Qb + (size_t)qrow * ldq + 32 * ks + 8 * g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (bf16)((float)raw[j] * scale_log2e);
+    }
+    // V^T "row 64": ones for the lanes that hold d = 0 of the extra block, zeros elsewhere
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)(c16 == 0 ? 1.0f : 0.0f);
+
+    // LDS-DMA sources: one running pointer per piece, advanced by 64 keys per tile (no per-tile address arithmetic);
+    // only a tile that reaches past S takes the checked form (rows beyond S read a zero line)
+    const int lr = lane >> 3, pc = lane & 7;
+    const bf16* dsrc[PIECES];
+    long dstep[PIECES];
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int pce = wave * PIECES + i;
+        const int isv = pce >> 3, row = (pce & 7) * 8 + lr;
+        const int c = pc ^ (isv ? swz_v16(row) : swz_k16(row));
+        dsrc[i] = isv ? Vb + (size_t)row * ldv + c * 8 : Kb + (size_t)row * ldk + c * 8;
+        dstep[i] = (long)ATT_KV * (isv ? ldv : ldk);
+    }
+    auto dma_tile = [&](int kt, int buf) {           // tiles are issued in order: kt = 0, 1, 2, ...
+        const bool tail = (kt + 1) * ATT_KV > S;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int pce = wave * PIECES + i;
+            const int isv = pce >> 3, rb = pce & 7;
+            const bf16* src = dsrc[i];
+            if (tail && kt * ATT_KV + rb * 8 + lr >= S) src = zeros;
+            __builtin_amdgcn_global_load_lds((att_gbl_cvoid_t*)src, (att_lds_void_t*)(lds + buf * BUF_B + isv * TILE_B + rb * 1024), 16, 0, 0);
+            dsrc[i] += dstep[i];
+        }
+    };
+    const int k_off0 = c16 * 128 + (((0 + g) ^ swz_k16(c16)) << 4);
+    const int k_off1 = c16 * 128 + (((4 + g) ^ swz_k16(c16)) << 4);
+    const int vkey = 4 * g + (c16 >> 2);
+    const int vsw = swz_v16(vkey);
+    const int vrow = vkey * 128 + 8 * (c16 & 1);
+    const int vbit = (c16 & 3) >> 1;
+    const int v_off0 = vrow + (((0 ^ vsw) + vbit) << 4), v_off1 = vrow + (((2 ^ vsw) + vbit) << 4);
+    const int v_off2 = vrow + (((4 ^ vsw) + vbit) << 4), v_off3 = vrow + (((6 ^ vsw) + vbit) << 4);
+
+    float m_ref = 0.f;                                // reference maximum of this lane's query row (base-2 exponent units)
+    auto qk_tile = [&](int buf, f32x4 (&s)[4]) {
+        const char* kb_ = lds + buf * BUF_B;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kb_ + kb * 2048 + k_off0);
+            const bf16x8 kc = *reinterpret_cast<const bf16x8*>(kb_ + kb * 2048 + k_off1);
+            f32x4 acc = {-m_ref, -m_ref, -m_ref, -m_ref};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[0], acc, 0, 0, 0);
+            s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc, qf[1], acc, 0, 0, 0);
+        }
+    };
+
+    f32x4 o[5];                                       // O^T d blocks 0..3; o[4] row 0 = running row sum
+#pragma unroll
+    for (int i = 0; i < 5; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nkt = (S + ATT_KV - 1) / ATT_KV;
+
+    dma_tile(0, 0);
+    if (nkt > 1) dma_tile(1, 1);
+    if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x4 sa[4], sb[4];                               // scores of the current / next tile, trading places every trip
+    qk_tile(0, sa);
+
+    // one trip: tile kt (scores in `s`, V in buffer cur); leaves the scores of tile kt+1 in `sn`
+    auto trip = [&](f32x4 (&s)[4], f32x4 (&sn)[4], int kt, int cur, int nb, int fb) {
+#ifndef ST_ATT_NOSYNC     // (timing experiment: no DMA, no barrier - the loop re-reads whatever the ring holds)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // own pieces of tile kt+1 have landed ...
+        __builtin_amdgcn_s_barrier();                              // ... and everyone's; tile kt-1 is dead
+        if (kt + 2 < nkt) dma_tile(kt + 2, fb);
+#endif
+        // V^T fragments of this tile [key pair-block kp][d block]: issued now, first used after the softmax
+        bf16x8 vf[2][4];
+        {
+            const char* vb = lds + cur * BUF_B + TILE_B;
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                vf[kp][0] = v_frag(vb, v_off0 + kp * 4096, v_off0 + kp * 4096 + 2048);
+                vf[kp][1] = v_frag(vb, v_off1 + kp * 4096, v_off1 + kp * 4096 + 2048);
+                vf[kp][2] = v_frag(vb, v_off2 + kp * 4096, v_off2 + kp * 4096 + 2048);
+                vf[kp][3] = v_frag(vb, v_off3 + kp * 4096, v_off3 + kp * 4096 + 2048);
+            }
+        }
+        // scores of the next tile: the matrix pipe works on them under this softmax (after the last tile the ring
+        // slot holds an old tile: computed all the same, never used)
+        qk_tile(nb, sn);
+        if ((kt + 1) * ATT_KV > S) {                               // mask the tail keys (only the last tile has any)
+            const int kbase = kt * ATT_KV + 4 * g;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kbase + 16 * kb + r >= S) s[kb][r] = -INFINITY;
+        }
+        float mx = att_max3(s[0][0], s[0][1], s[0][2]);
+        mx = att_max3(mx, s[0][3], s[1][0]);
+        mx = att_max3(mx, s[1][1], s[1][2]);
+        mx = att_max3(mx, s[1][3], s[2][0]);
+        mx = att_max3(mx, s[2][1], s[2][2]);
+        mx = att_max3(mx, s[2][3], s[3][0]);
+        mx = att_max3(mx, s[3][1], s[3][2]);
+        mx = fmaxf(mx, s[3][3]);
+        if (kt == 0 || __any(mx > ATT_LAG)) {
+            // exact path: the row maximum (over the four lanes that share the row) becomes the reference of every row
+            // that is on its first tile or has outrun the lag; everything already expressed against the old reference
+            // (O, the row sum, this tile's and the next tile's scores) moves by the same amount
+            const float rmx = xmax32(xmax16(mx));
+            const float delta = ((kt == 0 || rmx > ATT_LAG) && rmx > -INFINITY) ? rmx : 0.f;
+            const float alpha = kt == 0 ? 1.f : fast_exp2(-delta);      // (nothing to rescale on the first tile; delta may be very negative there)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[kb][r] -= delta; sn[kb][r] -= delta; }
+#pragma unroll
+            for (int db = 0; db < 5; ++db)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[db][r] *= alpha;
+            m_ref += delta;
+        }
+#ifndef ST_ATT_NOEXP      // (timing experiment: skip the exponentials)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kb][r] = fast_exp2(s[kb][r]);
+#endif
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) {
+            const bf16x8 pb = pack8(s[2 * kp][0], s[2 * kp][1], s[2 * kp][2], s[2 * kp][3],
+                                    s[2 * kp + 1][0], s[2 * kp + 1][1], s[2 * kp + 1][2], s[2 * kp + 1][3]);
+#pragma unroll
+            for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kp][db], pb, o[db], 0, 0, 0);
+            o[4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb, o[4], 0, 0, 0);
+        }
+    };
+    int cur = 0;
+    for (int kt = 0; kt < nkt; kt += 2) {
+        const int b1 = cur == 2 ? 0 : cur + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+        trip(sa, sb, kt, cur, b1, b2);
+        if (kt + 1 < nkt) trip(sb, sa, kt + 1, b1, b2, cur);
+        cur = b2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // row sum: row 0 of the extra block lives in register 0 of the lanes with g == 0
+    const float l = __shfl(o[4][0], c16, 64);
+    const float inv = 1.0f / l;
+    if (q0 + c16 < T) {
+        bf16* orow = O + (size_t)b * T * ldo + (size_t)(q0 + c16) * ldo + (size_t)head * ATT_D;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            bf16x4 a_;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a_[e] = (bf16)(o[db][e] * inv);
+            *reinterpret_cast<bf16x4*>(orow + 16 * db + 4 * g) = a_;
+        }
+    }
+}
+
+// ---- 32-row kernel, second generation (v_mfma_f32_32x32x16_bf16) -------------------------------------
+// Same softmax economy as attn16v2_kernel (pre-scaled Q, accumulators started at -m_ref, lazy reference maximum,
+// row sums from a third accumulator block fed with a V^T row of ones) on 32 query rows per wave: per row it issues
+// half the MFMAs (a 32x32x16 holds the SIMD's issue port for 8 of its 32 cycles, a 16x16x32 for 8 of its 16), half
+// the K / V fragment reads and half the LDS-DMA pieces - and at D = 64 the instruction issue of the SIMD, not the
+// matrix pipe, is what the loop runs out of (measured: tools/build_one_variant.sh experiments).
+// Pipeline, LDS images and the key split (KS) are those of attn_bf16_kernel.
+template <int NW, int KS>
+__global__ __launch_bounds__(NW * KS * 64) void attn32v2_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                                const bf16* __restrict__ V, bf16* __restrict__ O,
+                                                                int T, int S, long ldq, long ldk, long ldv, long ldo, float scale_log2e) {
+    constexpr int TILE_B = ATT_KV * 128;
+    constexpr int BUF_B = 2 * TILE_B;
+    constexpr int PIECES = 16 / NW > 0 ? 16 / NW : 1;
+    static_assert(16 % NW == 0, "waves must divide the 16 DMA pieces of a tile");
+    extern __shared__ __attribute__((aligned(16))) char lds_all[];      // KS rings of 3 tile buffers
+
+    const int t_ = threadIdx.x, lane = t_ & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(t_ >> 6);
+    const int kg = KS > 1 ? wave_all / NW : 0;
+    const int wave = wave_all - kg * NW;
+    char* lds = lds_all + kg * (3 * BUF_B);
+    const int r32 = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = (blockIdx.x * NW + wave) * 32;
+    const int qrow = min(q0 + r32, T - 1);
+
+    const bf16* Qb = Q + (size_t)b * T * ldq + (size_t)head * ATT_D;
+    const bf16* Kb = K + (size_t)b * S * ldk + (size_t)head * ATT_D;
+    const bf16* Vb = V + (size_t)b * S * ldv + (size_t)head * ATT_D;
+    const bf16* zeros = reinterpret_cast<const bf16*>(g_att_zero16);
+
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 raw = *reinterpret_cast<const bf16x8*>(Qb + (size_t)qrow * ldq + 16 * ks + 8 * h);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (bf16)((float)raw[j] * scale_log2e);
+    }
+    bf16x8 ones;                                      // V^T "row 64" of the row-sum block: 1 for the lanes that hold its d = 0
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)(r32 == 0 ? 1.0f : 0.0f);
+
+    const int nkt_all = (S + ATT_KV - 1) / ATT_KV;
+    const int nkt = (nkt_all + KS - 1) / KS;
+    const int kt0 = kg * nkt;
+
+    // LDS-DMA sources: one running pointer per piece, advanced by 64 keys per tile; only a tile that reaches past S
+    // takes the checked form (rows beyond S read a zero line)
+    const int lr = lane >> 3, pc = lane & 7;
+    const bf16* dsrc[PIECES];
+    long dstep[PIECES];
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int pce = wave * PIECES + i;
+        const int isv = pce >> 3, row = (pce & 7) * 8 + lr;
+        const int c = pc ^ (isv ? swz_v(row) : swz_k(row));
+        const size_t key0 = (size_t)kt0 * ATT_KV + row;
+        dsrc[i] = isv ? Vb + key0 * ldv + c * 8 : Kb + key0 * ldk + c * 8;
+        dstep[i] = (long)ATT_KV * (isv ? ldv : ldk);
+    }
+    auto dma_tile = [&](int kt, int buf) {           // tiles are issued in order: kt = 0, 1, 2, ...
+        const bool tail = (kt0 + kt + 1) * ATT_KV > S;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int pce = wave * PIECES + i;
+            const int isv = pce >> 3, rb = pce & 7;
+            const bf16* src = dsrc[i];
+            if (tail && (kt0 + kt) * ATT_KV + rb * 8 + lr >= S) src = zeros;
+            __builtin_amdgcn_global_load_lds((att_gbl_cvoid_t*)src, (att_lds_void_t*)(lds + buf * BUF_B + isv * TILE_B + rb * 1024), 16, 0, 0);
+            dsrc[i] += dstep[i];
+        }
+    };
+    // lane-constant offsets of the transposed V reads (d block 0 / 1); k-step s_ adds 2048, the second key half 1024
+    int v_base0, v_base1;
+    {
+        const int q4 = (lane & 15) >> 2;
+        const int key = 4 * h + q4;
+        const int ch0 = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+        const int row = key * 128 + 8 * (lane & 1);
+        v_base0 = row + ((ch0 ^ swz_v(key)) << 4);
+        v_base1 = row + (((ch0 + 4) ^ swz_v(key)) << 4);
+    }
+    float m_ref = 0.f;
+    auto qk_tile = [&](int buf, f32x16& s0, f32x16& s1) {
+        const char* kb = lds + buf * BUF_B;
+        bf16x8 kf0[4], kf1[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = 2 * ks + h;
+            const int ra = r32, rb_ = 32 + r32;
+            kf0[ks] = *reinterpret_cast<const bf16x8*>(kb + ra * 128 + ((c ^ swz_k(ra)) << 4));
+            kf1[ks] = *reinterpret_cast<const bf16x8*>(kb + rb_ * 128 + ((c ^ swz_k(rb_)) << 4));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = -m_ref; s1[r] = -m_ref; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], s1, 0, 0, 0);
+        }
+    };
+
+    f32x16 o0 = {0}, o1 = {0}, o2 = {0};              // O^T rows d 0..31, 32..63; o2 row 0 = running row sum
+    dma_tile(0, 0);
+    if (nkt > 1) dma_tile(1, 1);
+    if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x16 sa0, sa1, sb0, sb1;                        // scores of the current / next tile, trading places every trip
+    qk_tile(0, sa0, sa1);
+
+    auto trip = [&](f32x16& s0, f32x16& s1, f32x16& n0, f32x16& n1, int kt, int cur, int nb, int fb) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nkt) dma_tile(kt + 2, fb);
+        // V^T fragments of this tile [k-step][d block]: issued now, first used after the softmax
+        bf16x8 vf[4][2];
+        {
+            const char* vb = lds + cur * BUF_B + TILE_B;
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                vf[s_][0] = v_frag(vb, v_base0 + s_ * 2048, v_base0 + s_ * 2048 + 1024);
+                vf[s_][1] = v_frag(vb, v_base1 + s_ * 2048, v_base1 + s_ * 2048 + 1024);
+            }
+        }
+        qk_tile(nb, n0, n1);                                       // next tile's scores (after the last tile: computed on an old slot, unused)
+        if ((kt0 + kt + 1) * ATT_KV > S) {
+            const int kbase = (kt0 + kt) * ATT_KV + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kbase + (r & 3) + 8 * (r >> 2);
+                if (key >= S) s0[r] = -INFINITY;
+                if (key + 32 >= S) s1[r] = -INFINITY;
+            }
+        }
+        float mx = att_max3(s0[0], s0[1], s0[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = att_max3(mx, s0[r], s0[r + 1]);
+        mx = att_max3(mx, s0[15], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 15; r += 2) mx = att_max3(mx, s1[r], s1[r + 1]);
+        mx = fmaxf(mx, s1[15]);
+        if (kt == 0 || __any(mx > ATT_LAG)) {
+            // exact path (first tile, or a row outran the lag): see attn16v2_kernel
+            const float rmx = xmax32(mx);
+            const float delta = ((kt == 0 || rmx > ATT_LAG) && rmx > -INFINITY) ? rmx : 0.f;
+            const float alpha = kt == 0 ? 1.f : fast_exp2(-delta);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s0[r] -= delta; s1[r] -= delta; n0[r] -= delta; n1[r] -= delta;
+                o0[r] *= alpha; o1[r] *= alpha; o2[r] *= alpha;
+            }
+            m_ref += delta;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = fast_exp2(s0[r]); s1[r] = fast_exp2(s1[r]); }
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            const f32x16& sx = s_ < 2 ? s0 : s1;
+            const int e = 8 * (s_ & 1);
+            const bf16x8 pb = pack8(sx[e], sx[e + 1], sx[e + 2], sx[e + 3], sx[e + 4], sx[e + 5], sx[e + 6], sx[e + 7]);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s_][0], pb, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s_][1], pb, o1, 0, 0, 0);
+            o2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb, o2, 0, 0, 0);
+        }
+    };
+    int cur = 0;
+    for (int kt = 0; kt < nkt; kt += 2) {
+        const int b1 = cur == 2 ? 0 : cur + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+        trip(sa0, sa1, sb0, sb1, kt, cur, b1, b2);
+        if (kt + 1 < nkt) trip(sb0, sb1, sa0, sa1, kt + 1, b1, b2, cur);
+        cur = b2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // row sum of query r32: register 0 of the lanes with h == 0 (row 0 of the third block)
+    float l = __shfl(o2[0], r32, 64);
+    if constexpr (KS > 1) {
+        // merge the key groups: group 1 parks (O, m_ref, l) in LDS (the rings are dead), group 0 folds them in
+        __syncthreads();
+        float* park = reinterpret_cast<float*>(lds_all) + (size_t)wave * (34 * 64) + lane;
+        if (kg == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { park[r * 64] = o0[r]; park[(16 + r) * 64] = o1[r]; }
+            park[32 * 64] = m_ref; park[33 * 64] = l;
+        }
+        __syncthreads();
+        if (kg == 1) return;
+        const float m2 = park[32 * 64], l2 = park[33 * 64];
+        const float m_new = fmaxf(m_ref, m2);
+        const float a1 = fast_exp2(m_ref - m_new), a2 = fast_exp2(m2 - m_new);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] = o0[r] * a1 + park[r * 64] * a2;
+            o1[r] = o1[r] * a1 + park[(16 + r) * 64] * a2;
+        }
+        l = l * a1 + l2 * a2;
+    }
+    const float inv = 1.0f / l;
+    if (q0 + r32 < T) {
+        bf16* orow = O + (size_t)b * T * ldo + (size_t)(q0 + r32) * ldo + (size_t)head * ATT_D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 a_, c_;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a_[e] = (bf16)(o0[4 * g + e] * inv); c_[e] = (bf16)(o1[4 * g + e] * inv); }
+            *reinterpret_cast<bf16x4*>(orow + 8 * g + 4 * h) = a_;
+            *reinterpret_cast<bf16x4*>(orow + 32 + 8 * g + 4 * h) = c_;
+        }
+    }
+}
+
 // ---- fp32 strict kernel: thread = one query row, keys in tiles of 32 via LDS ----
 __global__ __launch_bounds__(128) void attn_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                        const float* __restrict__ V, float* __restrict__ O, int T, int S,
@@ -589,6 +1030,17 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
         // measured (tools/op_bench.py): 16-row waves win for the 77-key text context (more waves for a
         // two-tile loop) and for the 4096-token level (2560 instead of 1280 waves)
         const int rows16 = rows16_env >= 0 ? rows16_env : ((S <= 256 || (T >= 4096 && S >= 4096)) ? 4 : 0);
+        static const int v2 = att_dev_env_int("ST_ATT_V2", 1);
+        if (rows16 && v2) {
+            // second-generation 16-row kernel; the text-context launches get their own instantiation (kernel name)
+            const bool cross = S <= 256;
+#define ST_ATT16V2(NW_, TAG_) hipLaunchKernelGGL((attn16v2_kernel<NW_, TAG_>), dim3(cdiv(T, 16 * NW_), H, B), dim3(64 * NW_), 0, st, (const bf16*)q, \
+                                                 (const bf16*)k, (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c)
+            if (rows16 == 8) { if (cross) ST_ATT16V2(8, 1); else ST_ATT16V2(8, 0); }
+            else { if (cross) ST_ATT16V2(4, 1); else ST_ATT16V2(4, 0); }
+#undef ST_ATT16V2
+            return st_check_launch("attention");
+        }
         if (rows16 == 16) {
             hipLaunchKernelGGL(attn16_bf16_kernel<16>, dim3(cdiv(T, 256), H, B), dim3(1024), 0, st, (const bf16*)q, (const bf16*)k,
                                (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c);
@@ -607,6 +1059,22 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
         // run two key groups per block instead - twice the waves, half the tiles each, one LDS merge
         static const int force_ks = att_dev_env_int("ST_ATT_KS", -1);
         const bool split = force_ks >= 0 ? force_ks == 2 : (nw == 4 && (long)cdiv(T, 128) * H * B <= 256 && S >= 512);
+        static const int v32 = att_dev_env_int("ST_ATT_32V2", 1);
+        if (v32) {
+#define ST_ATT32V2(NW_, KS_, GX_)                                                                                                   \
+    do {                                                                                                                           \
+        auto kfn2 = attn32v2_kernel<NW_, KS_>;                                                                                      \
+        static bool once2 = (hipFuncSetAttribute((const void*)kfn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KS_ * RING)), true); \
+        (void)once2;                                                                                                               \
+        hipLaunchKernelGGL(kfn2, dim3(GX_, H, B), dim3(64 * NW_ * KS_), KS_ * RING, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, \
+                           (bf16*)out, T, S, ldq, ldk, ldv, ldo, c);                                                                \
+    } while (0)
+            if (split) ST_ATT32V2(4, 2, cdiv(T, 128));
+            else if (nw == 8) ST_ATT32V2(8, 1, cdiv(T, 256));
+            else ST_ATT32V2(4, 1, cdiv(T, 128));
+#undef ST_ATT32V2
+            return st_check_launch("attention");
+        }
         if (split) {
             auto kfn = attn_bf16_kernel<4, 2>;
             static bool once = (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * RING)), true);

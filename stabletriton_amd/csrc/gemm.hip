@@ -235,7 +235,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n,
 }
 
 // lane (r16, q) holds rows m = .. + r16, columns n = .. + 4q .. 4q+3 of every 16x16 tile.
-template <typename T, int TM, int TN, int WTM, int WTN, bool GEGLU, int WGM_ = 0, int WGN_ = 0>
+template <typename T, int TM, int TN, int WTM, int WTN, bool GEGLU, int WGM_ = 0, int WGN_ = 0, bool ALIGNED_N = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
                                               int r16, int q, int split = 0, const float* row_mean = nullptr,
                                               const float* row_rstd = nullptr, char* lds_scratch = nullptr, int tile_n = 0,
@@ -245,7 +245,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
     for (int i = 0; i < TM; ++i) { rs1[i] = 0.f; rs2[i] = 0.f; }
     constexpr int TNO = GEGLU ? TN / 2 : TN;
     constexpr int WTNO = GEGLU ? WTN / 2 : WTN;
-    if ((p.N & 3) != 0) {
+    if (!ALIGNED_N && (p.N & 3) != 0) {
         // ragged N: per-tile loads, arithmetic and element stores
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -279,7 +279,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
         const T* __restrict__ bias = (const T*)p.bias;
         unsigned int touch_next = 0;                       // destination of the next-weights touches (kept live to the end)
         // wide wave tiles take the load + arithmetic passes in column chunks of JC tiles (registers)
-        constexpr int JC = TNO <= 5 ? TNO : 5;
+        constexpr int JC = TM >= 8 ? 1 : (TNO <= 5 ? TNO : 5);      // (tall wave tiles: one column of tiles per pass)
         auto chunk = [&](auto jc) {
             constexpr int J0 = decltype(jc)::value;
             constexpr int NJ = (J0 + JC <= TNO) ? JC : TNO - J0;
@@ -1088,6 +1088,289 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
 }
 
 // =============================================================================
+// gemm8p: 256 x 256 x 64 tiles for the large Linear problems (the projections at batch >= 2, the GEGLU
+// projection at any batch).  A 128 x 128 tile needs (128+128)*128 B of LDS fill per 0.21 us of MFMA work
+// - more than the ~130 GB/s one CU pulls from its L2 - a 256 x 256 tile half of that.
+//   * 8 waves = 2 (rows) x 4 (columns), wave tile 128 x 64 = four quadrants of 64 x 32; a K tile is four
+//     phases, one quadrant (16 MFMAs 16x16x32) each: (A0,B0) (A0,B1) (A1,B1) (A1,B0) with Ah / Bh the
+//     64-row / 32-column halves of the wave tile.  A phase reads only the fragments it is the first to
+//     use (A0+B0, B1, A1, nothing), so a K tile costs 24 ds_read_b128 per wave for 64 MFMAs.
+//   * The two wave rows run half a phase apart (waves 4-7 pass one extra barrier first): while one row's
+//     waves multiply, the other row's waves read fragments and issue DMAs, on the same SIMDs - a software
+//     ping-pong with two raw barriers per phase and no wave ever doing both at once.
+//   * LDS: two K tiles, each as four 16-KiB half tiles (A0, A1, B0, B1: the rows all eight waves read in
+//     the same phase), filled by LDS-DMA one half tile per phase (two 1-KiB pieces per wave), swizzled on
+//     the source side as in gemm_dma_kernel.  A half tile is refilled two phases after its last read and
+//     waited for (counted vmcnt, never 0) one phase before its first read, which leaves four half tiles
+//     (64 KiB per CU) in flight at all times.
+// Epilogue, LayerNorm folding, row statistics, next-weights touches and the XCD-aware tile order are the
+// ones of gemm_dma_kernel.  No K split (the shapes that come here have >= 160 tiles).
+// =============================================================================
+template <bool GEGLU, bool LNF>
+__global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
+    typedef bf16 T;
+    constexpr int BM = 256, BN = 256, KB = 64, WGM = 2, WGN = 4, NW = 8;
+    constexpr int WTM = 128, WTN = 64, TM = 8, TN = 4;
+    constexpr int HALF_B = 128 * 128;                 // bytes of one half tile (128 rows x 128 B)
+    constexpr int TILE_B = 4 * HALF_B;                // A0 A1 B0 B1
+    constexpr int BNO = GEGLU ? BN / 2 : BN;
+    typedef typename Mma<T>::Frag Frag;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* const lnrows = lds + 2 * TILE_B;            // LayerNorm (mean, rstd) per row
+    char* const dump = lnrows + BM * 8;               // target of the dummy DMAs past the last K tile
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tiles_m = p.M / BM;
+    const int nblk = gridDim.x - p.helper_blocks, bid = blockIdx.x;
+    if (bid >= nblk) {                               // helper block on an otherwise idle CU: the next launch's weights
+        unsigned int sink = 0;
+        touch_next_weights(p, sink, true);
+        retire_touches(sink);
+        return;
+    }
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
+    const int tw = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    int tile_m, tile_n;
+    {
+        const int tiles_n_all = nblk / tiles_m;
+        const int per_panel = p.panel_h * tiles_n_all;
+        const int pn = tw / per_panel, rem = tw - pn * per_panel;
+        const int rows = min(p.panel_h, tiles_m - pn * p.panel_h);
+        tile_n = rem / rows;
+        tile_m = pn * p.panel_h + (rem - tile_n * rows);
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BNO;
+    const T* __restrict__ Ap = (const T*)p.A;
+    const T* __restrict__ Wp = (const T*)p.W;
+    const T* zeros = reinterpret_cast<const T*>(g_zero16);
+
+    // ---- per-lane DMA sources: piece e (0, 1) of this wave inside a half tile covers rows idx = (2*wave+e)*8 + lr
+    const int lr = lane >> 3;
+    const int lc = (lane & 7) ^ lr;                  // logical 16-byte chunk this lane fetches (source-side swizzle)
+    const T* a_src[2];
+    const T* b_src[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int idx = (2 * wave + e) * 8 + lr;
+        a_src[e] = Ap + (size_t)(m0 + (idx >> 6) * 128 + (idx & 63)) * p.lda + lc * 8;              // half h adds 64 rows
+        b_src[e] = GEGLU ? Wp + (size_t)(n0 + idx) * p.K + lc * 8                                    // half 0 = value rows, half 1 (+N rows) = gate rows
+                         : Wp + (size_t)(n0 + (idx >> 5) * 64 + (idx & 31)) * p.K + lc * 8;          // half h adds 32 rows
+    }
+    const size_t a_half = (size_t)64 * p.lda, b_half = GEGLU ? (size_t)p.N * p.K : (size_t)32 * p.K;
+    const int nk = p.K / KB;
+
+    // region r of a K tile: 0 = A0, 1 = A1, 2 = B0, 3 = B1.  `kt >= nk` issues the two dummy pieces.
+    auto issue_half = [&](int kt, int region) {
+        char* dst = lds + (kt & 1) * TILE_B + region * HALF_B + (2 * wave) * 1024;
+        const bool live = kt < nk;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const T* src = region < 2 ? a_src[e] + (region & 1) * a_half : b_src[e] + (region & 1) * b_half;
+            src = live ? src + (size_t)kt * KB : zeros;
+            dma16<0>(src, live ? dst + e * 1024 : dump);
+        }
+    };
+
+    // touch the epilogue's operands now (they are first read after the K loop, where a miss would be exposed)
+    unsigned int touch_sink = 0;
+    {
+        auto touch_at = [&](const char* a) {
+            a = (const char*)((uintptr_t)a & ~(uintptr_t)3);
+            asm volatile("global_load_dword %0, %1, off" : "+v"(touch_sink) : "v"(a) : "memory");
+        };
+        auto touch = [&](const void* base, long byte_off, int nbytes) {
+            for (int o = t * 128; o < nbytes; o += 512 * 128) touch_at((const char*)base + byte_off + o);
+        };
+        if (p.epi & ST_EPI_BIAS) {
+            touch(p.bias, (long)n0 * 2, BNO * 2);
+            if (GEGLU) touch(p.bias, ((long)p.N + n0) * 2, BNO * 2);
+        }
+        if (LNF) {
+            touch(p.ln_c, (long)n0 * 4, BNO * 4); touch(p.ln_d, (long)n0 * 4, BNO * 4);
+            if (GEGLU) { touch(p.ln_c, ((long)p.N + n0) * 4, BNO * 4); touch(p.ln_d, ((long)p.N + n0) * 4, BNO * 4); }
+        }
+        if (p.epi & ST_EPI_RESIDUAL) {
+            constexpr int lines = BNO * 2 / 128;
+            for (int o = t; o < BM * lines; o += 512) {
+                const int r = o / lines, l = o - r * lines;
+                touch_at((const char*)p.residual + ((size_t)(m0 + r) * p.ldr + n0) * 2 + l * 128);
+            }
+        }
+    }
+    // LayerNorm-folded GEMM: row statistics from the producer's partials (two threads per row)
+    constexpr int LN_UNROLL = 8;
+    float2 ln_part[LN_UNROLL];
+    if constexpr (LNF) {
+        const float2* st2 = reinterpret_cast<const float2*>(p.ln_stats);
+        const int row = t >> 1, part = t & 1;
+#pragma unroll
+        for (int k_ = 0; k_ < LN_UNROLL; ++k_) {
+            const int c = part + k_ * 2;
+            ln_part[k_] = st2[(size_t)(m0 + row) * p.ln_chunks + (c < p.ln_chunks ? c : 0)];
+        }
+    }
+    // prologue: K tile 0 whole and A0, B0 of K tile 1 (the loop issues B1(1), A1(1), A0(2), B0(2), B1(2), ...)
+    issue_half(0, 0); issue_half(0, 2); issue_half(0, 3); issue_half(0, 1); issue_half(1, 0); issue_half(1, 2);
+    if constexpr (LNF) {
+        const float2* st2 = reinterpret_cast<const float2*>(p.ln_stats);
+        const int row = t >> 1, part = t & 1;
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k_ = 0; k_ < LN_UNROLL; ++k_) {
+            const bool ok = part + k_ * 2 < p.ln_chunks;
+            a1 += ok ? ln_part[k_].x : 0.f; a2 += ok ? ln_part[k_].y : 0.f;
+        }
+        for (int c = part + LN_UNROLL * 2; c < p.ln_chunks; c += 2) { const float2 v = st2[(size_t)(m0 + row) * p.ln_chunks + c]; a1 += v.x; a2 += v.y; }
+        a1 += __shfl_xor(a1, 1, 64); a2 += __shfl_xor(a2, 1, 64);
+        const float mean = a1 / (float)p.K;
+        const float rstd = rsqrtf(fmaxf(a2 / (float)p.K - mean * mean, 0.f) + p.ln_eps);
+        if (part == 0) reinterpret_cast<float2*>(lnrows)[row] = make_float2(mean, rstd);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    wait_vmcnt<8>();                                 // A0(0), B0(0) have landed (and every load older than the DMAs)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::"v"(touch_sink));
+    if (wm == 1) __builtin_amdgcn_s_barrier();       // the second wave row runs one barrier (half a phase) behind the first
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int r16 = lane & 15, q = lane >> 4;
+    // fragment addresses: LDS row = half*128 + w*64 (A) / w*32 (B) + frag*16 + r16, chunk 4*kk + q, swizzled by row & 7 = r16 & 7
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int sw = ((4 * kk + q) ^ (r16 & 7)) << 4;
+        a_off[kk] = (wm * 64 + r16) * 128 + sw;
+        b_off[kk] = 2 * HALF_B + (wn * 32 + r16) * 128 + sw;
+    }
+    Frag fa[4][2], fb0[2][2], fb1[2][2];              // A half in use, B0 (kept for the fourth phase), B1
+    auto read_a = [&](const char* tile, int h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fa[i][kk] = *reinterpret_cast<const Frag*>(tile + h * HALF_B + i * 2048 + a_off[kk]);
+    };
+    auto read_b = [&](const char* tile, int h, Frag (&fb)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fb[j][kk] = *reinterpret_cast<const Frag*>(tile + h * HALF_B + j * 2048 + b_off[kk]);
+    };
+    auto quadrant = [&](auto mh_, auto nh_, Frag (&fb)[2][2]) {
+        constexpr int mh = decltype(mh_)::value, nh = decltype(nh_)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) Mma<T>::run(acc[mh * 4 + i][nh * 2 + j], fb[j][kk], fa[i][kk]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // one phase: [fragment reads] [one half tile of DMA] [counted wait] barrier [16 MFMAs] barrier
+    // after the issue of phase ph the eight DMAs of phases ph-3 .. ph may stay in flight: the half tile issued in
+    // phase ph-4 has landed for this wave, and for everybody once both wave rows have passed their next barrier
+#define ST_PHASE_SYNC()                                   \
+    __builtin_amdgcn_sched_barrier(0);                    \
+    wait_vmcnt<8>();                                      \
+    __builtin_amdgcn_s_barrier();                         \
+    __builtin_amdgcn_sched_barrier(0)
+#define ST_PHASE_END()                                    \
+    __builtin_amdgcn_sched_barrier(0);                    \
+    __builtin_amdgcn_s_barrier();                         \
+    __builtin_amdgcn_sched_barrier(0)
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* tile = lds + (kt & 1) * TILE_B;
+        // phase 0: (A0, B0); refill B1 of tile kt+1 (last read in phase 1 of tile kt-1)
+        read_a(tile, 0); read_b(tile, 0, fb0);
+        issue_half(kt + 1, 3);
+        ST_PHASE_SYNC();
+        quadrant(I0{}, I0{}, fb0);
+        ST_PHASE_END();
+        // phase 1: (A0, B1); refill A1 of tile kt+1 (last read in phase 2 of tile kt-1)
+        read_b(tile, 1, fb1);
+        issue_half(kt + 1, 1);
+        ST_PHASE_SYNC();
+        quadrant(I0{}, I1{}, fb1);
+        ST_PHASE_END();
+        // phase 2: (A1, B1); refill A0 of tile kt+2 (last read in phase 0 of this tile)
+        read_a(tile, 1);
+        issue_half(kt + 2, 0);
+        ST_PHASE_SYNC();
+        quadrant(I1{}, I1{}, fb1);
+        ST_PHASE_END();
+        // phase 3: (A1, B0) from registers; refill B0 of tile kt+2 (last read in phase 0 of this tile)
+        issue_half(kt + 2, 2);
+        ST_PHASE_SYNC();
+        quadrant(I1{}, I0{}, fb0);
+        ST_PHASE_END();
+    }
+#undef ST_PHASE_SYNC
+#undef ST_PHASE_END
+    if (wm == 0) __builtin_amdgcn_s_barrier();       // barrier counts of the two wave rows are equal again
+    wait_vmcnt<0>();                                  // no LDS-DMA may outlive the workgroup's LDS allocation
+    __builtin_amdgcn_s_barrier();
+    if constexpr (LNF) {
+        float mean[TM], rstd[TM];
+        const float2* lnst = reinterpret_cast<const float2*>(lnrows);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float2 v = lnst[wm * WTM + i * 16 + r16];
+            mean[i] = v.x; rstd[i] = v.y;
+        }
+        gemm_epilogue<T, TM, TN, WTM, WTN, GEGLU, 0, 0, true>(p, acc, m0, n0, wm, wn, r16, q, 0, mean, rstd);
+    } else {
+        gemm_epilogue<T, TM, TN, WTM, WTN, GEGLU, WGM, WGN, true>(p, acc, m0, n0, wm, wn, r16, q, 0, nullptr, nullptr, lds, tile_n);
+    }
+}
+
+static bool gemm8p_applies(const GemmArgs& a) {
+    const long n_rows = (a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N;
+    return a.M % 256 == 0 && n_rows % 256 == 0 && a.K % 64 == 0 && a.K >= 256 && a.N % 4 == 0 &&
+           !(a.epi & ST_EPI_ROWBIAS) && (!a.row_stats || !(a.epi & ST_EPI_GEGLU));
+}
+
+template <bool GEGLU, bool LNF>
+static void gemm8p_go(const GemmArgs& a, hipStream_t st) {
+    constexpr size_t lds = 2 * 4 * 128 * 128 + 256 * 8 + 1024;
+    auto kfn = gemm8p_kernel<GEGLU, LNF>;
+    static bool once = (allow_big_lds(kfn, lds), true);
+    (void)once;
+    GemmArgs b = a;
+    const int tiles_m = a.M / 256, tiles_n = (int)(((a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N) / 256);
+    {   // XCD partition of the tile order: bytes from beyond L2 ~ A * (8 / panels) + W * panels
+        const double abytes = (double)a.M * a.K, wbytes = (double)tiles_n * 256 * a.K;
+        int best_p = 1;
+        double best = 1e300;
+        for (int pm = 1; pm <= 8 && pm <= tiles_m; pm *= 2) {
+            const double c = abytes * (8.0 / pm) + wbytes * pm;
+            if (c < best) { best = c; best_p = pm; }
+        }
+        b.panel_h = cdiv(tiles_m, best_p);
+    }
+    const int main_blocks = tiles_m * tiles_n;
+    b.splitk = 1;
+    b.helper_blocks = (b.next_w && main_blocks <= 208) ? (256 - main_blocks > 96 ? 96 : 256 - main_blocks) : 0;
+    b.stats_chunks = tiles_n;
+    if (a.stats_chunks_out) *a.stats_chunks_out = a.row_stats ? b.stats_chunks : 0;
+    hipLaunchKernelGGL(kfn, dim3(main_blocks + b.helper_blocks), dim3(512), lds, st, b);
+}
+
+static void gemm8p_launch(const GemmArgs& a, hipStream_t st) {
+    const bool geglu = a.epi & ST_EPI_GEGLU;
+    if (a.ln_c) { if (geglu) gemm8p_go<true, true>(a, st); else gemm8p_go<false, true>(a, st); }
+    else { if (geglu) gemm8p_go<true, false>(a, st); else gemm8p_go<false, false>(a, st); }
+}
+
+// =============================================================================
 // conv3x3, stride 1, pad 1, with the input patch resident in LDS ("halo" loop).
 // The K loop runs channel-slice-major: for every 64 input channels the (TH+2) x (W+2)
 // pixel patch that the block's TH full image rows need is staged ONCE (zero padding
@@ -1358,7 +1641,7 @@ static void launch_dma(const GemmArgs& a, hipStream_t st) {
 // overrides the heuristic for A/B runs.
 enum { CFG_64x64_S4 = 0, CFG_64x64_S8 = 1, CFG_64x64_S4_U2 = 2, CFG_128x64_S4 = 3, CFG_128x64_S3_U2 = 4,
        CFG_128x128_S3 = 5, CFG_64x64_S3 = 6, CFG_64x64_W8 = 7, CFG_128x64_W8 = 8, CFG_128x128_W8 = 9,
-       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_128x320_W8 = 23, CFG_128x256_W8 = 24, CFG_64x320_W8 = 25, CFG_64x80_W4 = 26, CFG_128x80_W8 = 27, CFG_128x160_W8 = 28, CFG_COUNT };
+       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_128x320_W8 = 23, CFG_128x256_W8 = 24, CFG_64x320_W8 = 25, CFG_64x80_W4 = 26, CFG_128x80_W8 = 27, CFG_128x160_W8 = 28, CFG_COUNT, CFG_256x256_8P = 100 };
 
 static int cfg_bn(int cfg) {
     switch (cfg) {
@@ -1418,7 +1701,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
         struct Cand { int cfg, bm, bn; double trip_us; };
         static const Cand cands[] = {{CFG_128x128_W8, 128, 128, 0.53}, {CFG_64x128_W8, 64, 128, 0.34}, {CFG_128x64_W8, 128, 64, 0.32},
                                      {CFG_64x64_W8, 64, 64, 0.19}, {CFG_128x320_W8, 128, 320, 1.38}, {CFG_64x320_W8, 64, 320, 0.64},
-                                     {CFG_256x128_W8, 256, 128, 0.72}, {CFG_128x80_W8, 128, 80, 0.37}};
+                                     {CFG_256x128_W8, 256, 128, 0.72}, {CFG_128x80_W8, 128, 80, 0.37}, {CFG_128x160_W8, 128, 160, 0.66}};
         static const int sks[] = {1, 2, 3, 4, 6, 8};
         static const int force_sk = dev_env_int("ST_GEMM_SPLITK", -1);     // 0/1: never split
         const int nk = a.K / KB;
@@ -1427,7 +1710,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
         int cfg = CFG_64x64_W8, sk = 1;
         double best = 1e30;
         for (const Cand& c : cands) {
-            if ((a.epi & ST_EPI_GEGLU) && (c.cfg == CFG_64x320_W8 || c.bn == 80)) continue;      // odd n-tiles per wave: no value/gate pairing
+            if ((a.epi & ST_EPI_GEGLU) && (c.cfg == CFG_64x320_W8 || c.bn == 80 || c.bn == 160)) continue;      // odd n-tiles per wave: no value/gate pairing
             const long nt = tiles(c.bm, c.bn);
             const double trip = c.trip_us * (CONV ? 1.6 : 1.0);
             for (int k_ : sks) {
@@ -1437,6 +1720,16 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
                 const double rounds = (double)((nt * k_ + 255) / 256);
                 const double cost = rounds * (cdiv(nk, k_) * trip + 3.0) + (k_ > 1 ? 2.1 + 0.4 * slab_mb : 0.0);
                 if (cost < best) { best = cost; cfg = c.cfg; sk = k_; }
+            }
+        }
+        if constexpr (!CONV) {
+            // the 256 x 256 eight-phase kernel: no K split, whole rounds of 256 blocks
+            if (gemm8p_applies(a)) {
+                const long nt = tiles(256, 256);
+                const double rounds = (double)((nt + 255) / 256);
+                const double cost = rounds * (nk * 1.65 + 4.0);      // a 256 x 256 x 64 step is MFMA-paced: ~1.6 us at the clock the chip holds
+                const int f = forced_cfg();
+                if ((cost < best && f < 0) || f == CFG_256x256_8P) { gemm8p_launch(a, st); return st_check_launch(who); }
             }
         }
         GemmArgs b = a;

@@ -166,6 +166,25 @@ def test_attention_peaked_softmax(gpu):
         assert_close(out, ref, dtype, "attention peaked")
 
 
+@pytest.mark.parametrize("T,S", [(64, 320), (48, 4096), (16, 77)])
+def test_attention_lazy_reference_maximum(gpu, T, S):
+    """The bf16 16-row kernel keeps a row's reference maximum until a tile outruns it by 2^6 (attention.hip ATT_LAG):
+    exercise rows whose maximum grows by less than the lag, by more (the exact path), late, and in the masked last
+    tile; rows whose first tile holds only very negative scores; rows with very large scores."""
+    H = 2
+    q, k, v = rnd("attl.q", (1, T, 128)), rnd("attl.k", (1, S, 128)), rnd("attl.v", (1, S, 128))
+    last = S - 1
+    k[:, 70 % S] = q[:, 1] * 1.5            # second tile (where there is one), growth below the lag
+    k[:, last] = q[:, 2] * 8.0              # last key (masked tile when S % 64 != 0), far above the lag
+    k[:, S // 2] = q[:, 3] * 3.0
+    k[:, :64] = k[:, :64] - q[:, 4:5] * 4.0 * (torch.arange(64)[None, :, None] >= 0)      # row 4: first tile strongly negative
+    q[:, 5] = q[:, 5] * 12.0                # row 5: scores of magnitude ~100
+    dtype = torch.bfloat16
+    ref = orc.attention_core(rounded(q, dtype), rounded(k, dtype), rounded(v, dtype), H)
+    out = ops.attention(q.to(gpu, dtype), k.to(gpu, dtype), v.to(gpu, dtype), H, 0.125)
+    assert_close(out, ref, dtype, "attention lazy maximum")
+
+
 CONVS = [  # N, Cin, H, W, Cout, k, stride, pad, upsample
     (1, 320, 32, 32, 320, 3, 1, 1, False), (2, 64, 16, 16, 128, 3, 1, 1, False), (1, 640, 32, 32, 640, 3, 2, 1, False),
     (1, 960, 16, 16, 320, 1, 1, 0, False), (1, 128, 16, 16, 128, 3, 1, 1, True), (1, 4, 32, 32, 320, 3, 1, 1, False),
