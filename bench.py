@@ -29,9 +29,10 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (guide: ~2.5 PF)
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
-BOUND = {"linear": "mfma", "conv2d": "mfma", "attention_self": "mfma", "attention_cross": "hbm",
+BOUND = {"linear": "mfma", "linear_fp8": "mfma", "quantize_fp8": "hbm", "conv2d": "mfma", "attention_self": "mfma", "attention_cross": "hbm",
          "group_norm": "hbm", "layer_norm": "hbm", "geglu": "hbm"}
-KERNEL = {"linear": "gemm_dma_kernel / gemm8p_kernel <bf16, CONV=false>", "conv2d": "conv_halo_kernel / gemm_dma_kernel<bf16, CONV=true>",
+KERNEL = {"linear_fp8": "gemm_dma_kernel<f8, CONV=false>", "quantize_fp8": "quant_fp8_kernel",
+          "linear": "gemm_dma_kernel / gemm8p_kernel <bf16, CONV=false>", "conv2d": "conv_halo_kernel / gemm_dma_kernel<bf16, CONV=true>",
           "attention_self": "attn_bf16_kernel / attn16_bf16_kernel", "attention_cross": "attn16_bf16_kernel",
           "group_norm": "gn_stats_nhwc+gn_finalize+gn_apply_nhwc", "layer_norm": "ln_kernel", "geglu": "geglu_kernel"}
 
@@ -44,6 +45,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--latent", type=int, default=128)
     ap.add_argument("--mode", choices=["auto", "loop", "step", "eager"], default="auto")
+    ap.add_argument("--fp8", action="store_true", help="transformer-block projections on the fp8 matrix pipe (BASELINE config #5 mode; "
+                                                       "a separate line with dtype fp8, never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-census", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a same-device rehearsal)")
@@ -197,6 +200,7 @@ def roofline_of(name, f, boundary_ms):
     ms = f["ms"] + f["launches"] * boundary_ms
     sec = ms * 1e-3
     if BOUND[name] == "mfma":
+        # (the non-scaled fp8 MFMA runs at the bf16 rate: same peak)
         ach, peak, unit = f["flops"] / sec / 1e12, PEAK_BF16_TFLOPS, "TFLOP/s"
     else:
         ach, peak, unit = f["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s"
@@ -322,7 +326,7 @@ def main():
         torch.distributed.all_reduce(ones)
         ranks_seen = int(ones.item())
         assert ranks_seen == world, f"all_reduce saw {ranks_seen} ranks, expected {world}"
-    gm = optimize_model(model, cuda_graph=False)
+    gm = optimize_model(model, cuda_graph=False, fp8=args.fp8)
     mode = args.mode
     if mode == "auto":
         mode = "loop" if (args.steps % n_sched == 0 and args.warmup % n_sched == 0) else "step"
@@ -362,9 +366,10 @@ def main():
             "value": round(world * args.batch * args.steps / elapsed, 3),
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "fp8" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": f"SDXL-base UNet, latent {args.latent}x{args.latent} (1024x1024 px), bs={args.batch}/GPU, "
-                                   f"{n_sched}-step Euler-discrete loop, hipGraph mode={mode}, no CFG",
+                                   f"{n_sched}-step Euler-discrete loop, hipGraph mode={mode}, no CFG"
+                                   + (", transformer projections e4m3 x e4m3 (everything else bf16)" if args.fp8 else ""),
                        "parallelism": f"prompt-parallel x{world}", "weights": "synthetic seed 0",
                        "weight_broadcasts": n_bcast},
             "finite": finite, "capture_s": round(t_capture, 2), "weights_s": round(t_fill, 2),

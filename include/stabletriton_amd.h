@@ -38,8 +38,8 @@ enum {
     ST_EPI_ROWBIAS   = 16   /* + rowbias[batch(m)][n]     (time-embedding add)    */
 };
 
-int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 6
-                                              (6: next-weights hint passed per call, st_timestep_sincos) */
+int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 7
+                                              (6: next-weights hint passed per call, st_timestep_sincos; 7: fp8 entry points) */
 const char* st_last_error(void);           /* host string, thread-local     */
 
 /* GroupNorm (+SiLU).  Replaces reference group_norm_wrapper
@@ -150,6 +150,24 @@ int st_step_advance(int* step, int n_steps, void* stream);
  * t is fp32 on the device; out is (batch, dim) of `dtype`. */
 int st_timestep_features(const float* t, long t_stride, const int* step, void* out,
                          int batch, int dim, int dtype, void* stream);
+
+/* ---- fp8 projection path (BASELINE config #5).  Seed in the reference: fp8-stored projection
+ * weights, up-converted before the product (kernels/attention_proj.py:36-39, 105-155); here both operands stay OCP
+ * e4m3 ("e4m3fn") down to the matrix pipe (v_mfma_f32_16x16x32_fp8_fp8), accumulation fp32, output bf16.
+ *
+ * st_quantize_fp8: x (rows, C) of `dtype`, row stride ldx elements -> xq (rows, C) e4m3 bytes, contiguous, and
+ *   row_scale[m] = max_k |x[m][k]| / 448 (fp32), xq[m][k] = e4m3(x[m][k] / row_scale[m]), round to nearest even.
+ * st_layer_norm_quantize_fp8: the same on LayerNorm(x) (the layer_norm_wrapper -> linear_wrapper pair of the
+ *   transformer blocks as one pass over x); x (rows, C) contiguous.
+ * st_linear_fp8: y[M,N] = epilogue((xq Wq^T) * row_scale[m] * w_scale[n]); Wq is (N, K) e4m3 bytes (2N rows and 2N
+ *   scales with ST_EPI_GEGLU), K a multiple of 128, bias / residual / y bf16.  workspace, next_weights: as st_linear. */
+int st_quantize_fp8(const void* x, long ldx, void* xq, float* row_scale, int rows, int C, int dtype, void* stream);
+int st_layer_norm_quantize_fp8(const void* x, const void* gamma, const void* beta, void* xq, float* row_scale,
+                               int rows, int C, float eps, int dtype, void* stream);
+int st_linear_fp8(const void* xq, const float* row_scale, const void* Wq, const float* w_scale, const void* bias,
+                  const void* residual, void* y, int M, int N, int K, long lda, long ldc, long ldr, int epilogue,
+                  void* workspace, size_t workspace_bytes, const void* next_weights, size_t next_weights_bytes,
+                  void* stream);
 
 /* The reference's own timestep operator, elementwise (optimizers/replace_timesteps.py:33-40 ->
  * kernels/timestep.py:13-45): x is fp32 of shape (..., half), n elements in all;

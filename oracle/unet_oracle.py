@@ -176,6 +176,19 @@ def unet_forward(sd: SD, sample, timestep, encoder_hidden_states, text_embeds, t
     return conv(sd, "conv_out", x)
 
 
+def euler_img2img(unet_fn, init_latent, noise_unit, tables, strength: float) -> torch.Tensor:
+    """img2img form (restated diffusers img2img `get_timesteps` + `add_noise`; third-party, parity unpinned): start at
+    schedule entry t_start = n - int(n * strength) from init + noise * sigma[t_start]."""
+    n = tables.n_steps
+    t_start = max(n - min(int(n * strength), n), 0)
+    x = init_latent.float() + noise_unit.float() * float(tables.sigmas[t_start])
+    in_scale, dsigma = tables.in_scale(), tables.dsigma()
+    for i in range(t_start, n):
+        eps = unet_fn(x * float(in_scale[i]), torch.tensor(float(tables.timesteps[i])))
+        x = x + eps.float() * float(dsigma[i])
+    return x
+
+
 def euler_denoise(unet_fn, latent_unit, tables, n_steps: Optional[int] = None) -> torch.Tensor:
     """Euler-discrete epsilon-prediction loop (restated diffusers==0.21.2
     EulerDiscreteScheduler, see stabletriton_amd/scheduler.py header; parity of

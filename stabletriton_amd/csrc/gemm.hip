@@ -36,6 +36,8 @@ struct GemmArgs {
     size_t partial_bytes;
     int* tile_counters;          // one arrival counter per output tile (zero between launches)
     int panel_h;                 // tile rows per panel of the block order (see gemm_dma_kernel); >= 1
+    // fp8 operands (st_linear_fp8): acc * row_scale[m] * col_scale[n] before anything else (col_scale has 2N entries with GEGLU)
+    const float* row_scale; const float* col_scale;
     const void* next_w; size_t next_bytes;   // weights of the NEXT launch (host hint): touched during this epilogue
     int helper_blocks;           // > 0: that many extra blocks at the end of the grid (idle CUs) do the touching instead
     unsigned long long* probe;   // diagnostic builds only (-DST_PROBE): per-wave phase cycle sums
@@ -69,6 +71,23 @@ template <> struct Mma<float> {
         for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
     }
 };
+
+// fp8 (OCP e4m3) operands: A and W are bytes in memory, accumulation is fp32, everything the epilogue touches is bf16
+struct f8 { unsigned char v; };
+template <> struct Mma<f8> {
+    typedef u32x4 Frag;              // 16 consecutive k of one row
+    // the low and the high 8 bytes feed one v_mfma_f32_16x16x32_fp8_fp8 each: lane (r, q) then contributes
+    // k = 16q .. 16q+7 and 16q+8 .. 16q+15 of this 64-wide k group - the same permutation on both operands
+    static __device__ __forceinline__ void run(f32x4& acc, const Frag& a, const Frag& b) {
+        const long a0 = (long)(((unsigned long)a[1] << 32) | a[0]), a1 = (long)(((unsigned long)a[3] << 32) | a[2]);
+        const long b0 = (long)(((unsigned long)b[1] << 32) | b[0]), b1 = (long)(((unsigned long)b[3] << 32) | b[2]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, acc, 0, 0, 0);
+    }
+};
+template <typename T> struct OutT { typedef T type; };
+template <> struct OutT<f8> { typedef bf16 type; };
+template <typename T> constexpr int mfma_per_frag() { return sizeof(T) == 4 ? 4 : (sizeof(T) == 1 ? 2 : 1); }
 
 template <typename T> struct Out4;
 template <> struct Out4<bf16> {
@@ -156,6 +175,10 @@ __device__ __forceinline__ void epilogue_compute4(const GemmArgs& p, int m, int 
     float g[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) g[e] = g_in[e];
+    if (p.col_scale) {                                 // fp8 operands: dequantisation scales
+        const float rs = p.row_scale[m];
+        for (int e = 0; e < 4 && n + e < p.N; ++e) { v[e] *= rs * p.col_scale[n + e]; if (GEGLU) g[e] *= rs * p.col_scale[p.N + n + e]; }
+    }
     if (p.ln_c) {                                      // folded LayerNorm: rank-1 correction per row / column
         if (full) {
             float c4[4], d4[4];
@@ -269,7 +292,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
         // counts stores too, so a load behind a store would also wait for that store's acknowledgement.
         typedef typename Raw4<T>::type R4;
         const bool has_bias = p.epi & ST_EPI_BIAS, has_res = p.epi & ST_EPI_RESIDUAL, has_rb = p.epi & ST_EPI_ROWBIAS;
-        const bool has_ln = p.ln_c != nullptr, do_silu = p.epi & ST_EPI_SILU;
+        const bool has_ln = p.ln_c != nullptr, do_silu = p.epi & ST_EPI_SILU, has_scale = p.col_scale != nullptr;
         int ncol[TNO], mrow[TM];
         bool nok[TNO], mok[TM];
 #pragma unroll
@@ -286,6 +309,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
             R4 braw[NJ] = {}, graw[NJ] = {};
             f32x4 cv[NJ] = {}, dv[NJ] = {}, cg[NJ] = {}, dg[NJ] = {};
             R4 rres[TM][NJ] = {}, rrb[TM][NJ] = {};
+            f32x4 csc[NJ] = {}, gsc[NJ] = {};
+            float rsc[TM] = {};
+            if (has_scale) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    csc[j] = *reinterpret_cast<const f32x4*>(p.col_scale + ncol[J0 + j]);
+                    if (GEGLU) gsc[j] = *reinterpret_cast<const f32x4*>(p.col_scale + p.N + ncol[J0 + j]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) rsc[i] = p.row_scale[mrow[i]];
+            }
             if (has_bias) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) { braw[j] = ld_raw4<T>(bias + ncol[J0 + j]); if (GEGLU) graw[j] = ld_raw4<T>(bias + p.N + ncol[J0 + j]); }
@@ -323,6 +357,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                     float v[4], g[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] = acc[i][J0 + j][e]; g[e] = GEGLU ? acc[i][J0 + j + (GEGLU ? TN / 2 : 0)][e] : 0.f; }
+                    if (has_scale) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] *= rsc[i] * csc[j][e]; if (GEGLU) g[e] *= rsc[i] * gsc[j][e]; }
+                    }
                     if (has_ln) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -683,6 +721,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     static_assert(!GEGLU || (TN % 2 == 0), "GEGLU pairs value/gate n-tiles inside one wave");
     static_assert((STAGES - 2) * G <= 63, "vmcnt immediate");
     typedef typename Mma<T>::Frag Frag;
+    typedef typename OutT<T>::type TO;                          // element type of C, bias, residual (fp8 operands: bf16)
 
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const dump = lds + STAGES * STAGE + BM * 8;          // after the ring and the LayerNorm (mean, rstd) rows
@@ -789,19 +828,19 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
             for (int o = t * 128; o < nbytes; o += NT_ * 128) touch_at((const char*)base + byte_off + o);
         };
         if (p.epi & ST_EPI_BIAS) {
-            touch(p.bias, (long)n0 * sizeof(T), ncols_out * (int)sizeof(T));
-            if (GEGLU) touch(p.bias, ((long)p.N + n0) * sizeof(T), ncols_out * (int)sizeof(T));
+            touch(p.bias, (long)n0 * sizeof(TO), ncols_out * (int)sizeof(TO));
+            if (GEGLU) touch(p.bias, ((long)p.N + n0) * sizeof(TO), ncols_out * (int)sizeof(TO));
         }
         if (LNF) {
             touch(p.ln_c, (long)n0 * 4, ncols_out * 4); touch(p.ln_d, (long)n0 * 4, ncols_out * 4);
             if (GEGLU) { touch(p.ln_c, ((long)p.N + n0) * 4, ncols_out * 4); touch(p.ln_d, ((long)p.N + n0) * 4, ncols_out * 4); }
         }
         if (p.epi & ST_EPI_RESIDUAL) {
-            const int lines = (ncols_out * (int)sizeof(T) + 127) / 128;      // per row
+            const int lines = (ncols_out * (int)sizeof(TO) + 127) / 128;      // per row
             const int rows = min(BM, p.M - m0);
             for (int o = t; o < rows * lines; o += NT_) {
                 const int r = o / lines, l = o - r * lines;
-                touch_at((const char*)p.residual + ((size_t)(m0 + r) * p.ldr + n0) * sizeof(T) + l * 128);
+                touch_at((const char*)p.residual + ((size_t)(m0 + r) * p.ldr + n0) * sizeof(TO) + l * 128);
             }
         }
     }
@@ -1027,7 +1066,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
 #ifndef ST_NO_PIN
             __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
             if constexpr (n_dma > 0) __builtin_amdgcn_sched_group_barrier(0x020, n_dma, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * (sizeof(T) == 4 ? 4 : 1), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * mfma_per_frag<T>(), 0);
             __builtin_amdgcn_sched_barrier(0);
 #else
             (void)n_dma;
@@ -1066,14 +1105,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
             const float2 v = lnst[wm * WTM + i * 16 + r16];
             mean[i] = v.x; rstd[i] = v.y;
         }
-        gemm_epilogue<T, TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wm, wn, r16, q, split, mean, rstd);
+        gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wm, wn, r16, q, split, mean, rstd);
     } else {
 #ifdef ST_PROBE
         unsigned long long ept[2] = {0, 0};
-        gemm_epilogue<T, TM, TN, WTM, WTN, GEGLU, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n, ept);
+        gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n, ept);
         pr_x = ept[0] - pr_end; pr_d = ept[1] - ept[0];
 #else
-        gemm_epilogue<T, TM, TN, WTM, WTN, GEGLU, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n);
+        gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n);
 #endif
     }
 #ifdef ST_PROBE
@@ -1623,6 +1662,7 @@ static void launch_dma(const GemmArgs& a, hipStream_t st) {
     if constexpr (!CONV) {
         const bool geglu = a.epi & ST_EPI_GEGLU;
         constexpr bool PAIRS = ((BN / WGN / 16) % 2 == 0);      // GEGLU pairs value/gate n-tiles inside a wave
+        if constexpr (sizeof(T) != 1)
         if (a.ln_c) {          // LayerNorm-folded variants (never split over K: the row statistics need all of K)
             if constexpr (PAIRS) {
                 if (geglu) { launch_dma_one<T, BM, BN, WGM, WGN, STAGES, U, false, true, true>(a, st, cdiv(a.N, BN / 2)); return; }
@@ -1674,7 +1714,9 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
     auto tiles = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(n_eff, bn); };
     constexpr int KB = 128 / (int)sizeof(T);
     const char* who = CONV ? "conv2d" : "linear";
-    if (a.K % KB != 0) {                         // ragged K: register-staged kernel (no LayerNorm partials)
+    if constexpr (sizeof(T) == 1) {
+        if (a.K % KB != 0) return st_fail("%s: fp8 operands need K to be a multiple of %d", who, KB);
+    } else if (a.K % KB != 0) {                  // ragged K: register-staged kernel (no LayerNorm partials)
         if (a.stats_chunks_out) *a.stats_chunks_out = 0;
         if (tiles(128, 128) >= 240) launch_cfg<T, 128, 128, 2, 2, CONV>(a, st);
         else if (tiles(128, 64) >= 200) launch_cfg<T, 128, 64, 2, 2, CONV>(a, st);
@@ -1722,7 +1764,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
                 if (cost < best) { best = cost; cfg = c.cfg; sk = k_; }
             }
         }
-        if constexpr (!CONV) {
+        if constexpr (!CONV && std::is_same<T, bf16>::value) {
             // the 256 x 256 eight-phase kernel: no K split, whole rounds of 256 blocks
             if (gemm8p_applies(a)) {
                 const long nt = tiles(256, 256);
@@ -1867,6 +1909,29 @@ extern "C" int st_ln_linear(const void* x, const float* row_stats, int row_stats
     take_hint(a, next_weights, next_weights_bytes);
     hipStream_t st = (hipStream_t)stream;
     return dtype == ST_BF16 ? gemm_dispatch<bf16, false>(a, st) : gemm_dispatch<float, false>(a, st);
+}
+
+// fp8 projections (seed: the reference's fp8-stored projection weights, kernels/attention_proj.py:36-39,
+// 105-155, which it up-converts before the product - here both operands go to the fp8 matrix pipe):
+//   y = epilogue((xq Wq^T) * row_scale[m] * w_scale[n]),  xq / Wq OCP e4m3 bytes, fp32 accumulation, bf16 out.
+extern "C" int st_linear_fp8(const void* xq, const float* row_scale, const void* Wq, const float* w_scale, const void* bias,
+                             const void* residual, void* y, int M, int N, int K, long lda, long ldc, long ldr, int epilogue,
+                             void* workspace, size_t workspace_bytes, const void* next_weights, size_t next_weights_bytes,
+                             void* stream) {
+    ST_REQUIRE(xq && row_scale && Wq && w_scale && y, "linear_fp8: null pointer");
+    ST_REQUIRE(M > 0 && N > 0 && K > 0, "linear_fp8: bad shape M=%d N=%d K=%d", M, N, K);
+    ST_REQUIRE(K % 128 == 0 && lda % 16 == 0, "linear_fp8: K=%d must be a multiple of 128 and lda=%ld of 16", K, lda);
+    ST_REQUIRE(N % 4 == 0 && ldc % 4 == 0 && (!(epilogue & ST_EPI_RESIDUAL) || ldr % 4 == 0), "linear_fp8: N, ldc, ldr must be multiples of 4");
+    ST_REQUIRE(!(epilogue & ST_EPI_ROWBIAS), "linear_fp8: the row-bias epilogue is not supported");
+    ST_REQUIRE(((uintptr_t)xq | (uintptr_t)Wq | (uintptr_t)y | (uintptr_t)w_scale) % 16 == 0, "linear_fp8: pointers must be 16-byte aligned");
+    GemmArgs a = {};
+    a.A = xq; a.W = Wq; a.bias = bias; a.residual = residual; a.C = y;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.epi = epilogue;
+    a.row_scale = row_scale; a.col_scale = w_scale;
+    a.splitk = 1; a.partial = (float*)workspace; a.partial_bytes = workspace ? workspace_bytes : 0;
+    take_hint(a, next_weights, next_weights_bytes);
+    if (int e = check_epilogue("linear_fp8", a)) return e;
+    return gemm_dispatch<f8, false>(a, (hipStream_t)stream);
 }
 
 // ---- host side of conv_halo_kernel --------------------------------------------------------------

@@ -418,6 +418,85 @@ def fold_layer_norm(gamma: torch.Tensor, beta: torch.Tensor, weight: torch.Tenso
     return wf, c, d.contiguous()
 
 
+# ----------------------------------------------------------------------------- fp8 projections
+FP8_MAX = 448.0           # largest finite OCP e4m3 value
+
+
+class Fp8Rows:
+    """An activation matrix quantised row by row: e4m3 bytes (M, K) + fp32 scale per row."""
+    __slots__ = ("q", "scale", "shape")
+
+    def __init__(self, q: torch.Tensor, scale: torch.Tensor, shape):
+        self.q, self.scale, self.shape = q, scale, tuple(shape)
+
+
+@torch.no_grad()
+def quantize_weight_fp8(weight: torch.Tensor):
+    """(N, K) weight -> (e4m3 bytes as uint8 (N, K), fp32 scale per output channel).  Host-side, once per weight."""
+    w = weight.detach().float()
+    scale = (w.abs().amax(dim=1).clamp_min(1e-12) / FP8_MAX).contiguous()
+    q = (w / scale[:, None]).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+    return q, scale
+
+
+def quantize_fp8(x: torch.Tensor, layernorm=None) -> Fp8Rows:
+    """Row-wise e4m3 quantisation of x (..., K); with `layernorm=(gamma, beta, eps)` of LayerNorm(x), in one pass."""
+    _C.require_device(x)
+    lib = _C.load()
+    K = x.shape[-1]
+    x2, M, ldx = _rows2d(x)
+    q = torch.empty((M, K), dtype=torch.uint8, device=x.device)
+    scale = torch.empty((M,), dtype=torch.float32, device=x.device)
+    if layernorm is None:
+        _C.check(_timed("quantize_fp8", 0.0, float(x2.numel() * (x.element_size() + 1)), lib.st_quantize_fp8, x2.data_ptr(), ldx,
+                        q.data_ptr(), scale.data_ptr(), M, K, _C.dtype_code(x.dtype), _C.stream_ptr()), "quantize_fp8")
+    else:
+        gamma, beta, eps = layernorm
+        if ldx != K:
+            x2 = x2.contiguous()
+        g = gamma if gamma.dtype == x.dtype else gamma.to(x.dtype)
+        b = beta if beta.dtype == x.dtype else beta.to(x.dtype)
+        _C.check(_timed("quantize_fp8", 0.0, float(x2.numel() * (x.element_size() + 1)), lib.st_layer_norm_quantize_fp8, x2.data_ptr(),
+                        g.data_ptr(), b.data_ptr(), q.data_ptr(), scale.data_ptr(), M, K, float(eps), _C.dtype_code(x.dtype),
+                        _C.stream_ptr()), "layer_norm_quantize_fp8")
+    return Fp8Rows(q, scale, x.shape)
+
+
+def linear_fp8(x: "Fp8Rows", wq: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor] = None, *, silu: bool = False,
+               geglu: bool = False, residual: Optional[torch.Tensor] = None, out_dtype=torch.bfloat16) -> torch.Tensor:
+    """epilogue((xq @ wq.T) * row_scale * w_scale): both operands e4m3 on the fp8 matrix pipe, fp32 accumulation, bf16 out."""
+    _C.require_device(x.q, wq, w_scale, bias, residual)
+    lib = _C.load()
+    M, K = x.q.shape
+    if wq.dtype != torch.uint8 or wq.dim() != 2 or wq.shape[1] != K or w_scale.numel() != wq.shape[0]:
+        raise BackendError("linear_fp8: weight must be (N, K) e4m3 bytes (uint8) with one fp32 scale per row")
+    if out_dtype != torch.bfloat16:
+        raise BackendError("linear_fp8: the output type is bfloat16")
+    N = wq.shape[0] // 2 if geglu else wq.shape[0]
+    out = torch.empty(*x.shape[:-1], N, dtype=out_dtype, device=wq.device)
+    epi = 0
+    if bias is not None:
+        epi |= _C.EPI_BIAS
+        bias = bias if bias.dtype == out_dtype else bias.to(out_dtype)
+    if silu:
+        epi |= _C.EPI_SILU
+    if geglu:
+        epi |= _C.EPI_GEGLU
+    ldr = 0
+    if residual is not None:
+        if residual.shape != out.shape or residual.dtype != out_dtype:
+            raise BackendError("linear_fp8: residual must match the output shape and dtype")
+        residual, _, ldr = _rows2d(residual)
+        epi |= _C.EPI_RESIDUAL
+    gws = _gemm_workspace(wq.device)
+    nxt_p, nxt_b = _next_weights(wq)
+    _label(f"M={M} N={N} K={K} fp8 epi={epi}")
+    _C.check(_timed("linear_fp8", 2.0 * M * wq.shape[0] * K, float(M * K + wq.numel() + 2 * M * N), lib.st_linear_fp8,
+                    x.q.data_ptr(), x.scale.data_ptr(), wq.data_ptr(), w_scale.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
+                    M, N, K, K, N, ldr, epi, gws.data_ptr(), gws.numel(), nxt_p, nxt_b, _C.stream_ptr()), "linear_fp8")
+    return out
+
+
 # ----------------------------------------------------------------------------- attention
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int, scale: float) -> torch.Tensor:
     """q (B,T,H*D), k/v (B,S,H*D) in projection layout -> (B,T,H*D)."""

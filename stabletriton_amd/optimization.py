@@ -18,12 +18,12 @@ from torch import fx, nn
 from . import _C, ops
 from .optimizers import (dedupe_pure_calls, fuse_token_residual, fuse_attention, fuse_geglu, fuse_geglu_into_linear, fuse_layernorm_into_linear, fuse_residual_adds,
                          fuse_shared_input_linears,
-                         fuse_temb_add, fuse_timesteps, split_context, split_region, keep_channels_last, make_dynamic_graphed_callable, remove_dropout,
+                         fuse_temb_add, fuse_timesteps, split_context, split_region, keep_channels_last, make_dynamic_graphed_callable, quantize_projections_fp8, remove_dropout,
                          replace_conv, replace_group_norm, replace_group_norm_activation, replace_layer_norm,
                          replace_linear, replace_linear_activ)
 
 
-def replace_backend(gm: fx.GraphModule, fuse: bool = True) -> fx.GraphModule:
+def replace_backend(gm: fx.GraphModule, fuse: bool = True, fp8: bool = False) -> fx.GraphModule:
     """Pass pipeline.  The first eight passes and their order are the reference's
     (optimization.py:10-22); replace_linear is enabled (the MFMA GEMM is the
     product here), replace_conv / epilogue fusions / layout are additions."""
@@ -46,6 +46,8 @@ def replace_backend(gm: fx.GraphModule, fuse: bool = True) -> fx.GraphModule:
         stats["residual_adds"] = fuse_residual_adds(gm)
         stats["token_residuals"] = fuse_token_residual(gm)
         stats["shared_input_gemms"] = fuse_shared_input_linears(gm)
+        if fp8:      # transformer-block projections on the fp8 matrix pipe (claims its LayerNorms before the bf16 folding does)
+            stats["fp8_projections"] = quantize_projections_fp8(gm)
         stats["layer_norm_in_gemm"] = fuse_layernorm_into_linear(gm)
     stats["channels_last_views"] = keep_channels_last(gm)
     gm.graph.eliminate_dead_code()
@@ -59,7 +61,9 @@ def run_compiler(gm: fx.GraphModule) -> fx.GraphModule:
     return replace_backend(gm)
 
 
-def optimize_model(model: nn.Module, cuda_graph: bool = True, fuse: bool = True) -> fx.GraphModule:
+def optimize_model(model: nn.Module, cuda_graph: bool = True, fuse: bool = True, fp8: bool = False) -> fx.GraphModule:
+    """`fp8=True` (addition, BASELINE config #5): the transformer-block projections of a bf16 model run with OCP e4m3
+    operands on the fp8 matrix pipe (optimizers/quantize_fp8.py); everything else is unchanged."""
     # same preconditions as the reference (optimization.py:29-33), for ROCm
     assert torch.cuda.is_available(), "a ROCm GPU is required to use stabletriton_amd"
     major, _ = torch.cuda.get_device_capability()
@@ -71,7 +75,9 @@ def optimize_model(model: nn.Module, cuda_graph: bool = True, fuse: bool = True)
         raise RuntimeError(f"model dtype {p0.dtype} not supported: use bfloat16 (fast) or float32 (strict parity)")
     _C.load()                                  # fail now, loudly, if the HIP library is missing
     model = model.eval().to(memory_format=torch.channels_last)      # conv weights -> (Cout,R,S,Cin) strides
-    gm = replace_backend(fx.symbolic_trace(model), fuse=fuse)
+    if fp8 and p0.dtype != torch.bfloat16:
+        raise RuntimeError("fp8 projections need a bfloat16 model")
+    gm = replace_backend(fx.symbolic_trace(model), fuse=fuse, fp8=fp8)
     # the compiled module owns its mutable host state (split-K workspace, next-weights plan, derived weight buffers):
     # two compiled modules, or two streams each driving their own, never share any (ops.ExecContext)
     gm.exec_context = ops.ExecContext()

@@ -23,7 +23,7 @@ from .scheduler import EulerTables, euler_discrete_tables
 class DenoiseLoop:
     def __init__(self, unet: Callable, batch: int, latent_hw: int, dtype: torch.dtype, device,
                  tables: Optional[EulerTables] = None, cross_dim: int = 2048, pooled_dim: int = 1280,
-                 tokens: int = 77, mode: str = "loop"):
+                 tokens: int = 77, mode: str = "loop", n_time_ids: int = 6):
         assert mode in ("loop", "step", "eager")
         self.unet, self.mode, self.dtype = unet, mode, dtype
         self.device = torch.device(device)
@@ -35,7 +35,7 @@ class DenoiseLoop:
         self.x_in = torch.zeros((batch, 4, latent_hw, latent_hw), dtype=dtype, device=dev).contiguous(memory_format=cl)
         self.ehs = torch.zeros((batch, tokens, cross_dim), dtype=dtype, device=dev)
         self.text_embeds = torch.zeros((batch, pooled_dim), dtype=dtype, device=dev)
-        self.time_ids = torch.zeros((batch, 6), dtype=dtype, device=dev)
+        self.time_ids = torch.zeros((batch, n_time_ids), dtype=dtype, device=dev)
         self.timesteps = torch.tensor(self.tables.timesteps, dtype=torch.float32, device=dev)
         self.dsigma = torch.tensor(self.tables.dsigma(), dtype=torch.float32, device=dev)
         self.in_scale = torch.tensor(self.tables.in_scale(), dtype=torch.float32, device=dev)
@@ -93,6 +93,19 @@ class DenoiseLoop:
         self.latent.copy_(latent_unit.to(self.device, torch.float32) * self.tables.init_noise_sigma)
         self.x_in.copy_(self.latent * float(self.tables.in_scale()[0]))
         self.step.zero_()
+
+    def set_image(self, init_latent: torch.Tensor, noise_unit: torch.Tensor, strength: float) -> int:
+        """img2img start (the refiner's use, BASELINE config #5; restated diffusers img2img: `get_timesteps` +
+        `scheduler.add_noise`): skip the first n - int(n * strength) schedule entries, start from
+        init_latent + noise * sigma[t_start].  Returns the number of steps left to run (`run_steps(k)`, mode step / eager)."""
+        n = self.n_steps
+        t_start = max(n - min(int(n * strength), n), 0)
+        sigma = float(self.tables.sigmas[t_start])
+        lat = init_latent.to(self.device, torch.float32) + noise_unit.to(self.device, torch.float32) * sigma
+        self.latent.copy_(lat)
+        self.x_in.copy_(self.latent * float(self.tables.in_scale()[t_start]))
+        self.step.fill_(t_start)
+        return n - t_start
 
     # ---- one step ------------------------------------------------------------------------
     def _cond(self) -> Dict[str, torch.Tensor]:

@@ -96,7 +96,7 @@ def state_dict_for(shapes: Dict[str, Tuple[int, ...]], seed: int = 0, device="cp
 
 
 def denoise_inputs(batch: int, latent_hw: int, seed: int = 1234, device="cpu",
-                   cross_dim: int = 2048, pooled_dim: int = 1280, tokens: int = 77):
+                   cross_dim: int = 2048, pooled_dim: int = 1280, tokens: int = 77, n_time_ids: int = 6):
     """SURVEY.md 8(d) synthetic inputs: unit-normal latent (caller scales by
     init sigma), text states, pooled text embedding and SDXL time ids."""
     px = float(latent_hw * 8)
@@ -104,5 +104,7 @@ def denoise_inputs(batch: int, latent_hw: int, seed: int = 1234, device="cpu",
         "latent": normal("latent", (batch, 4, latent_hw, latent_hw), seed, device),
         "encoder_hidden_states": normal("ehs", (batch, tokens, cross_dim), seed, device),
         "text_embeds": normal("text_embeds", (batch, pooled_dim), seed, device),
-        "time_ids": torch.tensor([[px, px, 0.0, 0.0, px, px]] * batch, dtype=torch.float32, device=device),
+        # base: (original h, w, crop top, left, target h, w); refiner (5 ids): (original h, w, crop top, left, aesthetic score)
+        "time_ids": torch.tensor([[px, px, 0.0, 0.0, px, px][:n_time_ids] if n_time_ids >= 6 else [px, px, 0.0, 0.0, 6.0][:n_time_ids]] * batch,
+                                 dtype=torch.float32, device=device),
     }

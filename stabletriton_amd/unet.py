@@ -41,6 +41,7 @@ class UNetSpec:
     n_time_ids: int = 6
     groups: int = 32
     sample_size: int = 128
+    mid_depth: Optional[int] = None                   # transformer layers of the middle block (None: those of the last level)
 
     @property
     def add_in_dim(self) -> int:
@@ -48,9 +49,17 @@ class UNetSpec:
 
 
 SDXL_BASE = UNetSpec()
+# SDXL-refiner (BASELINE config #5).  The reference has no refiner model: the topology below is the
+# published stabilityai/stable-diffusion-xl-refiner-1.0 UNet configuration (four levels 384/768/1536/1536, four
+# transformer layers on the two middle levels and in the middle block, 1280-wide text context, five size / crop /
+# aesthetic-score ids), restated by the oracle from the state_dict keys - parity unpinned.
+SDXL_REFINER = UNetSpec(widths=(384, 768, 1536, 1536), depths=(0, 4, 4, 0), mid_depth=4, cross_dim=1280, temb_dim=1536,
+                        time_proj_dim=384, add_time_proj_dim=256, pooled_dim=1280, n_time_ids=5)
 # small network with the same topology, for CPU tests and quick GPU parity runs
 TINY = UNetSpec(widths=(64, 128, 256), depths=(0, 1, 2), cross_dim=128, temb_dim=256,
                 time_proj_dim=64, add_time_proj_dim=32, pooled_dim=64, sample_size=16)
+TINY_REFINER = UNetSpec(widths=(64, 128, 256, 256), depths=(0, 1, 1, 0), mid_depth=1, cross_dim=128, temb_dim=256,
+                        time_proj_dim=64, add_time_proj_dim=32, pooled_dim=64, n_time_ids=5, sample_size=16)
 
 
 class SinusoidalProj(nn.Module):
@@ -288,7 +297,7 @@ class UNet2DConditionModel(nn.Module):
             skip_ch += [w[lvl]] * spec.resnets_per_level + ([w[lvl]] if lvl < n - 1 else [])
             c_prev = w[lvl]
         self.down_blocks = nn.ModuleList(downs)
-        self.mid_block = MidStage(w[-1], spec, spec.depths[-1])
+        self.mid_block = MidStage(w[-1], spec, spec.depths[-1] if spec.mid_depth is None else spec.mid_depth)
 
         ups = []
         for lvl in reversed(range(n)):

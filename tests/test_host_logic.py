@@ -191,3 +191,19 @@ def test_wrappers_are_fx_leaves():
         return wrappers.linear_wrapper(v, lin, False)
     g = fx.symbolic_trace(f)
     assert any(n.op == "call_function" and n.target is wrappers.linear_wrapper for n in g.graph.nodes)
+
+
+def test_refiner_spec_and_fp8_pass_counts():
+    """SDXL-refiner topology (BASELINE config #5; no reference model, parity unpinned): parameter count of the published
+    configuration, pass counts, and the fp8 mode claiming every transformer-block projection."""
+    from stabletriton_amd.unet import SDXL_REFINER
+    with torch.device("meta"):
+        m = UNet2DConditionModel(SDXL_REFINER).to(torch.bfloat16)
+    assert sum(p.numel() for p in m.parameters()) == 2_259_526_660
+    gm = replace_backend(fx.symbolic_trace(m), fp8=True)
+    st = gm.rewrite_stats
+    # 4 + 4 layers x 2 resnets on the middle levels down, 3 on the way up, + 4 in the middle block = 8 + 8 + 12 + 12 + 4
+    assert st["layer_norm"] == 3 * 44 and st["attention"] == 2 * 44 and st["geglu_in_gemm"] == 44
+    assert st["fp8_projections"] > 0 and st["layer_norm_in_gemm"] == 0
+    left = [n for n in gm.graph.nodes if n.op == "call_module"]
+    assert not [n for n in left if isinstance(gm.get_submodule(n.target), (nn.Linear, nn.Conv2d, nn.GroupNorm, nn.LayerNorm, nn.Dropout))]

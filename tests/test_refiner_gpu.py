@@ -1,0 +1,115 @@
+"""SDXL-refiner UNet + img2img + fp8 projections (BASELINE config #5).
+
+PARITY UNPINNED: the reference contains no refiner model, so the only oracle is the CPU restatement
+(oracle/unet_oracle.py reads the topology off the state_dict keys) driven with the published refiner configuration;
+the restatement itself is pinned on SDXL-base (tests/test_oracle_golden.py) and the two networks share every block type.
+"""
+import pytest
+import torch
+
+from oracle import unet_oracle as orc
+from stabletriton_amd import synth
+from stabletriton_amd.optimization import optimize_model
+from stabletriton_amd.pipeline import DenoiseLoop
+from stabletriton_amd.scheduler import euler_discrete_tables
+from stabletriton_amd.unet import SDXL_REFINER, TINY_REFINER, UNet2DConditionModel
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(spec, dtype, dev):
+    with torch.device("meta"):
+        m = UNet2DConditionModel(spec)
+    m = m.to_empty(device=dev).to(dtype).eval().requires_grad_(False)
+    synth.fill_module_(m, 0)
+    return m
+
+
+def _inputs(spec, batch, hw):
+    return synth.denoise_inputs(batch, hw, 1234, cross_dim=spec.cross_dim, pooled_dim=spec.pooled_dim, n_time_ids=spec.n_time_ids)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 0.1)])
+def test_tiny_refiner_step(gpu, dtype, tol):
+    m = _build(TINY_REFINER, dtype, gpu)
+    gm = optimize_model(m, cuda_graph=True)
+    x = _inputs(TINY_REFINER, 2, 16)
+    xr = {k: v.to(dtype).float() for k, v in x.items()}
+    t = torch.tensor(200.0)
+    sd = {k: v.float().cpu() for k, v in m.state_dict().items()}
+    ref = orc.unet_forward(sd, xr["latent"], t, xr["encoder_hidden_states"], xr["text_embeds"], xr["time_ids"])
+    with torch.no_grad():
+        out = gm(x["latent"].to(gpu, dtype), t.to(gpu), x["encoder_hidden_states"].to(gpu, dtype),
+                 {"text_embeds": x["text_embeds"].to(gpu, dtype), "time_ids": x["time_ids"].to(gpu, dtype)})[0]
+    err = float((out.float().cpu() - ref).abs().max())
+    print(f"tiny refiner step {dtype}: max abs err {err:.2e} (|ref| max {float(ref.abs().max()):.2f})")
+    assert err <= tol
+
+
+def test_tiny_refiner_img2img_fp32(gpu):
+    m = _build(TINY_REFINER, torch.float32, gpu)
+    gm = optimize_model(m, cuda_graph=False)
+    tables = euler_discrete_tables(20)
+    x = _inputs(TINY_REFINER, 1, 16)
+    init = synth.normal("img2img.init", (1, 4, 16, 16), 77) * 0.8
+    loop = DenoiseLoop(gm, 1, 16, torch.float32, gpu, tables, cross_dim=TINY_REFINER.cross_dim, pooled_dim=TINY_REFINER.pooled_dim,
+                       mode="step", n_time_ids=TINY_REFINER.n_time_ids)
+    loop.set_conditioning(x["encoder_hidden_states"].to(gpu), x["text_embeds"].to(gpu), x["time_ids"].to(gpu))
+    with torch.no_grad():
+        left = loop.set_image(init, x["latent"], 0.3)
+        assert left == 6
+        loop.run_steps(left)
+        out = loop.latent.contiguous(memory_format=torch.contiguous_format).cpu()
+    sd = {k: v.float().cpu() for k, v in m.state_dict().items()}
+    ref = orc.euler_img2img(lambda xi, t: orc.unet_forward(sd, xi, t, x["encoder_hidden_states"], x["text_embeds"], x["time_ids"]),
+                            init, x["latent"], tables, 0.3)
+    err = float((out - ref).abs().max())
+    print(f"tiny refiner img2img (strength 0.3, 6 of 20 steps) fp32: max abs err {err:.2e}")
+    assert err <= 1e-3
+
+
+def test_sdxl_refiner_fp32_step_vs_oracle(gpu):
+    """Full-size refiner (2.26 G parameters), one strict-mode step at latent 32 against the oracle restatement."""
+    m = _build(SDXL_REFINER, torch.float32, gpu)
+    assert sum(p.numel() for p in m.parameters()) == 2_259_526_660
+    gm = optimize_model(m, cuda_graph=False)
+    x = _inputs(SDXL_REFINER, 1, 32)
+    t = torch.tensor(250.0)
+    with torch.no_grad():
+        out = gm(x["latent"].to(gpu), t.to(gpu), x["encoder_hidden_states"].to(gpu),
+                 {"text_embeds": x["text_embeds"].to(gpu), "time_ids": x["time_ids"].to(gpu)})[0].cpu()
+    sd = {k: v.float().cpu() for k, v in m.state_dict().items()}
+    del m, gm
+    torch.cuda.empty_cache()
+    with torch.no_grad():
+        ref = orc.unet_forward(sd, x["latent"], t, x["encoder_hidden_states"], x["text_embeds"], x["time_ids"])
+    err = float((out - ref).abs().max())
+    print(f"SDXL-refiner step fp32, latent 32: max abs err vs oracle {err:.2e} (|ref| max {float(ref.abs().max()):.2f})")
+    assert err <= 1e-3
+
+
+def test_sdxl_refiner_img2img_1024_fp8(gpu):
+    """BASELINE config #5 as named: refiner, 1024 x 1024 (latent 128), img2img, projections on the fp8 matrix pipe.
+    Checked against the same trajectory with bf16 projections (the fp8 tolerance is that of tests/test_fp8_gpu.py)."""
+    m = _build(SDXL_REFINER, torch.bfloat16, gpu)
+    x = _inputs(SDXL_REFINER, 1, 128)
+    init = synth.normal("img2img.init", (1, 4, 128, 128), 78) * 0.8
+    finals = {}
+    for fp8 in (False, True):
+        gm = optimize_model(m, cuda_graph=False, fp8=fp8)
+        if fp8:
+            assert gm.rewrite_stats["fp8_projections"] > 200
+        loop = DenoiseLoop(gm, 1, 128, torch.bfloat16, gpu, euler_discrete_tables(50), cross_dim=SDXL_REFINER.cross_dim,
+                           pooled_dim=SDXL_REFINER.pooled_dim, mode="step", n_time_ids=SDXL_REFINER.n_time_ids)
+        loop.set_conditioning(x["encoder_hidden_states"].to(gpu, torch.bfloat16), x["text_embeds"].to(gpu, torch.bfloat16),
+                              x["time_ids"].to(gpu, torch.bfloat16))
+        with torch.no_grad():
+            left = loop.set_image(init, x["latent"], 0.3)
+            assert left == 15
+            loop.run_steps(left)
+        finals[fp8] = loop.latent.float().cpu()
+        del loop, gm
+    assert torch.isfinite(finals[True]).all()
+    rms = float((finals[True] - finals[False]).pow(2).mean().sqrt() / finals[False].pow(2).mean().sqrt())
+    print(f"SDXL-refiner img2img 1024 px, 15 steps: fp8-projection trajectory vs bf16 trajectory, relative rms difference {rms:.3f}")
+    assert rms <= 0.5
