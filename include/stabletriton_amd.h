@@ -38,8 +38,8 @@ enum {
     ST_EPI_ROWBIAS   = 16   /* + rowbias[batch(m)][n]     (time-embedding add)    */
 };
 
-int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 7
-                                              (6: next-weights hint passed per call, st_timestep_sincos; 7: fp8 entry points) */
+int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 8
+                                              (6: next-weights hint passed per call, st_timestep_sincos; 7: fp8 entry points; 8: GroupNorm partials from the producer) */
 const char* st_last_error(void);           /* host string, thread-local     */
 
 /* GroupNorm (+SiLU).  Replaces reference group_norm_wrapper
@@ -52,6 +52,15 @@ size_t st_group_norm_workspace_bytes(int N, int C, int HW, int groups);
 int st_group_norm(const void* x, const void* gamma, const void* beta, void* y,
                   int N, int C, int HW, int groups, float eps, int silu,
                   int layout, int dtype, void* workspace, void* stream);
+
+/* GroupNorm (+SiLU) of an NHWC tensor whose statistics come from its producer: `stats0` (and `stats1` for the second
+ * half of a channel concatenation, unet_pt.py:352-357; else NULL / 0 / 0) are the `col_stats` buffers of the st_linear /
+ * st_conv2d launches that wrote x - C0 (+ C1 = C) channels, rows0 / rows1 rows per partial.  Same arithmetic contract
+ * as st_group_norm (fp32 statistics, biased variance; the partial sums are combined in double precision); the statistics
+ * pass over x and its launch are gone.  workspace: st_group_norm_workspace_bytes(). */
+int st_group_norm_from_stats(const void* x, const void* gamma, const void* beta, void* y, int N, int C, int HW,
+                             int groups, float eps, int silu, int dtype, const float* stats0, int C0, int rows0,
+                             const float* stats1, int C1, int rows1, void* workspace, void* stream);
 
 /* LayerNorm over the last dimension.  Replaces layer_norm_wrapper
  * (optimizers/replace_layernorm.py:17-24 -> kernels/layer_norm.py:282-335);
@@ -83,6 +92,11 @@ int st_geglu(const void* state, const void* gate, void* out, int rows, int F,
  * kernel also writes, per output row and per N tile, (sum, sum of squares) of the values it
  * stored - the LayerNorm partials st_ln_linear consumes; the number of tiles actually used is
  * returned through the HOST pointer `row_stats_chunks` (0 = none written).
+ * `col_stats` (may be NULL): device buffer of col_stats_tiles * N float2; when given (with rows_per_batch = rows per
+ * image), the kernel also writes, per tile row of the launch and per output column, (sum, sum of squares) of the values
+ * it stored - the GroupNorm partials st_group_norm_from_stats consumes; the rows per tile row actually used come back
+ * through the HOST pointer `col_stats_rows` (0 = none written: tile rows would straddle images, or the shape takes a
+ * kernel that cannot emit them).
  * `next_weights` / `next_weights_bytes` (may be NULL / 0; no reference counterpart): the weight matrix the
  * GEMM-shaped launch AFTER this one will read.  This launch touches it (one dword per 128-byte line, spread
  * over its blocks, during its epilogue or from helper blocks on idle CUs) so that it waits in the memory-side
@@ -93,6 +107,7 @@ int st_linear(const void* x, const void* W, const void* bias, const void* residu
               long lda, long ldc, long ldr, int rows_per_batch,
               int epilogue, int dtype, void* workspace, size_t workspace_bytes,
               float* row_stats, int row_stats_capacity, int* row_stats_chunks,
+              float* col_stats, int col_stats_tiles, int* col_stats_rows,
               const void* next_weights, size_t next_weights_bytes, void* stream);
 
 /* LayerNorm folded into the Linear (or GEGLU projection) that consumes it - the pair
@@ -123,11 +138,13 @@ int st_attention(const void* q, const void* k, const void* v, void* out,
  * to cuDNN (optimizations.txt:5).  `upsample2x` folds a nearest 2x upsample of
  * the input into the gather (unet_pt.py:264-266).  Epilogue flags as for
  * st_linear; rowbias is (N_batch, Cout) (the time-embedding projection,
- * unet_pt.py:82-83), residual is NHWC (N,Hout,Wout,Cout).  workspace, next_weights: as st_linear. */
+ * unet_pt.py:82-83), residual is NHWC (N,Hout,Wout,Cout).  workspace, col_stats, next_weights: as st_linear
+ * (rows per image = Hout*Wout). */
 int st_conv2d(const void* x, const void* W, const void* bias, const void* residual,
               const void* rowbias, void* y, int N, int Hin, int Win, int Cin,
               int Cout, int R, int S, int stride, int pad, int upsample2x,
               int epilogue, int dtype, void* workspace, size_t workspace_bytes,
+              float* col_stats, int col_stats_tiles, int* col_stats_rows,
               const void* next_weights, size_t next_weights_bytes, void* stream);
 
 /* Euler-discrete update of the fp32 latent and preparation of the next UNet

@@ -31,6 +31,10 @@ struct GemmArgs {
     const float* ln_stats; int ln_chunks;     // per-row (sum, sum of squares) partials written by the producer GEMM
     float* row_stats; int stats_chunks;       // producer side: emit those partials, one float2 per (row, N tile)
     int stats_capacity; int* stats_chunks_out; // host-side plumbing of the chunk count
+    // GroupNorm partials of the output (consumed by st_group_norm_from_stats): per tile row of the launch and per output
+    // column, (sum, sum of squares) of the values stored; col_tiles_cap = tile rows the buffer holds, *col_rows_out = rows
+    // per tile row actually used (host pointer; 0 = this launch emitted nothing)
+    float* col_stats; int col_tiles_cap; int* col_rows_out;
     int splitk;                  // K slices (1 = none): every slice stores an fp32 slab to `partial`; the block of a tile
     float* partial;              //   that finishes last sums the slabs in slice order and runs the epilogue (in-launch combine)
     size_t partial_bytes;
@@ -54,6 +58,8 @@ static inline int dev_env_int(const char* name, int dflt) {
     return dflt;
 #endif
 }
+
+static bool colstats_ok(const GemmArgs& a, int bm, bool lnf);      // (defined with the launchers)
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
@@ -157,6 +163,16 @@ template <typename T> struct Raw4 { typedef bf16x4 type; };
 template <> struct Raw4<float> { typedef f32x4 type; };
 template <typename T> __device__ __forceinline__ typename Raw4<T>::type ld_raw4(const T* p) {
     return *reinterpret_cast<const typename Raw4<T>::type*>(p);
+}
+
+// Sum over the sixteen lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: four single VALU instructions
+// (quad butterflies, then row rotations by 4 and 8) instead of four LDS-crossbar permutes.  Fixed order: bit-reproducible.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));     // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));     // row_ror:8
+    return v;
 }
 
 // ---- shared epilogue ---------------------------------------------------------------------------
@@ -438,6 +454,33 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                 for (int w = 0; w < WGN_; ++w) { const float2 t = sm[row * WGN_ + w]; a1 += t.x; a2 += t.y; }
                 if (m0 + row < p.M)
                     reinterpret_cast<float2*>(p.row_stats)[(size_t)(m0 + row) * p.stats_chunks + tile_n] = make_float2(a1, a2);
+            }
+        }
+        // GroupNorm partials: per output column of this tile, (sum, sum of squares) over the tile's rows of the values just
+        // stored (acc holds them, zero for rows / columns outside the problem).  In-lane over the row tiles, a fixed
+        // butterfly over the sixteen row lanes, then the WGM waves of the column through LDS: bit-reproducible.
+        if (p.col_stats && (p.N & 3) == 0) {
+            constexpr int TNO_ = GEGLU ? TN / 2 : TN;
+            constexpr int WTNO_ = GEGLU ? WTN / 2 : WTN;
+            float2* cm = reinterpret_cast<float2*>(lds_scratch + WGM_ * WTM * WGN_ * 8);      // behind the row-statistics area
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TNO_; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) { const float v = acc[i][j][e]; c1 += v; c2 = fmaf(v, v, c2); }
+                    c1 = row16_sum(c1); c2 = row16_sum(c2);
+                    if (r16 == 0) cm[wm * (WGN_ * WTNO_) + wn * WTNO_ + j * 16 + 4 * q + e] = make_float2(c1, c2);
+                }
+            __syncthreads();
+            const int tile_m = m0 / (WGM_ * WTM);
+            for (int col = threadIdx.x; col < WGN_ * WTNO_; col += WGM_ * WGN_ * 64) {
+                float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WGM_; ++w) { const float2 t = cm[w * (WGN_ * WTNO_) + col]; c1 += t.x; c2 += t.y; }
+                if (n0 + col < p.N) reinterpret_cast<float2*>(p.col_stats)[(size_t)tile_m * p.N + n0 + col] = make_float2(c1, c2);
             }
         }
     }
@@ -1400,6 +1443,7 @@ static void gemm8p_go(const GemmArgs& a, hipStream_t st) {
     b.helper_blocks = (b.next_w && main_blocks <= 208) ? (256 - main_blocks > 96 ? 96 : 256 - main_blocks) : 0;
     b.stats_chunks = tiles_n;
     if (a.stats_chunks_out) *a.stats_chunks_out = a.row_stats ? b.stats_chunks : 0;
+    if (!colstats_ok(a, 256, LNF)) b.col_stats = nullptr;
     hipLaunchKernelGGL(kfn, dim3(main_blocks + b.helper_blocks), dim3(512), lds, st, b);
 }
 
@@ -1625,11 +1669,21 @@ static void launch_cfg(const GemmArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WGM, WGN, CONV, false>), dim3(tiles_m * cdiv(a.N, BN)), dim3(WGM * WGN * 64), lds, st, a);
 }
 
+// Can a launch with BM-row tiles emit GroupNorm partials?  (tile rows must not straddle images; the LayerNorm-folded
+// kernels have no scratch for it.)  Tells the host through *col_rows_out.
+static bool colstats_ok(const GemmArgs& a, int bm, bool lnf) {
+    const bool ok = a.col_stats && !lnf && (a.N & 3) == 0 && a.rows_per_batch > 0 && a.rows_per_batch % bm == 0 &&
+                    cdiv(a.M, bm) <= a.col_tiles_cap;
+    if (a.col_rows_out) *a.col_rows_out = ok ? bm : 0;
+    return ok;
+}
+
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV, bool GEGLU, bool LNF>
 static void launch_dma_one(const GemmArgs& a, hipStream_t st, int tiles_n) {
     const size_t lds = (size_t)STAGES * U * (BM + BN) * 128 + (size_t)BM * 8 + 1024;      // ring + LayerNorm (mean, rstd) per row + DMA dump
     const int sk = a.splitk > 1 ? a.splitk : 1;
     auto kfn = gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, U, CONV, GEGLU, LNF>;
+    const bool emit_cols = colstats_ok(a, BM, LNF);
     static bool once = (allow_big_lds(kfn, lds), true);
     (void)once;
     // XCD partition: bytes from beyond L2 ~ A * (8 / panels) + W * panels (A = activations, all of K)
@@ -1654,6 +1708,7 @@ static void launch_dma_one(const GemmArgs& a, hipStream_t st, int tiles_n) {
     // loops instead of extending the epilogues)
     static const bool no_helpers = dev_env_int("ST_NO_HELPER_BLOCKS", 0) != 0;
     b.helper_blocks = (b.next_w && main_blocks <= 208 && !no_helpers) ? (256 - main_blocks > 96 ? 96 : 256 - main_blocks) : 0;
+    if (!emit_cols) b.col_stats = nullptr;
     hipLaunchKernelGGL(kfn, dim3(main_blocks + b.helper_blocks), dim3(WGM * WGN * 64), lds, st, b);
 }
 
@@ -1742,7 +1797,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
         // (write-through fp32 slabs: ~2 us + 0.4 us per MB of slab).
         struct Cand { int cfg, bm, bn; double trip_us; };
         static const Cand cands[] = {{CFG_128x128_W8, 128, 128, 0.53}, {CFG_64x128_W8, 64, 128, 0.34}, {CFG_128x64_W8, 128, 64, 0.32},
-                                     {CFG_64x64_W8, 64, 64, 0.19}, {CFG_128x320_W8, 128, 320, 1.38}, {CFG_64x320_W8, 64, 320, 0.64},
+                                     {CFG_64x64_W8, 64, 64, 0.19}, {CFG_128x320_W8, 128, 320, 1.9}, {CFG_64x320_W8, 64, 320, 1.1},
                                      {CFG_256x128_W8, 256, 128, 0.72}, {CFG_128x80_W8, 128, 80, 0.37}, {CFG_128x160_W8, 128, 160, 0.66}};
         static const int sks[] = {1, 2, 3, 4, 6, 8};
         static const int force_sk = dev_env_int("ST_GEMM_SPLITK", -1);     // 0/1: never split
@@ -1867,7 +1922,9 @@ static int check_epilogue(const char* who, const GemmArgs& a) {
 extern "C" int st_linear(const void* x, const void* W, const void* bias, const void* residual, const void* rowbias, void* y,
                          int M, int N, int K, long lda, long ldc, long ldr, int rows_per_batch, int epilogue, int dtype,
                          void* workspace, size_t workspace_bytes, float* row_stats, int row_stats_capacity,
-                         int* row_stats_chunks, const void* next_weights, size_t next_weights_bytes, void* stream) {
+                         int* row_stats_chunks, float* col_stats, int col_stats_tiles, int* col_stats_rows,
+                         const void* next_weights, size_t next_weights_bytes, void* stream) {
+    if (col_stats_rows) *col_stats_rows = 0;
     ST_REQUIRE(x && W && y, "linear: null pointer");
     ST_REQUIRE(M > 0 && N > 0 && K > 0, "linear: bad shape M=%d N=%d K=%d", M, N, K);
     const int vec = dtype == ST_BF16 ? 8 : 4;
@@ -1881,6 +1938,7 @@ extern "C" int st_linear(const void* x, const void* W, const void* bias, const v
     a.splitk = 1; a.partial = (float*)workspace; a.partial_bytes = workspace ? workspace_bytes : 0;
     ST_REQUIRE(!row_stats || !(epilogue & ST_EPI_GEGLU), "linear: row_stats with GEGLU is not supported");
     a.row_stats = row_stats; a.stats_capacity = row_stats_capacity; a.stats_chunks_out = row_stats_chunks;
+    a.col_stats = col_stats; a.col_tiles_cap = col_stats_tiles; a.col_rows_out = col_stats_rows;
 #ifdef ST_PROBE
     a.probe = g_probe;
 #endif
@@ -1958,7 +2016,9 @@ static void conv_halo_go(const GemmArgs& b, int blocks, hipStream_t st) {
     auto kfn = conv_halo_kernel<WL2, TH, BN, WGM, WGN, UPS>;
     static bool once = (allow_big_lds(kfn, lds), true);
     (void)once;
-    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, st, b);
+    GemmArgs c = b;
+    if (!colstats_ok(b, TH * W, false)) c.col_stats = nullptr;
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, st, c);
 }
 
 static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
@@ -2084,7 +2144,9 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GemmArgs p, int R,
 extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const void* residual, const void* rowbias, void* y,
                          int N, int Hin, int Win, int Cin, int Cout, int R, int S, int stride, int pad, int upsample2x,
                          int epilogue, int dtype, void* workspace, size_t workspace_bytes,
+                         float* col_stats, int col_stats_tiles, int* col_stats_rows,
                          const void* next_weights, size_t next_weights_bytes, void* stream) {
+    if (col_stats_rows) *col_stats_rows = 0;
     ST_REQUIRE(x && W && y, "conv2d: null pointer");
     ST_REQUIRE(N > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0,
                "conv2d: bad geometry");
@@ -2105,6 +2167,7 @@ extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const v
     a.M = N * a.Hout * a.Wout; a.N = Cout; a.K = R * S * Cin;
     a.lda = 0; a.ldc = Cout; a.ldr = Cout; a.rows_per_batch = a.Hout * a.Wout; a.epi = epilogue;
     a.splitk = 1; a.partial = (float*)workspace; a.partial_bytes = workspace ? workspace_bytes : 0;
+    a.col_stats = col_stats; a.col_tiles_cap = col_stats_tiles; a.col_rows_out = col_stats_rows;
     take_hint(a, next_weights, next_weights_bytes);
     if (int e = check_epilogue("conv2d", a)) return e;
     hipStream_t st = (hipStream_t)stream;

@@ -255,6 +255,85 @@ extern "C" int st_group_norm(const void* x, const void* gamma, const void* beta,
     return st_fail("group_norm: unsupported dtype %d", dtype);
 }
 
+// GroupNorm whose statistics come from the producer: the GEMM / conv that wrote x also left, per tile row of its
+// launch and per channel, (sum, sum of squares) of the values it stored (st_linear / st_conv2d `col_stats`).  A channel
+// concatenation (the decoder's skip connections, unet_pt.py:352-357) is two such sources side by side.  One wave per
+// (image, group) adds the partials of its channels in double precision (fixed order), and the apply pass is the usual
+// one: the statistics launch and its read of x are gone.
+struct GnSource { const float2* part; int C; int tiles_per_image; };
+
+__global__ __launch_bounds__(256) void gn_cols_finalize(GnSource s0, GnSource s1, float2* __restrict__ stats, int G, int NG,
+                                                        int cpg, double count, float eps) {
+    // one block per (image, group): its cpg channels are contiguous in a partial row, so consecutive threads read
+    // consecutive channels of one tile row (coalesced), 256 / cpg tile rows at a time
+    const int i = blockIdx.x, t_ = threadIdx.x;
+    const int n = i / G, g = i - n * G;
+    const int c_lo = g * cpg;
+    double S = 0.0, Q = 0.0;
+    auto sweep = [&](const GnSource& src, int lo, int hi) {        // channels [lo, hi) of this source
+        const int w = hi - lo;
+        if (w <= 0) return;
+        const float2* base = src.part + (size_t)n * src.tiles_per_image * src.C + lo;
+        const int total = w * src.tiles_per_image;
+        for (int k = t_; k < total; k += 256) {
+            const int t = k / w, c = k - t * w;
+            const float2 v = base[(size_t)t * src.C + c];
+            S += (double)v.x; Q += (double)v.y;
+        }
+    };
+    const int c_hi = c_lo + cpg;
+    sweep(s0, min(c_lo, s0.C), min(c_hi, s0.C));
+    sweep(s1, max(c_lo, s0.C) - s0.C, max(c_hi, s0.C) - s0.C);
+    __shared__ double red[2][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { S += __shfl_xor(S, o, 64); Q += __shfl_xor(Q, o, 64); }
+    if ((t_ & 63) == 0) { red[0][t_ >> 6] = S; red[1][t_ >> 6] = Q; }
+    __syncthreads();
+    if (t_ == 0) {
+        S = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        Q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const double mean = S / count;
+        const double var = fmax(Q / count - mean * mean, 0.0);
+        stats[i] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+    }
+    (void)NG;
+}
+
+template <typename T>
+static int gn_from_stats_launch(const void* x, const void* gamma, const void* beta, void* y, int N, int C, int HW, int G, float eps,
+                                int silu, GnSource s0, GnSource s1, void* ws, hipStream_t st) {
+    ST_REQUIRE(C % Elem<T>::VEC == 0, "group_norm_from_stats: C=%d must be a multiple of %d", C, Elem<T>::VEC);
+    GnGeom g = gn_geom<T>(C, HW);
+    ST_REQUIRE(g.VC <= GN_THREADS, "group_norm_from_stats: C=%d too wide", C);
+    float2* stats = (float2*)ws;
+    hipLaunchKernelGGL(gn_cols_finalize, dim3(N * G), dim3(256), 0, st, s0, s1, stats, G, N * G, C / G,
+                       (double)(C / G) * (double)HW, eps);
+    if (silu)
+        hipLaunchKernelGGL((gn_apply_nhwc<T, true>), dim3(g.NB, N), dim3(GN_THREADS), 0, st, (const T*)x, (const T*)gamma,
+                           (const T*)beta, stats, (T*)y, C, HW, G, g.VC, g.RP, g.P);
+    else
+        hipLaunchKernelGGL((gn_apply_nhwc<T, false>), dim3(g.NB, N), dim3(GN_THREADS), 0, st, (const T*)x, (const T*)gamma,
+                           (const T*)beta, stats, (T*)y, C, HW, G, g.VC, g.RP, g.P);
+    return st_check_launch("group_norm_from_stats");
+}
+
+extern "C" int st_group_norm_from_stats(const void* x, const void* gamma, const void* beta, void* y, int N, int C, int HW,
+                                        int groups, float eps, int silu, int dtype, const float* stats0, int C0, int rows0,
+                                        const float* stats1, int C1, int rows1, void* workspace, void* stream) {
+    ST_REQUIRE(x && gamma && beta && y && workspace && stats0, "group_norm_from_stats: null pointer");
+    ST_REQUIRE(N > 0 && C > 0 && HW > 0 && groups > 0 && C % groups == 0, "group_norm_from_stats: bad shape N=%d C=%d HW=%d G=%d", N, C, HW, groups);
+    ST_REQUIRE(groups <= 1024 && N <= 65535, "group_norm_from_stats: shape exceeds launch limits");
+    ST_REQUIRE(C0 > 0 && rows0 > 0 && HW % rows0 == 0, "group_norm_from_stats: source 0 has %d rows per partial for HW=%d", rows0, HW);
+    ST_REQUIRE((stats1 == nullptr && C1 == 0 && C0 == C) || (stats1 && C1 > 0 && rows1 > 0 && HW % rows1 == 0 && C0 + C1 == C),
+               "group_norm_from_stats: sources cover %d + %d channels, input has %d", C0, C1, C);
+    GnSource s0 = {(const float2*)stats0, C0, HW / rows0};
+    GnSource s1 = {(const float2*)stats1, C1, stats1 ? HW / rows1 : 0};
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ST_BF16) return gn_from_stats_launch<bf16>(x, gamma, beta, y, N, C, HW, groups, eps, silu, s0, s1, workspace, st);
+    if (dtype == ST_F32) return gn_from_stats_launch<float>(x, gamma, beta, y, N, C, HW, groups, eps, silu, s0, s1, workspace, st);
+    return st_fail("group_norm_from_stats: unsupported dtype %d", dtype);
+}
+
 // =============================================================================
 // LayerNorm: one wave per row, row held in registers, exact two-pass variance.
 // =============================================================================

@@ -281,6 +281,52 @@ def group_norm(x: torch.Tensor, num_groups: int, weight: torch.Tensor, bias: tor
     return y
 
 
+class ColStats:
+    """GroupNorm partials a GEMM / conv left beside its output: (tiles, C) float2 = per tile row of the launch and per
+    channel (sum, sum of squares); `rows` = rows per tile row."""
+    __slots__ = ("buf", "rows", "channels")
+
+    def __init__(self, buf: torch.Tensor, rows: int, channels: int):
+        self.buf, self.rows, self.channels = buf, rows, channels
+
+
+COLSTATS_MIN_ROWS = 64         # smallest tile height of any GEMM configuration: sizes the partial buffers
+
+
+def _colstats_buffer(M: int, N: int, device):
+    import ctypes
+    tiles = (M + COLSTATS_MIN_ROWS - 1) // COLSTATS_MIN_ROWS
+    return torch.empty((tiles, N, 2), dtype=torch.float32, device=device), tiles, ctypes.c_int(0)
+
+
+def group_norm_from_stats(x: torch.Tensor, sources, num_groups: int, weight: torch.Tensor, bias: torch.Tensor,
+                          eps: float, silu: bool) -> torch.Tensor:
+    """GroupNorm(+SiLU) of a channels_last x whose statistics its producer(s) emitted (`sources`: one ColStats, or two for
+    a channel concatenation; None entries = that producer could not emit): no statistics pass over x.  Falls back to
+    `group_norm` when a source is missing."""
+    if any(s is None for s in sources) or not _is_nhwc(x) or not 1 <= len(sources) <= 2:
+        return group_norm(x, num_groups, weight, bias, eps, silu)
+    _C.require_device(x, weight, bias)
+    lib = _C.load()
+    N, Cc = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * Cc)
+    if sum(s.channels for s in sources) != Cc or any(HW % s.rows for s in sources):
+        return group_norm(x, num_groups, weight, bias, eps, silu)
+    y = torch.empty_like(x)
+    w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+    b = bias if bias.dtype == x.dtype else bias.to(x.dtype)
+    ws = torch.empty(lib.st_group_norm_workspace_bytes(N, Cc, HW, num_groups), dtype=torch.uint8, device=x.device)
+    s0 = sources[0]
+    s1 = sources[1] if len(sources) == 2 else None
+    _label(f"N={N} C={Cc} HW={HW} silu={int(bool(silu))} from-stats")
+    _C.check(_timed("group_norm", 0.0, 2.0 * x.numel() * x.element_size(), lib.st_group_norm_from_stats, x.data_ptr(), w.data_ptr(),
+                    b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups, float(eps), int(bool(silu)), _C.dtype_code(x.dtype),
+                    s0.buf.data_ptr(), s0.channels, s0.rows, None if s1 is None else s1.buf.data_ptr(),
+                    0 if s1 is None else s1.channels, 0 if s1 is None else s1.rows, ws.data_ptr(), _C.stream_ptr()),
+             "group_norm_from_stats")
+    return y
+
+
 def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> torch.Tensor:
     _C.require_device(x, weight, bias)
     lib = _C.load()
@@ -332,10 +378,11 @@ class RowStats:
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, silu: bool = False,
-           geglu: bool = False, residual: Optional[torch.Tensor] = None, emit_stats: bool = False):
+           geglu: bool = False, residual: Optional[torch.Tensor] = None, emit_stats: bool = False, emit_colstats: bool = False):
     """epilogue(x @ weight.T): +bias, then SiLU or GEGLU (weight has 2N rows), then +residual.
     With emit_stats the GEMM also writes the LayerNorm partials of its output rows and the call
-    returns (out, RowStats)."""
+    returns (out, RowStats).  With emit_colstats (x is (B, T, K): T tokens per image) it writes the GroupNorm partials
+    of its output columns and the call returns (out, ColStats or None)."""
     _C.require_device(x, weight, bias, residual)
     lib = _C.load()
     K = x.shape[-1]
@@ -371,12 +418,23 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         stats = torch.empty((M, cap, 2), dtype=torch.float32, device=x.device)
         chunks = ctypes.c_int(0)
     nxt_p, nxt_b = _next_weights(w)
-    _label(f"M={M} N={N} K={K} epi={epi}{' stats' if emit_stats else ''}")
+    cbuf = ctiles = crows = None
+    rows_per_image = 0
+    if emit_colstats:
+        import ctypes
+        if x.dim() != 3:
+            raise BackendError("linear: emit_colstats needs a (batch, tokens, K) input")
+        rows_per_image = x.shape[1]
+        cbuf, ctiles, crows = _colstats_buffer(M, N, x.device)
+    _label(f"M={M} N={N} K={K} epi={epi}{' stats' if emit_stats else ''}{' colstats' if emit_colstats else ''}")
     _C.check(_timed("linear", 2.0 * M * w.shape[0] * K, float((M * K + w.numel() + M * N) * x.element_size()),
                     lib.st_linear, x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
-                    lda, N, ldr, 0, epi, _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(),
+                    lda, N, ldr, rows_per_image, epi, _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(),
                     _ptr(stats), 0 if stats is None else stats.shape[1],
-                    None if chunks is None else ctypes.byref(chunks), nxt_p, nxt_b, _C.stream_ptr()), "linear")
+                    None if chunks is None else ctypes.byref(chunks), _ptr(cbuf), ctiles or 0,
+                    None if crows is None else ctypes.byref(crows), nxt_p, nxt_b, _C.stream_ptr()), "linear")
+    if emit_colstats:
+        return out, (ColStats(cbuf, crows.value, N) if crows.value > 0 else None)
     if emit_stats:
         if chunks.value <= 0:
             raise BackendError("linear: this shape cannot emit LayerNorm row statistics (K must be a multiple of the K tile)")
@@ -528,10 +586,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int,
 # ----------------------------------------------------------------------------- conv
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, padding: int, *,
            upsample2x: bool = False, rowbias: Optional[torch.Tensor] = None,
-           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+           residual: Optional[torch.Tensor] = None, emit_colstats: bool = False):
     """NHWC implicit-GEMM conv.  x: (N,C,H,W) logical; returns a channels_last tensor.
     rowbias (N,Cout) is added per image (time-embedding projection); residual is
-    (N,Cout,Hout,Wout) channels_last."""
+    (N,Cout,Hout,Wout) channels_last.  With emit_colstats the conv also writes the GroupNorm partials of its output
+    channels and the call returns (out, ColStats or None)."""
     _C.require_device(x, weight, bias, rowbias, residual)
     lib = _C.load()
     if x.dim() != 4 or weight.dim() != 4:
@@ -566,11 +625,18 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
         epi |= _C.EPI_RESIDUAL
     gws = _gemm_workspace(x.device)
     nxt_p, nxt_b = _next_weights(w)
-    _label(f"Cin={Cin} H={H} Cout={Cout} k={R} s={stride} ups={int(upsample2x)} epi={epi}")
+    cbuf = ctiles = crows = None
+    if emit_colstats:
+        import ctypes
+        cbuf, ctiles, crows = _colstats_buffer(N * Ho * Wo, Cout, x.device)
+    _label(f"Cin={Cin} H={H} Cout={Cout} k={R} s={stride} ups={int(upsample2x)} epi={epi}{' colstats' if emit_colstats else ''}")
     _C.check(_timed("conv2d", 2.0 * N * Ho * Wo * Cout * R * S * Cin,
                     float((x.numel() + w.numel() + out.numel()) * x.element_size()), lib.st_conv2d, x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(rowbias), out.data_ptr(),
                            N, H, W, Cin, Cout, R, S, stride, padding, int(upsample2x), epi,
-                           _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(), nxt_p, nxt_b, _C.stream_ptr()), "conv2d")
+                           _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(), _ptr(cbuf), ctiles or 0,
+                           None if crows is None else ctypes.byref(crows), nxt_p, nxt_b, _C.stream_ptr()), "conv2d")
+    if emit_colstats:
+        return out, (ColStats(cbuf, crows.value, Cout) if crows.value > 0 else None)
     return out
 
 

@@ -71,11 +71,20 @@ def timestep_embedding_wrapper(t: torch.Tensor, dim: int) -> torch.Tensor:
 
 
 def conv2d_wrapper(v: torch.Tensor, conv: nn.Conv2d, upsample2x: bool = False,
-                   rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, emit_colstats: bool = False):
+    """`emit_colstats` (addition): also return the GroupNorm partials of the output channels, for a following
+    `group_norm_stats_wrapper`; the result is then the pair (out, stats)."""
     s, p = conv.stride, conv.padding
     if s[0] != s[1] or p[0] != p[1] or conv.dilation != (1, 1) or conv.groups != 1 or isinstance(p, str):
         raise ops.BackendError("conv2d_wrapper: only square stride/padding, dilation 1, groups 1")
-    return ops.conv2d(v, conv.weight, conv.bias, s[0], p[0], upsample2x=upsample2x, rowbias=rowbias, residual=residual)
+    return ops.conv2d(v, conv.weight, conv.bias, s[0], p[0], upsample2x=upsample2x, rowbias=rowbias, residual=residual,
+                      emit_colstats=emit_colstats)
+
+
+def group_norm_stats_wrapper(v: torch.Tensor, stats, groupnorm: nn.GroupNorm, activation: bool) -> torch.Tensor:
+    """group_norm_wrapper whose statistics come from the launch(es) that produced `v` (`stats`: one ColStats, or two
+    for a channel concatenation): finalize + apply, no statistics pass over v."""
+    return ops.group_norm_from_stats(v, tuple(stats), groupnorm.num_groups, groupnorm.weight, groupnorm.bias, groupnorm.eps, activation)
 
 
 def linear_geglu_wrapper(v: torch.Tensor, linear: nn.Linear) -> torch.Tensor:
@@ -83,13 +92,14 @@ def linear_geglu_wrapper(v: torch.Tensor, linear: nn.Linear) -> torch.Tensor:
     return ops.linear(v, linear.weight, linear.bias, geglu=True)
 
 
-def linear_residual_wrapper(v: torch.Tensor, linear: nn.Linear, residual: torch.Tensor, emit_stats: bool = False):
-    return ops.linear(v, linear.weight, linear.bias, residual=residual, emit_stats=emit_stats)
+def linear_residual_wrapper(v: torch.Tensor, linear: nn.Linear, residual: torch.Tensor, emit_stats: bool = False,
+                            emit_colstats: bool = False):
+    return ops.linear(v, linear.weight, linear.bias, residual=residual, emit_stats=emit_stats, emit_colstats=emit_colstats)
 
 
 for _name in ("attention_wrapper", "geglu_triton", "group_norm_wrapper", "layer_norm_wrapper", "linear_wrapper",
               "linear_wrapper_functional", "timestep_wrapper", "timestep_embedding_wrapper", "conv2d_wrapper", "linear_geglu_wrapper",
-              "linear_residual_wrapper"):
+              "linear_residual_wrapper", "group_norm_stats_wrapper"):
     torch.fx.wrap(_name)
 
 

@@ -59,6 +59,7 @@ def test_pass_counts_match_reference_probe_on_sdxl():
         assert gm.rewrite_stats[k] == v, (k, gm.rewrite_stats[k], v)
     assert gm.rewrite_stats["geglu_in_gemm"] == 70 and gm.rewrite_stats["temb_rowbias"] == 17
     assert gm.rewrite_stats["layer_norm_in_gemm"] == 210 and gm.rewrite_stats["shared_input_gemms"] == 72
+    assert gm.rewrite_stats["group_norm_stats"] == 46          # every GroupNorm reads a conv / GEMM output or a cat of two
     _install_context_split(gm)
     assert gm.rewrite_stats["context_outputs"] == 140 and gm.rewrite_stats["time_outputs"] == 1
     # no M=batch GEMM is left in the per-step graph: the whole time path lives in gm.time_module
@@ -77,13 +78,15 @@ def _cpu_backend(monkeypatch):
     monkeypatch.setattr(ops, "layer_norm", lambda x, w, b, eps: F.layer_norm(x, w.shape, w, b, eps))
     monkeypatch.setattr(ops, "geglu", lambda s, g: s * F.gelu(g))
 
-    def linear(x, w, b=None, *, silu=False, geglu=False, residual=None, emit_stats=False):
+    def linear(x, w, b=None, *, silu=False, geglu=False, residual=None, emit_stats=False, emit_colstats=False):
         y = F.linear(x, w, b)
         if silu:
             y = F.silu(y)
         if geglu:
             y = orc.geglu(y)
         y = y if residual is None else y + residual
+        if emit_colstats:
+            return y, "colstats"
         return (y, "stats") if emit_stats else y
     monkeypatch.setattr(ops, "linear", linear)
 
@@ -96,14 +99,20 @@ def _cpu_backend(monkeypatch):
     monkeypatch.setattr(ops, "ln_linear", ln_linear)
     monkeypatch.setattr(ops, "attention", lambda q, k, v, h, scale: orc.attention_core(q, k, v, h))
 
-    def conv2d(x, w, b, stride, padding, *, upsample2x=False, rowbias=None, residual=None):
+    def conv2d(x, w, b, stride, padding, *, upsample2x=False, rowbias=None, residual=None, emit_colstats=False):
         if upsample2x:
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         y = F.conv2d(x, w, b, stride=stride, padding=padding)
         if rowbias is not None:
             y = y + rowbias[:, :, None, None]
-        return y if residual is None else y + residual
+        y = y if residual is None else y + residual
+        return (y, "colstats") if emit_colstats else y
     monkeypatch.setattr(ops, "conv2d", conv2d)
+
+    def group_norm_from_stats(x, sources, g, w, b, eps, silu):
+        assert all(s == "colstats" for s in sources) and 1 <= len(sources) <= 2
+        return (F.silu if silu else (lambda t: t))(F.group_norm(x, g, w, b, eps))
+    monkeypatch.setattr(ops, "group_norm_from_stats", group_norm_from_stats)
     monkeypatch.setattr(ops, "timestep_features", lambda t, dim, dtype, **kw: orc.timestep_features(t, dim).to(dtype))
 
 

@@ -254,3 +254,63 @@ def test_ops_fail_loudly(gpu):
     with pytest.raises(ops.BackendError):
         ops.attention(torch.zeros(1, 8, 96, device=gpu), torch.zeros(1, 8, 96, device=gpu),
                       torch.zeros(1, 8, 96, device=gpu), 3, 1.0)   # head_dim 32 unsupported
+
+
+# ---------------------------------------------------------------------------------- GroupNorm statistics from the producer
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,Cin,H,Cout,k,ups", [(1, 320, 32, 320, 3, False), (2, 640, 32, 1280, 3, False), (1, 128, 64, 200, 3, False),
+                                                (1, 960, 32, 320, 1, False), (1, 64, 32, 160, 3, True), (1, 320, 64, 640, 3, False)])
+def test_conv_column_partials_and_group_norm_from_them(gpu, dtype, N, Cin, H, Cout, k, ups):
+    """A conv that also emits per-channel (sum, sum of squares) of what it stored, and the GroupNorm(+SiLU) that runs on
+    those partials instead of its own statistics pass - against the oracle's conv -> group_norm."""
+    cl = torch.channels_last
+    x = rnd("cs.x", (N, Cin, H, H))
+    w = rnd("cs.w", (Cout, Cin, k, k), (Cin * k * k) ** -0.5)
+    b = rnd("cs.b", (Cout,), 0.5)                         # a visible mean per channel
+    g, be = rnd("cs.g", (Cout,)) * 0.2 + 1.0, rnd("cs.be", (Cout,)) * 0.2
+    xr = rounded(x, dtype)
+    if ups:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    conv_ref = F.conv2d(xr, rounded(w, dtype), rounded(b, dtype), padding=k // 2)
+    out, st = ops.conv2d(x.to(gpu, dtype).contiguous(memory_format=cl), w.to(gpu, dtype).contiguous(memory_format=cl), b.to(gpu, dtype),
+                         1, k // 2, upsample2x=ups, emit_colstats=True)
+    assert st is not None and st.channels == Cout and (out.shape[2] * out.shape[3]) % st.rows == 0
+    tiles = N * out.shape[2] * out.shape[3] // st.rows
+    part = st.buf[:tiles].double()
+    stored = out.float().permute(0, 2, 3, 1).reshape(tiles, st.rows, Cout).double()
+    assert torch.allclose(part[..., 0], stored.sum(1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(part[..., 1], (stored * stored).sum(1), rtol=1e-5, atol=1e-3)
+    groups = 32 if Cout % 32 == 0 else 8
+    for silu in (False, True):
+        y = ops.group_norm_from_stats(out, (st,), groups, g.to(gpu, dtype), be.to(gpu, dtype), 1e-5, silu)
+        ref = F.group_norm(conv_ref if dtype == torch.float32 else rounded(conv_ref, dtype), groups, rounded(g, dtype), rounded(be, dtype), 1e-5)
+        ref = F.silu(ref) if silu else ref
+        assert y.stride() == out.stride()
+        assert_close(y, ref, dtype, "group_norm_from_stats", factor=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_group_norm_from_two_sources_unaligned_groups(gpu, dtype):
+    """The decoder case (unet_pt.py:352-357): GroupNorm over cat([a, b]) where a comes from a GEMM epilogue (tokens) and b
+    from a conv, 1280 + 640 channels in 32 groups of 60 - group 21 straddles the two sources."""
+    cl = torch.channels_last
+    B, H = 2, 32
+    xa, wa, ra = rnd("g2.xa", (B, H * H, 256)), rnd("g2.wa", (1280, 256), 256 ** -0.5), rnd("g2.ra", (B, H * H, 1280))
+    a, sa = ops.linear(xa.to(gpu, dtype), wa.to(gpu, dtype), None, residual=ra.to(gpu, dtype), emit_colstats=True)
+    xb, wb = rnd("g2.xb", (B, 128, H, H)), rnd("g2.wb", (640, 128, 3, 3), (128 * 9) ** -0.5)
+    bb, sb = ops.conv2d(xb.to(gpu, dtype).contiguous(memory_format=cl), wb.to(gpu, dtype).contiguous(memory_format=cl), None, 1, 1,
+                        emit_colstats=True)
+    assert sa is not None and sb is not None
+    a_img = a.reshape(B, H, H, 1280).permute(0, 3, 1, 2)
+    cat = torch.cat([a_img, bb], dim=1).contiguous(memory_format=cl)
+    g, be = rnd("g2.g", (1920,)) * 0.2 + 1.0, rnd("g2.be", (1920,)) * 0.2
+    y = ops.group_norm_from_stats(cat, (sa, sb), 32, g.to(gpu, dtype), be.to(gpu, dtype), 1e-5, True)
+    ref = F.silu(F.group_norm(cat.float().cpu(), 32, rounded(g, dtype), rounded(be, dtype), 1e-5))
+    assert_close(y, ref, dtype, "group_norm_from_stats(cat)")
+    # a producer that cannot emit (thin conv_in kernel) -> the wrapper falls back to the three-launch GroupNorm
+    xi, wi = rnd("g2.xi", (1, 4, 32, 32)), rnd("g2.wi", (320, 4, 3, 3), 36 ** -0.5)
+    ci, si = ops.conv2d(xi.to(gpu, dtype).contiguous(memory_format=cl), wi.to(gpu, dtype).contiguous(memory_format=cl), None, 1, 1,
+                        emit_colstats=True)
+    assert si is None
+    y2 = ops.group_norm_from_stats(ci, (si,), 32, g[:320].to(gpu, dtype), be[:320].to(gpu, dtype), 1e-5, False)
+    assert_close(y2, F.group_norm(ci.float().cpu(), 32, rounded(g[:320], dtype), rounded(be[:320], dtype), 1e-5), dtype, "fallback")
