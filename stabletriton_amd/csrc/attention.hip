@@ -45,10 +45,37 @@ __device__ __forceinline__ unsigned long long att_now() {
 #define AP_ADD(a, t1, t0)
 #endif
 
+#ifdef ST_PROBE
+#define ATT_PROBE_ARG g_att_probe
+#else
+#define ATT_PROBE_ARG nullptr
+#endif
+
+#ifndef ST_ATT_PRIO
+#define ST_ATT_PRIO 1
+#endif
 static constexpr int ATT_D = 64;
 static constexpr int ATT_KV = 64;          // keys per tile
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+typedef __attribute__((address_space(3))) void att_lds_void_t;
+typedef __attribute__((address_space(1))) const void att_gbl_cvoid_t;
+
+// LDS-DMA issue in assembly.  The builtin form makes hipcc 7.2 treat every later ds_read_b64_tr_b16 (an intrinsic it
+// takes for a possible LDS store) as dependent on the DMA: it puts s_waitcnt vmcnt(0) in front of the first transposed
+// read after each issue, i.e. the wave waits out the flight time of the tile it has just requested.  Issued from asm,
+// the DMA is invisible to that pass and only the kernel's own counted waits apply.  lds_off: wave-uniform byte offset.
+__device__ __forceinline__ void att_dma16(const void* src, unsigned lds_off) {
+#ifdef ATT_X_BUILTIN
+    __builtin_amdgcn_global_load_lds((att_gbl_cvoid_t*)src, (att_lds_void_t*)(size_t)lds_off, 16, 0, 0);
+    return;
+#endif
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_off) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned att_lds_offset(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
 
 // max / sum with the lane 32 (or 16) away, through v_permlane32_swap / v_permlane16_swap instead of a
 // ds_bpermute: no LDS round trip and, above all, no s_waitcnt lgkmcnt(0) in the middle of the softmax
@@ -93,8 +120,6 @@ __device__ __forceinline__ void v_tile_wait(VTile& v) {
 __device__ __forceinline__ int swz_k(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 1) << 2; }
 
-typedef __attribute__((address_space(3))) void att_lds_void_t;
-typedef __attribute__((address_space(1))) const void att_gbl_cvoid_t;
 __device__ __attribute__((aligned(16))) unsigned int g_att_zero16[4] = {0u, 0u, 0u, 0u};
 
 // Pipeline per 64-key tile t (one barrier per tile, three LDS tile buffers filled by LDS-DMA):
@@ -521,12 +546,11 @@ __device__ __forceinline__ bf16x8 pack8(float a0, float a1, float a2, float a3, 
     return r;
 }
 
-// fmaxf on MFMA outputs makes hipcc canonicalise each operand first (v_max_f32 x, x, x): one instruction instead
-__device__ __forceinline__ float att_max3(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+// Three-way maximum, deliberately NOT inline asm: the scores it reads come straight out of MFMAs, and the hardware does
+// not interlock an MFMA result against a VALU read - the compiler inserts the wait states, but only for instructions it
+// can see.  An asm v_max3_f32 here read accumulators that were still being written whenever the matrix pipe was shared
+// with another kernel (tools/att_race.py: output changed by 1 ulp when a second stream kept the CUs busy).
+__device__ __forceinline__ float att_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
 template <int NW, int TAG>
 __global__ __launch_bounds__(NW * 64) void attn16v2_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
@@ -929,6 +953,623 @@ __global__ __launch_bounds__(NW * KS * 64) void attn32v2_kernel(const bf16* __re
     }
 }
 
+// ---- 32-row kernel, staggered: eight waves whose two halves take turns on the matrix pipe -----------
+// In attn32v2_kernel the two waves of a SIMD belong to one block and meet at the same barrier every tile, so they run
+// in step: both multiply at once (fighting over the pipe), both do softmax at once (pipe idle).  Here a trip is two
+// phases separated by block barriers,
+//     V: the softmax of this tile's scores -> bf16 P fragments                       (VALU only)
+//     M: twelve P V MFMAs, then the eight K Q^T MFMAs of the next tile, and between them the LDS reads of the NEXT
+//        trip's fragments (V^T of tile k+1 into the registers the P V MFMAs have just consumed, K of tile k+2 likewise)
+//        and the DMA issue of tile k+4 - the loads land while the wave is in its next V phase
+// and waves 4-7 - the second wave of every SIMD - run one phase behind waves 0-3 (one extra barrier up front, repaid
+// at the end): while one half multiplies, the other half's softmax runs on the VALU of the same SIMD.  Measured with
+// in-kernel stamps (tools/att_probe2.py): M = 690 cycles; a V phase that also carried the fragment reads and the DMA
+// issue took 2150 (one wave cannot hide its own LDS / DMA latencies), the softmax alone 790.
+// Eight row waves (256 query rows) share one ring of six K/V tiles.  Tile t is issued at the top of V(t-4), retired by
+// the issuing wave's counted vmcnt at the end of V(t-3) (one DMA group of its own is younger: a full trip of flight
+// time), first read - K fragments - in M(t-2): for the early half that is two barriers after the late half retired its
+// pieces.  Fragment reads are retired (lgkmcnt(0)) before the barrier that ends a V phase, so a slot is free for the
+// DMA of tile t+6 two phases after the late half's last read of tile t.
+template <bool STG>
+__global__ __launch_bounds__(512) void attn32s_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                      const bf16* __restrict__ V, bf16* __restrict__ O,
+                                                      int T, int S, long ldq, long ldk, long ldv, long ldo, float scale_log2e,
+                                                      unsigned long long* probe) {
+    constexpr int NW = 8;
+    constexpr int TILE_B = ATT_KV * 128;
+    constexpr int BUF_B = 2 * TILE_B;
+    constexpr int RB = 6;                             // ring buffers
+    constexpr int PIECES = 16 / NW;
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // the ring, then a 1-KiB dump for the dummy DMAs
+    char* const dump = lds + RB * BUF_B;
+#ifdef ST_PROBE
+    unsigned long long pv = 0, pvw = 0, pm = 0, pmw = 0;
+#endif
+
+    const int t_ = threadIdx.x, lane = t_ & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t_ >> 6);
+    const int late = wave >> 2;                       // 1: this wave runs one phase behind
+    const int r32 = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = (blockIdx.x * NW + wave) * 32;
+    const int qrow = min(q0 + r32, T - 1);
+
+    const bf16* Qb = Q + (size_t)b * T * ldq + (size_t)head * ATT_D;
+    const bf16* Kb = K + (size_t)b * S * ldk + (size_t)head * ATT_D;
+    const bf16* Vb = V + (size_t)b * S * ldv + (size_t)head * ATT_D;
+    const bf16* zeros = reinterpret_cast<const bf16*>(g_att_zero16);
+
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 raw = *reinterpret_cast<const bf16x8*>(Qb + (size_t)qrow * ldq + 16 * ks + 8 * h);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (bf16)((float)raw[j] * scale_log2e);
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)(r32 == 0 ? 1.0f : 0.0f);
+
+    const int nkt = (S + ATT_KV - 1) / ATT_KV;
+    const int lr = lane >> 3, pc = lane & 7;
+    const bf16* dsrc[PIECES];
+    long dstep[PIECES];
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int pce = wave * PIECES + i;
+        const int isv = pce >> 3, row = (pce & 7) * 8 + lr;
+        const int c = pc ^ (isv ? swz_v(row) : swz_k(row));
+        dsrc[i] = isv ? Vb + (size_t)row * ldv + c * 8 : Kb + (size_t)row * ldk + c * 8;
+        dstep[i] = (long)ATT_KV * (isv ? ldv : ldk);
+    }
+    // tiles are issued in order kt = 0, 1, 2, ...; past the last tile the pieces become dummies (one zero line into the
+    // dump area) so that every trip issues the same number of DMAs and the counted waits stay valid
+    int dbuf = 0;                                     // ring slot of the next tile to issue
+    auto dma_tile = [&](int kt) {
+        char* const slot = lds + dbuf * BUF_B;
+        if ((kt + 1) * ATT_KV <= S) {                 // a whole tile inside S: no per-lane checks, three instructions per piece
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int pce = wave * PIECES + i;
+                __builtin_amdgcn_global_load_lds((att_gbl_cvoid_t*)dsrc[i], (att_lds_void_t*)(slot + (pce >> 3) * TILE_B + (pce & 7) * 1024), 16, 0, 0);
+            }
+        } else {                                      // the tile that reaches past S, and the dummies after the last tile
+            const bool live = kt < nkt;
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int pce = wave * PIECES + i;
+                const int isv = pce >> 3, rb = pce & 7;
+                const bf16* src = (live && kt * ATT_KV + rb * 8 + lr < S) ? dsrc[i] : zeros;
+                __builtin_amdgcn_global_load_lds((att_gbl_cvoid_t*)src, (att_lds_void_t*)(live ? slot + isv * TILE_B + rb * 1024 : dump), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) dsrc[i] += dstep[i];
+        dbuf = dbuf == RB - 1 ? 0 : dbuf + 1;
+    };
+    // STG: the pieces travel through registers instead (global_load a trip ahead, ds_write at the top of the next V
+    // phase) - a DMA instruction costs the issuing wave ~200 cycles, a global_load + ds_write_b128 pair a few tens
+    typedef unsigned int stg_t __attribute__((ext_vector_type(4)));
+    stg_t stg[PIECES];
+    auto load_tile = [&](int kt) {                    // tile kt -> registers
+        if (kt < nkt) {
+            const bool whole = (kt + 1) * ATT_KV <= S;
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int rb = (wave * PIECES + i) & 7;
+                const bf16* src = (whole || kt * ATT_KV + rb * 8 + lr < S) ? dsrc[i] : zeros;
+                stg[i] = *reinterpret_cast<const stg_t*>(src);
+                dsrc[i] += dstep[i];
+            }
+        }
+    };
+    auto store_tile = [&](int kt) {                   // registers -> ring slot of tile kt
+        if (kt < nkt) {
+            char* const slot = lds + dbuf * BUF_B;
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int pce = wave * PIECES + i;
+                *reinterpret_cast<stg_t*>(slot + (pce >> 3) * TILE_B + (pce & 7) * 1024 + lane * 16) = stg[i];
+            }
+        }
+        dbuf = dbuf == RB - 1 ? 0 : dbuf + 1;
+    };
+    int v_base0, v_base1;
+    {
+        const int q4 = (lane & 15) >> 2;
+        const int key = 4 * h + q4;
+        const int ch0 = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+        const int row = key * 128 + 8 * (lane & 1);
+        v_base0 = row + ((ch0 ^ swz_v(key)) << 4);
+        v_base1 = row + (((ch0 + 4) ^ swz_v(key)) << 4);
+    }
+    int k_off[4][2];                                  // K fragment offsets [k-step][key half]
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int c = 2 * ks + h;
+        k_off[ks][0] = r32 * 128 + ((c ^ swz_k(r32)) << 4);
+        k_off[ks][1] = (32 + r32) * 128 + ((c ^ swz_k(32 + r32)) << 4);
+    }
+    float m_ref = 0.f;
+    f32x16 o0 = {0}, o1 = {0}, o2 = {0};
+    bf16x8 kf0[4], kf1[4], vf[4][2], pb[4];
+
+    // prologue: four tiles in flight, the first three landed; scores of tile 0; fragments of the first M phase
+    dma_tile(0); dma_tile(1); dma_tile(2);
+    if constexpr (STG) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        load_tile(3);
+    } else {
+        dma_tile(3);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    f32x16 sa0, sa1, sb0, sb1;
+    {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf0[ks] = *reinterpret_cast<const bf16x8*>(lds + k_off[ks][0]);
+            kf1[ks] = *reinterpret_cast<const bf16x8*>(lds + k_off[ks][1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa0[r] = 0.f; sa1[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], sa0, 0, 0, 0);
+            sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], sa1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {                 // V^T of tile 0, K of tile 1
+            vf[s_][0] = v_frag(lds + TILE_B, v_base0 + s_ * 2048, v_base0 + s_ * 2048 + 1024);
+            vf[s_][1] = v_frag(lds + TILE_B, v_base1 + s_ * 2048, v_base1 + s_ * 2048 + 1024);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf0[ks] = *reinterpret_cast<const bf16x8*>(lds + BUF_B + k_off[ks][0]);
+            kf1[ks] = *reinterpret_cast<const bf16x8*>(lds + BUF_B + k_off[ks][1]);
+        }
+    }
+    if (late) __builtin_amdgcn_s_barrier();          // the second half runs one phase behind the first
+
+    int vslot = 1, kslot = 2;                         // ring slots of tile kt+1 (V^T) and tile kt+2 (K)
+    auto trip = [&](f32x16& s0, f32x16& s1, f32x16& n0, f32x16& n1, int kt) {
+        // ---- phase V: DMA issue of tile kt+4, softmax of tile kt ----
+        AP_STAMP(t0)
+        if constexpr (STG) {
+            store_tile(kt + 3);
+            load_tile(kt + 4);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            dma_tile(kt + 4);
+        }
+        if ((kt + 1) * ATT_KV > S) {
+            const int kbase = kt * ATT_KV + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kbase + (r & 3) + 8 * (r >> 2);
+                if (key >= S) s0[r] = -INFINITY;
+                if (key + 32 >= S) s1[r] = -INFINITY;
+            }
+        }
+        // four independent maximum chains (one dependent chain of sixteen v_max3 is all latency)
+        float ma = att_max3(s0[0], s0[1], s0[2]), mb = att_max3(s0[8], s0[9], s0[10]);
+        float mc = att_max3(s1[0], s1[1], s1[2]), md = att_max3(s1[8], s1[9], s1[10]);
+        ma = att_max3(ma, s0[3], s0[4]); mb = att_max3(mb, s0[11], s0[12]); mc = att_max3(mc, s1[3], s1[4]); md = att_max3(md, s1[11], s1[12]);
+        ma = att_max3(ma, s0[5], s0[6]); mb = att_max3(mb, s0[13], s0[14]); mc = att_max3(mc, s1[5], s1[6]); md = att_max3(md, s1[13], s1[14]);
+        ma = fmaxf(ma, s0[7]); mb = fmaxf(mb, s0[15]); mc = fmaxf(mc, s1[7]); md = fmaxf(md, s1[15]);
+        const float mx = fmaxf(fmaxf(ma, mb), fmaxf(mc, md));
+        if (kt == 0 || __any(mx > ATT_LAG)) {
+            // exact path (first tile, or a row outran the lag): see attn16v2_kernel; the next tile's scores do not exist yet
+            const float rmx = xmax32(mx);
+            const float delta = ((kt == 0 || rmx > ATT_LAG) && rmx > -INFINITY) ? rmx : 0.f;
+            const float alpha = kt == 0 ? 1.f : fast_exp2(-delta);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s0[r] -= delta; s1[r] -= delta;
+                o0[r] *= alpha; o1[r] *= alpha; o2[r] *= alpha;
+            }
+            m_ref += delta;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = fast_exp2(s0[r]); s1[r] = fast_exp2(s1[r]); }
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            const f32x16& sx = s_ < 2 ? s0 : s1;
+            const int e = 8 * (s_ & 1);
+            pb[s_] = pack8(sx[e], sx[e + 1], sx[e + 2], sx[e + 3], sx[e + 4], sx[e + 5], sx[e + 6], sx[e + 7]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        AP_STAMP(t1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the fragment reads issued in the last M phase are in registers
+        if constexpr (!STG)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");   // own pieces of tile kt+3 (issued a trip ago) have landed; tile kt+4's may fly
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase M: the matrix pipe, with the next trip's loads between the MFMAs ----
+        AP_STAMP(t2)
+        {
+            const char* vb = lds + vslot * BUF_B + TILE_B;
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s_][0], pb[s_], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s_][1], pb[s_], o1, 0, 0, 0);
+                o2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb[s_], o2, 0, 0, 0);
+                vf[s_][0] = v_frag(vb, v_base0 + s_ * 2048, v_base0 + s_ * 2048 + 1024);      // V^T of tile kt+1
+                vf[s_][1] = v_frag(vb, v_base1 + s_ * 2048, v_base1 + s_ * 2048 + 1024);
+            }
+            const char* kb = lds + kslot * BUF_B;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { n0[r] = -m_ref; n1[r] = -m_ref; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], n0, 0, 0, 0);
+                n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], n1, 0, 0, 0);
+                kf0[ks] = *reinterpret_cast<const bf16x8*>(kb + k_off[ks][0]);                 // K of tile kt+2
+                kf1[ks] = *reinterpret_cast<const bf16x8*>(kb + k_off[ks][1]);
+            }
+        }
+        vslot = vslot == RB - 1 ? 0 : vslot + 1;
+        kslot = kslot == RB - 1 ? 0 : kslot + 1;
+        __builtin_amdgcn_sched_barrier(0);
+        AP_STAMP(t3)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        AP_STAMP(t4)
+        AP_ADD(pv, t1, t0) AP_ADD(pvw, t2, t1) AP_ADD(pm, t3, t2) AP_ADD(pmw, t4, t3)
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        trip(sa0, sa1, sb0, sb1, kt);
+        if (kt + 1 < nkt) trip(sb0, sb1, sa0, sa1, kt + 1);
+    }
+#ifdef ST_PROBE
+    if (probe && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+        unsigned long long* o = probe + wave * 8;
+        o[0] = pv; o[1] = pvw; o[2] = pm; o[3] = pmw; o[4] = nkt; o[5] = 0; o[6] = 0; o[7] = 0;
+    }
+#endif
+    if (!late) __builtin_amdgcn_s_barrier();         // barrier counts of the two halves are equal again
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    const float l = __shfl(o2[0], r32, 64);
+    const float inv = 1.0f / l;
+    if (q0 + r32 < T) {
+        bf16* orow = O + (size_t)b * T * ldo + (size_t)(q0 + r32) * ldo + (size_t)head * ATT_D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 a_, c_;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a_[e] = (bf16)(o0[4 * g + e] * inv); c_[e] = (bf16)(o1[4 * g + e] * inv); }
+            *reinterpret_cast<bf16x4*>(orow + 8 * g + 4 * h) = a_;
+            *reinterpret_cast<bf16x4*>(orow + 32 + 8 * g + 4 * h) = c_;
+        }
+    }
+}
+
+// ---- 32-row kernel, interleaved: softmax instructions placed in the gaps between the MFMAs of the same wave ----------
+// At D = 64 a 64-key tile costs a wave 20 MFMAs (640 pipe cycles) and ~80 VALU instructions, 32 of them v_exp_f32 at
+// 8 issue cycles: ~420 cycles of vector issue, which fit the 24 free issue cycles of each MFMA gap only if they are
+// PLACED there (a wave issues in order: eight MFMAs in a row stall it at the second one, and the VALU behind them
+// waits).  One trip of this kernel is a single scheduling region, pinned gap by gap with sched_barrier:
+//     QK phase, 8 MFMAs  K(t+1) Q^T -> next scores   | exp + pack of the first half of tile t | V^T(t) fragment reads
+//     PV phase, 12 MFMAs V^T(t) P(t) (+ ones block)  | exp + pack of the second half, max of the next scores | K(t+2) reads
+// then the counted DMA wait, one block barrier, and the (rare) branch that moves the lazy maximum.  Because P(t) is
+// multiplied in the trip that exponentiates it, nothing is pending when the maximum moves.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn32i_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                      const bf16* __restrict__ V, bf16* __restrict__ O,
+                                                      int T, int S, long ldq, long ldk, long ldv, long ldo, float scale_log2e,
+                                                      unsigned long long* probe) {
+    constexpr int TILE_B = ATT_KV * 128;
+    constexpr int BUF_B = 2 * TILE_B;
+    constexpr int RB = 6;                             // ring buffers
+    constexpr int PIECES = 16 / NW;
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // the ring, then a 1-KiB dump for the dummy DMAs
+#ifdef ST_PROBE
+    unsigned long long pv = 0, pvw = 0, pm = 0, pmw = 0;
+#endif
+
+    const int t_ = threadIdx.x, lane = t_ & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t_ >> 6);
+    const int r32 = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = (blockIdx.x * NW + wave) * 32;
+    const int qrow = min(q0 + r32, T - 1);
+
+    const bf16* Qb = Q + (size_t)b * T * ldq + (size_t)head * ATT_D;
+    const bf16* Kb = K + (size_t)b * S * ldk + (size_t)head * ATT_D;
+    const bf16* Vb = V + (size_t)b * S * ldv + (size_t)head * ATT_D;
+    const bf16* zeros = reinterpret_cast<const bf16*>(g_att_zero16);
+
+    // Q through asm loads: a compiler-counted wait would not know about the DMAs issued behind them and would drain those too
+    typedef unsigned int q_raw_t __attribute__((ext_vector_type(4)));
+    q_raw_t qraw[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(qraw[ks]) : "v"(Qb + (size_t)qrow * ldq + 16 * ks + 8 * h) : "memory");
+    bf16x8 qf[4];
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)(r32 == 0 ? 1.0f : 0.0f);
+
+    const int nkt = (S + ATT_KV - 1) / ATT_KV;
+    const int lr = lane >> 3, pc = lane & 7;
+    const bf16* dsrc[PIECES];
+    long dstep[PIECES];
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int pce = wave * PIECES + i;
+        const int isv = pce >> 3, row = (pce & 7) * 8 + lr;
+        const int c = pc ^ (isv ? swz_v(row) : swz_k(row));
+        dsrc[i] = isv ? Vb + (size_t)row * ldv + c * 8 : Kb + (size_t)row * ldk + c * 8;
+        dstep[i] = (long)ATT_KV * (isv ? ldv : ldk);
+    }
+    // tiles are issued in order; past the last tile the pieces become dummies (a zero line into the dump area) so that
+    // every trip issues the same number of DMAs and the counted waits stay valid
+    int dbuf = 0;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(att_lds_offset(lds));
+    const unsigned dump_off = lds0 + RB * BUF_B;
+    auto dma_piece = [&](int kt, int i) {             // piece i of tile kt into ring slot dbuf
+        const unsigned slot = lds0 + dbuf * BUF_B;
+        const int pce = wave * PIECES + i;
+        const int isv = pce >> 3, rb = pce & 7;
+        if ((kt + 1) * ATT_KV <= S) {
+            att_dma16(dsrc[i], slot + isv * TILE_B + rb * 1024);
+        } else {
+            const bool live = kt < nkt;
+            const bf16* src = (live && kt * ATT_KV + rb * 8 + lr < S) ? dsrc[i] : zeros;
+            att_dma16(src, live ? slot + isv * TILE_B + rb * 1024 : dump_off);
+        }
+        dsrc[i] += dstep[i];
+    };
+    auto dma_next = [&]() { dbuf = dbuf == RB - 1 ? 0 : dbuf + 1; };
+    auto dma_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) dma_piece(kt, i);
+        dma_next();
+    };
+    int v_base0, v_base1;
+    {
+        const int q4 = (lane & 15) >> 2;
+        const int key = 4 * h + q4;
+        const int ch0 = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+        const int row = key * 128 + 8 * (lane & 1);
+        v_base0 = row + ((ch0 ^ swz_v(key)) << 4);
+        v_base1 = row + (((ch0 + 4) ^ swz_v(key)) << 4);
+    }
+    int k_off[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int c = 2 * ks + h;
+        k_off[ks][0] = r32 * 128 + ((c ^ swz_k(r32)) << 4);
+        k_off[ks][1] = (32 + r32) * 128 + ((c ^ swz_k(32 + r32)) << 4);
+    }
+    f32x16 negm;                                       // -m_ref of this lane's query row in every register: the C operand of a tile's first MFMAs
+    f32x16 o0 = {0}, o1 = {0}, o2 = {0};
+    bf16x8 kf0[4], kf1[4], vf[4][2], pb[4];
+    auto mask_tail = [&](f32x16& s0, f32x16& s1, int kt) {
+        const int kbase = kt * ATT_KV + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kbase + (r & 3) + 8 * (r >> 2);
+            if (key >= S) s0[r] = -INFINITY;
+            if (key + 32 >= S) s1[r] = -INFINITY;
+        }
+    };
+    auto max32 = [&](const f32x16& s0, const f32x16& s1) {
+        float ma = att_max3(s0[0], s0[1], s0[2]), mb = att_max3(s0[8], s0[9], s0[10]);
+        float mc = att_max3(s1[0], s1[1], s1[2]), md = att_max3(s1[8], s1[9], s1[10]);
+        ma = att_max3(ma, s0[3], s0[4]); mb = att_max3(mb, s0[11], s0[12]); mc = att_max3(mc, s1[3], s1[4]); md = att_max3(md, s1[11], s1[12]);
+        ma = att_max3(ma, s0[5], s0[6]); mb = att_max3(mb, s0[13], s0[14]); mc = att_max3(mc, s1[5], s1[6]); md = att_max3(md, s1[13], s1[14]);
+        ma = att_max3(ma, s0[7], mb); mc = att_max3(mc, s1[7], md);
+        return att_max3(ma, s0[15], att_max3(mc, s1[15], mc));
+    };
+
+    // prologue: four tiles in flight, the first three landed; exact scores of tile 0; K fragments of tile 1
+    dma_tile(0); dma_tile(1); dma_tile(2); dma_tile(3);
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(qraw[2]), "+v"(qraw[3]) : "n"(3 * PIECES) : "memory");   // Q and tile 0: start on them while the others fly
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 raw = __builtin_bit_cast(bf16x8, qraw[ks]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (bf16)((float)raw[j] * scale_log2e);
+    }
+    f32x16 sa0, sa1, sb0, sb1;
+    {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf0[ks] = *reinterpret_cast<const bf16x8*>(lds + k_off[ks][0]);
+            kf1[ks] = *reinterpret_cast<const bf16x8*>(lds + k_off[ks][1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa0[r] = 0.f; sa1[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], sa0, 0, 0, 0);
+            sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], sa1, 0, 0, 0);
+        }
+        if (ATT_KV > S) mask_tail(sa0, sa1, 0);
+        const float rmx = xmax32(max32(sa0, sa1));
+        const float m0 = rmx > -INFINITY ? rmx : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa0[r] -= m0; sa1[r] -= m0; negm[r] = -m0; }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf0[ks] = *reinterpret_cast<const bf16x8*>(lds + BUF_B + k_off[ks][0]);
+            kf1[ks] = *reinterpret_cast<const bf16x8*>(lds + BUF_B + k_off[ks][1]);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");           // tile 2: its K fragments are read in the first trip
+        __builtin_amdgcn_s_barrier();
+    }
+
+    int vslot = 0, kslot = 2;                         // ring slots of tile kt (V^T) and tile kt+2 (K)
+#ifdef ATT_I_PRIO
+    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+    auto trip = [&](f32x16& s0, f32x16& s1, f32x16& n0, f32x16& n1, int kt) {
+        AP_STAMP(t0)
+        AP_STAMP(t1)
+        const char* vb = lds + vslot * BUF_B + TILE_B;
+        const char* kb = lds + kslot * BUF_B;
+        float mch[4];                                  // four maximum chains over the next tile's scores
+        // ---- QK phase: gap g carries MFMA g, two exponentials + their pack, one V^T fragment (two transposed reads) ----
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int ks = g >> 1;
+            if ((g & 1) == 0) n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], ks == 0 ? negm : n0, 0, 0, 0);
+            else              n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], ks == 0 ? negm : n1, 0, 0, 0);
+#ifdef ATT_I_NOEXP
+            const float e0 = s0[2 * g], e1 = s0[2 * g + 1];
+#else
+            const float e0 = fast_exp2(s0[2 * g]), e1 = fast_exp2(s0[2 * g + 1]);
+#endif
+            pb[g >> 2][2 * (g & 3)] = (bf16)e0; pb[g >> 2][2 * (g & 3) + 1] = (bf16)e1;
+#if defined(ATT_I_DMA_SPREAD) && !defined(ATT_I_NODMA)
+            if (PIECES == 2 ? g == 3 : (g == 1 || g == 5)) dma_piece(kt + 4, PIECES == 2 ? 0 : (g == 1 ? 0 : 1));
+#endif
+            vf[g >> 1][g & 1] = v_frag(vb, ((g & 1) ? v_base1 : v_base0) + (g >> 1) * 2048, ((g & 1) ? v_base1 : v_base0) + (g >> 1) * 2048 + 1024);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        AP_STAMP(tq)
+        // ---- PV phase: gap p carries MFMA p; gaps 0-7 the other sixteen exponentials, gaps 2-11 the maximum of the next
+        //      tile's scores, gaps 4-11 the K fragments of tile kt+2 ----
+#pragma unroll
+        for (int p = 0; p < 12; ++p) {
+            const int s_ = p / 3, w = p % 3;
+            if (w == 0)      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s_][0], pb[s_], o0, 0, 0, 0);
+            else if (w == 1) o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s_][1], pb[s_], o1, 0, 0, 0);
+            else             o2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb[s_], o2, 0, 0, 0);
+            if (p < 8) {
+#ifdef ATT_I_NOEXP
+                const float e0 = s1[2 * p], e1 = s1[2 * p + 1];
+#else
+                const float e0 = fast_exp2(s1[2 * p]), e1 = fast_exp2(s1[2 * p + 1]);
+#endif
+                pb[2 + (p >> 2)][2 * (p & 3)] = (bf16)e0; pb[2 + (p >> 2)][2 * (p & 3) + 1] = (bf16)e1;
+            }
+#ifdef ATT_I_NOMAX
+            if (p == 2) { mch[0] = n0[0]; mch[1] = n0[8]; mch[2] = n1[0]; mch[3] = n1[8]; }
+#define ATT_I_MAXOFF && false
+#else
+#define ATT_I_MAXOFF
+#endif
+            if (p >= 2 && p < 6 ATT_I_MAXOFF) {                     // one chain start per gap
+                const int c = p - 2;
+                const f32x16& sx = c < 2 ? n0 : n1;
+                const int e = 8 * (c & 1);
+                mch[c] = att_max3(sx[e], sx[e + 1], sx[e + 2]);
+            }
+            if (p >= 6 && p < 8 ATT_I_MAXOFF) {
+#pragma unroll
+                for (int c = 2 * (p - 6); c < 2 * (p - 6) + 2; ++c) {
+                    const f32x16& sx = c < 2 ? n0 : n1;
+                    const int e = 8 * (c & 1);
+                    mch[c] = att_max3(mch[c], sx[e + 3], sx[e + 4]);
+                }
+            }
+            if (p >= 8 ATT_I_MAXOFF) {
+                const int c = p - 8;
+                const f32x16& sx = c < 2 ? n0 : n1;
+                const int e = 8 * (c & 1);
+                mch[c] = att_max3(mch[c], sx[e + 5], sx[e + 6]);
+                mch[c] = att_max3(mch[c], sx[e + 7], sx[e + 7]);
+            }
+#ifndef ATT_I_NODMA
+            // LDS-DMA of tile kt+4 (spreading the pieces over the gaps by wave was tried: the per-gap branches cost more
+            // than the queueing of sixteen simultaneous wave-instructions in the CU's load path)
+#if defined(ATT_I_DMA_SPREAD)
+            if (PIECES == 2 ? p == 9 : (p == 3 || p == 9)) dma_piece(kt + 4, PIECES == 2 ? 1 : (p == 3 ? 2 : 3));
+#elif defined(ATT_I_DMA_SPREAD2)
+            if (PIECES == 2 ? (p == 2 || p == 8) : (p == 1 || p == 4 || p == 7 || p == 10)) dma_piece(kt + 4, PIECES == 2 ? (p == 8) : (p - 1) / 3);
+#elif !defined(ATT_I_DMA_END)
+            if (p >= 12 - PIECES) dma_piece(kt + 4, p - (12 - PIECES));
+#endif
+#endif
+#ifdef ATT_I_NOLDS
+            if (kt == 0)
+#endif
+            if (p >= 4) {
+                const int i = p - 4, ks = i >> 1;
+                if ((i & 1) == 0) kf0[ks] = *reinterpret_cast<const bf16x8*>(kb + k_off[ks][0]);
+                else              kf1[ks] = *reinterpret_cast<const bf16x8*>(kb + k_off[ks][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float mx = att_max3(mch[0], mch[1], att_max3(mch[2], mch[3], mch[3]));
+        vslot = vslot == RB - 1 ? 0 : vslot + 1;
+        kslot = kslot == RB - 1 ? 0 : kslot + 1;
+        AP_STAMP(t2)
+        if (kt + 1 < nkt) {
+            if ((kt + 2) * ATT_KV > S) { mask_tail(n0, n1, kt + 1); mx = max32(n0, n1); }
+            if (__any(mx > ATT_LAG)) {
+                // a row outran the lag: move its reference maximum (nothing is pending: P of this trip is already in O)
+                const float rmx = xmax32(mx);
+                const float delta = (rmx > ATT_LAG && rmx > -INFINITY) ? rmx : 0.f;
+                const float alpha = fast_exp2(-delta);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    n0[r] -= delta; n1[r] -= delta; negm[r] -= delta;
+                    o0[r] *= alpha; o1[r] *= alpha; o2[r] *= alpha;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        AP_STAMP(t3)
+#ifdef ATT_I_NODMA
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+#ifdef ATT_I_DMA_END
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) dma_piece(kt + 4, i);
+#endif
+#ifdef ATT_X_VM0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");   // own pieces of tile kt+3 have landed; tile kt+4's may fly
+#endif
+#ifdef ATT_X_LGKM0
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+#endif
+        dma_next();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        AP_STAMP(t4)
+        AP_ADD(pv, tq, t1) AP_ADD(pvw, t2, tq) AP_ADD(pm, t3, t2) AP_ADD(pmw, t4, t3)
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        trip(sa0, sa1, sb0, sb1, kt);
+        if (kt + 1 < nkt) trip(sb0, sb1, sa0, sa1, kt + 1);
+    }
+#ifdef ST_PROBE
+    if (probe && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+        unsigned long long* o = probe + wave * 8;
+        o[0] = pv; o[1] = pvw; o[2] = pm; o[3] = pmw; o[4] = nkt; o[5] = 0; o[6] = 0; o[7] = 0;
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    const float l = __shfl(o2[0], r32, 64);
+    const float inv = 1.0f / l;
+    if (q0 + r32 < T) {
+        bf16* orow = O + (size_t)b * T * ldo + (size_t)(q0 + r32) * ldo + (size_t)head * ATT_D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 a_, c_;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a_[e] = (bf16)(o0[4 * g + e] * inv); c_[e] = (bf16)(o1[4 * g + e] * inv); }
+            *reinterpret_cast<bf16x4*>(orow + 8 * g + 4 * h) = a_;
+            *reinterpret_cast<bf16x4*>(orow + 32 + 8 * g + 4 * h) = c_;
+        }
+    }
+}
+
 // ---- fp32 strict kernel: thread = one query row, keys in tiles of 32 via LDS ----
 __global__ __launch_bounds__(128) void attn_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                        const float* __restrict__ V, float* __restrict__ O, int T, int S,
@@ -1001,12 +1642,6 @@ __global__ __launch_bounds__(128) void attn_f32_kernel(const float* __restrict__
     }
 }
 
-#ifdef ST_PROBE
-#define ATT_PROBE_ARG g_att_probe
-#else
-#define ATT_PROBE_ARG nullptr
-#endif
-
 extern "C" int st_attention(const void* q, const void* k, const void* v, void* out, int B, int T, int S, int H, int D,
                             long ldq, long ldk, long ldv, long ldo, float scale, int dtype, void* stream) {
     ST_REQUIRE(q && k && v && out, "attention: null pointer");
@@ -1029,7 +1664,7 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
         static const int rows16_env = att_dev_env_int("ST_ATT_R16", -1);
         // measured (tools/op_bench.py): 16-row waves win for the 77-key text context (more waves for a
         // two-tile loop) and for the 4096-token level (2560 instead of 1280 waves)
-        const int rows16 = rows16_env >= 0 ? rows16_env : ((S <= 256 || (T >= 4096 && S >= 4096)) ? 4 : 0);
+        const int rows16 = rows16_env >= 0 ? rows16_env : (S < 256 ? 4 : 0);
         static const int v2 = att_dev_env_int("ST_ATT_V2", 1);
         if (rows16 && v2) {
             // second-generation 16-row kernel; the text-context launches get their own instantiation (kernel name)
@@ -1059,6 +1694,30 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
         // run two key groups per block instead - twice the waves, half the tiles each, one LDS merge
         static const int force_ks = att_dev_env_int("ST_ATT_KS", -1);
         const bool split = force_ks >= 0 ? force_ks == 2 : (nw == 4 && (long)cdiv(T, 128) * H * B <= 256 && S >= 512);
+        // dev knob: 0 = interleaved kernel (product), 1/2 = staggered experiments, 5 = previous generation (attn32v2)
+        static const int stag = att_dev_env_int("ST_ATT_STAG", 0);
+        if (stag != 5 && S >= 256) {
+            constexpr size_t RING5 = 6 * 2 * ATT_KV * 128 + 1024;
+            if (stag == 0 || stag == 3 || stag == 4) {
+                // eight waves (256 query rows) share a K/V ring unless that leaves half the CUs idle: SDXL's 32x32 level at
+                // batch 1 is 80 such blocks; as 160 blocks of four waves every SIMD holds one wave (16.9 us against 20.4)
+                const int nwi = stag == 3 ? 8 : stag == 4 ? 4 : ((long)cdiv(T, 256) * H * B <= 128 ? 4 : 8);
+                auto kfi = nwi == 8 ? attn32i_kernel<8> : attn32i_kernel<4>;
+                static bool o3_ = (hipFuncSetAttribute((const void*)attn32i_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RING5),
+                                   hipFuncSetAttribute((const void*)attn32i_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RING5), true);
+                (void)o3_;
+                hipLaunchKernelGGL(kfi, dim3(cdiv(T, 32 * nwi), H, B), dim3(64 * nwi), RING5, st, (const bf16*)q, (const bf16*)k, (const bf16*)v,
+                                   (bf16*)out, T, S, ldq, ldk, ldv, ldo, c, ATT_PROBE_ARG);
+                return st_check_launch("attention");
+            }
+            auto kfs = stag == 2 ? attn32s_kernel<true> : attn32s_kernel<false>;
+            static bool o2_ = (hipFuncSetAttribute((const void*)attn32s_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RING5),
+                               hipFuncSetAttribute((const void*)attn32s_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RING5), true);
+            (void)o2_;
+            hipLaunchKernelGGL(kfs, dim3(cdiv(T, 256), H, B), dim3(512), RING5, st, (const bf16*)q, (const bf16*)k, (const bf16*)v,
+                               (bf16*)out, T, S, ldq, ldk, ldv, ldo, c, ATT_PROBE_ARG);
+            return st_check_launch("attention");
+        }
         static const int v32 = att_dev_env_int("ST_ATT_32V2", 1);
         if (v32) {
 #define ST_ATT32V2(NW_, KS_, GX_)                                                                                                   \

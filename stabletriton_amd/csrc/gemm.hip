@@ -704,6 +704,9 @@ template <int TM, int TN, int TILE_ELEMS>
 __device__ __forceinline__ bool splitk_combine(const GemmArgs& p, f32x4 (&acc)[TM][TN], int tw, int split, char* lds, int t, int wave, int lane) {
     float* slab0 = p.partial + (size_t)tw * p.splitk * TILE_ELEMS;
     {
+        // the stores below are inline asm, which the compiler's hazard pass does not protect against the MFMAs that have
+        // just written `acc` (no hardware interlock either): 19 wait states cover the longest (16-pass) MFMA
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" ::: "memory");
         float* mine = slab0 + (size_t)split * TILE_ELEMS + (size_t)wave * (TM * TN * 256) + lane * 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
