@@ -1829,7 +1829,10 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
                 const double rounds = (double)((nt + 255) / 256);
                 const double cost = rounds * (nk * 1.65 + 4.0);      // a 256 x 256 x 64 step is MFMA-paced: ~1.6 us at the clock the chip holds
                 const int f = forced_cfg();
-                if ((cost < best && f < 0) || f == CFG_256x256_8P) { gemm8p_launch(a, st); return st_check_launch(who); }
+                // the per-trip constants above were fitted on one-round launches and run 25-45 % optimistic once a launch
+                // takes several rounds (tools/gemm_sweep.py: FF1 of the 1280-channel level 51 us predicted 35, this kernel 39
+                // predicted 37; QKV at batch 4 72 us against 55), so this kernel also takes the near ties
+                if ((cost < 1.3 * best && f < 0) || f == CFG_256x256_8P) { gemm8p_launch(a, st); return st_check_launch(who); }
             }
         }
         GemmArgs b = a;

@@ -145,7 +145,9 @@ def test_ln_linear(gpu, dtype, M, K, N, geglu):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,T,S,H", [(1, 256, 256, 10), (2, 128, 77, 5), (1, 1024, 1024, 20), (1, 100, 33, 2),
-                                     (1, 64, 1, 1), (1, 4096, 77, 10), (1, 256, 640, 2), (1, 200, 1000, 3)])      # the last three (with 1024^2) take the key-split kernel
+                                     (1, 64, 1, 1), (1, 4096, 77, 10), (1, 256, 640, 2), (1, 200, 1000, 3),
+                                     (1, 4096, 320, 10), (2, 300, 333, 3), (1, 513, 257, 2)])
+# S >= 256: attn32i_kernel (four waves per block; (1, 4096, 320, 10) is 160 blocks of eight); S < 256: attn16v2_kernel
 def test_attention(gpu, dtype, B, T, S, H):
     C = H * 64
     q, k, v = rnd("att.q", (B, T, C)), rnd("att.k", (B, S, C)), rnd("att.v", (B, S, C))
@@ -183,6 +185,42 @@ def test_attention_lazy_reference_maximum(gpu, T, S):
     ref = orc.attention_core(rounded(q, dtype), rounded(k, dtype), rounded(v, dtype), H)
     out = ops.attention(q.to(gpu, dtype), k.to(gpu, dtype), v.to(gpu, dtype), H, 0.125)
     assert_close(out, ref, dtype, "attention lazy maximum")
+
+
+def test_attention_eight_wave_blocks_lazy_maximum(gpu):
+    """attn32i_kernel<8> (more than 128 blocks of 256 rows): rows whose maximum outruns the lag in a late tile, in the
+    masked last tile, and rows that start from a very negative first tile."""
+    B, T, S, H = 9, 512, 330, 8
+    q, k, v = rnd("att8.q", (B, T, H * 64)), rnd("att8.k", (B, S, H * 64)), rnd("att8.v", (B, S, H * 64))
+    k[:, 329] = q[:, 2] * 8.0
+    k[:, 200] = q[:, 300] * 5.0
+    k[:, 70] = q[:, 511] * 1.5
+    k[:, :64] = k[:, :64] - q[:, 4:5] * 4.0
+    dtype = torch.bfloat16
+    ref = orc.attention_core(rounded(q, dtype), rounded(k, dtype), rounded(v, dtype), H)
+    out = ops.attention(q.to(gpu, dtype), k.to(gpu, dtype), v.to(gpu, dtype), H, 0.125)
+    assert_close(out, ref, dtype, "attention, eight-wave blocks")
+
+
+@pytest.mark.parametrize("B,T,S,H", [(1, 1024, 1024, 10), (1, 4096, 4096, 10), (2, 1024, 1024, 20), (1, 1024, 77, 20)])
+def test_attention_is_bit_stable_when_another_stream_shares_the_cus(gpu, B, T, S, H):
+    """The hardware does not interlock MFMA results against VALU reads and the compiler only protects instructions it
+    can see; an inline-asm maximum over fresh accumulators once changed results by 1 ulp whenever the matrix pipe was
+    shared with another kernel.  Solo and crowded runs must agree bit for bit."""
+    dtype = torch.bfloat16
+    q, k, v = (rnd(f"attc.{n}", (B, L, H * 64)).to(gpu, dtype) for n, L in (("q", T), ("k", S), ("v", S)))
+    solo = ops.attention(q, k, v, H, 0.125).clone()
+    torch.cuda.synchronize()
+    a = torch.randn(2048, 2048, device=gpu, dtype=dtype)
+    side = torch.cuda.Stream(device=gpu)
+    for _ in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(8):
+                a2 = (a @ a).tanh_()
+        out = ops.attention(q, k, v, H, 0.125)
+        torch.cuda.synchronize()
+        assert torch.equal(out, solo)
+    del a2
 
 
 CONVS = [  # N, Cin, H, W, Cout, k, stride, pad, upsample

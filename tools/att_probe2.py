@@ -1,4 +1,6 @@
-"""Developer probe of attn32s_kernel (needs -DST_PROBE -DST_DEV_CONFIGS build): per-wave cycles of the two phases and their barrier waits."""
+"""Developer probe of attn32i_kernel (needs a -DST_PROBE build, e.g. tools/build_one_variant.sh attprobe attention.hip -DST_PROBE;
+run with ST_LIB_VARIANT=attprobe): per-wave cycles per trip of the QK phase, the PV phase, the lazy-maximum check and the DMA wait + barrier.
+The stamps themselves drain the LDS queue (s_memtime + lgkmcnt(0)), so the phases read a little long."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stabletriton_amd import _C, ops
@@ -15,4 +17,4 @@ torch.cuda.synchronize()
 p = probe.cpu().view(8, 8)
 for w in range(8):
     n = max(int(p[w, 4]), 1)
-    print(f"wave {w}: V work {int(p[w,0])/n:7.0f}  V wait+barrier {int(p[w,1])/n:7.0f}  M work {int(p[w,2])/n:7.0f}  M barrier {int(p[w,3])/n:7.0f}  cycles per trip, {n} trips")
+    print(f"wave {w}: QK {int(p[w,0])/n:7.0f}  PV {int(p[w,1])/n:7.0f}  check {int(p[w,2])/n:7.0f}  wait+barrier {int(p[w,3])/n:7.0f}  cycles per trip, {n} trips")
