@@ -325,7 +325,7 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void attn32i_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                       const bf16* __restrict__ V, bf16* __restrict__ O,
                                                       int T, int S, long ldq, long ldk, long ldv, long ldo, float scale_log2e,
-                                                      unsigned long long* probe) {
+                                                      int H, unsigned long long* probe) {
     constexpr int TILE_B = ATT_KV * 128;
     constexpr int BUF_B = 2 * TILE_B;
     constexpr int RB = 6;                             // ring buffers
@@ -338,8 +338,21 @@ __global__ __launch_bounds__(NW * 64) void attn32i_kernel(const bf16* __restrict
     const int t_ = threadIdx.x, lane = t_ & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t_ >> 6);
     const int r32 = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = (blockIdx.x * NW + wave) * 32;
+    // 1-D grid, XCD-aware: consecutive block ids go round-robin to the eight XCDs, so XCD c takes the c-th contiguous
+    // eighth of the (batch, head, query block) list - the query blocks of one head (they all stream that head's K and V)
+    // meet in one L2 instead of eight (HBM-side bytes of the 4096-token launch: 4.5x the algorithmic bytes before)
+    int head, b, xblk;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int xq = nb >> 3, xr = nb & 7, xcd = bid & 7;
+        const int w = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+        const int gx = (T + 32 * NW - 1) / (32 * NW);
+        const int hb = w / gx;
+        xblk = w - hb * gx;
+        b = hb / H;
+        head = hb - b * H;
+    }
+    const int q0 = (xblk * NW + wave) * 32;
     const int qrow = min(q0 + r32, T - 1);
 
     const bf16* Qb = Q + (size_t)b * T * ldq + (size_t)head * ATT_D;
@@ -565,7 +578,7 @@ __global__ __launch_bounds__(NW * 64) void attn32i_kernel(const bf16* __restrict
         if (kt + 1 < nkt) trip(sb0, sb1, sa0, sa1, kt + 1);
     }
 #ifdef ST_PROBE
-    if (probe && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    if (probe && lane == 0 && q0 == wave * 32 && head == 0 && b == 0) {
         unsigned long long* o = probe + wave * 8;
         o[0] = pv; o[1] = pvw; o[2] = pm; o[3] = pmw; o[4] = nkt; o[5] = 0; o[6] = 0; o[7] = 0;
     }
@@ -692,8 +705,9 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
         static bool once = ((void)hipFuncSetAttribute((const void*)attn32i_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RING),
                             (void)hipFuncSetAttribute((const void*)attn32i_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RING), true);
         (void)once;
-        hipLaunchKernelGGL(kfn, dim3(cdiv(T, 32 * nw), H, B), dim3(64 * nw), RING, st, (const bf16*)q, (const bf16*)k, (const bf16*)v,
-                           (bf16*)out, T, S, ldq, ldk, ldv, ldo, c, ATT_PROBE_ARG);
+        ST_REQUIRE((long)cdiv(T, 32 * nw) * H * B < (1L << 31), "attention: too many blocks");
+        hipLaunchKernelGGL(kfn, dim3(cdiv(T, 32 * nw) * H * B), dim3(64 * nw), RING, st, (const bf16*)q, (const bf16*)k, (const bf16*)v,
+                           (bf16*)out, T, S, ldq, ldk, ldv, ldo, c, H, ATT_PROBE_ARG);
     } else if (dtype == ST_F32) {
         hipLaunchKernelGGL(attn_f32_kernel, dim3(cdiv(T, 128), H, B), dim3(128), 0, st, (const float*)q, (const float*)k,
                            (const float*)v, (float*)out, T, S, ldq, ldk, ldv, ldo, scale);

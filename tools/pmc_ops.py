@@ -28,7 +28,7 @@ def meta(name):
     if name.startswith("attn"):
         b = 4 if name.endswith("b4") else 1
         T, S, H = {"attn_self_4096": (4096, 4096, 10), "attn_self_1024": (1024, 1024, 20), "attn_cross_4096": (4096, 77, 10),
-                   "attn_cross_1024": (1024, 77, 20), "attn_self_1024_b4": (1024, 1024, 20)}[name]
+                   "attn_cross_1024": (1024, 77, 20), "attn_self_1024_b4": (1024, 1024, 20), "attn_self_4096_b4": (4096, 4096, 10)}[name]
         fam = "attention_self" if "self" in name else "attention_cross"
         cnt = {"attn_self_4096": 10, "attn_self_1024": 60, "attn_cross_4096": 10, "attn_cross_1024": 60}.get(name, 0)
         return fam, 4.0 * b * H * T * S * 64, 2.0 * b * H * 64 * (2 * T + 2 * S), cnt
