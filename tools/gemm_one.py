@@ -1,0 +1,38 @@
+"""Developer timing of one Linear shape: product dispatch, forced configurations, hipBLASLt (torch) - warm and cold weights.
+usage: gemm_one.py M K N [g]   (needs ST_LIB_VARIANT=dev for the forced rows)"""
+import ctypes, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stabletriton_amd import _C, ops
+from tools.op_bench import timeit, rnd
+lib = _C.load()
+force = getattr(lib, "st_debug_force_gemm", None)
+if force is not None:
+    force.argtypes, force.restype = [ctypes.c_int, ctypes.c_int], None
+M, K, N = (int(v) for v in sys.argv[1:4])
+geglu = len(sys.argv) > 4 and "g" in sys.argv[4]
+rows = 2 * N if geglu else N
+x, b = rnd(M, K), rnd(rows)
+fl = 2.0 * M * K * rows
+for ncopy, tag in ((1, "warm"), (max(1, min(32, int(600e6 // (rows * K * 2)))), "cold")):
+    ws = [rnd(rows, K) * K ** -0.5 for _ in range(ncopy)]
+    it = [0]
+    def ours():
+        it[0] += 1
+        return ops.linear(x, ws[it[0] % ncopy], b, geglu=geglu)
+    def vendor():
+        it[0] += 1
+        return torch.nn.functional.linear(x, ws[it[0] % ncopy], b)
+    line = f"{tag} weights ({ncopy} copies): "
+    if force is not None: force(-1, -1)
+    us = timeit(ours, iters=max(20, ncopy)); line += f"product {us:.1f} us ({fl/us/1e6:.0f} TF/s)"
+    if force is not None:
+        for cfg, name in ((100, "8p"), (19, "256x128"), (9, "128x128"), (28, "128x160")):
+            force(cfg, 1)
+            try:
+                us = timeit(ours, iters=max(20, ncopy)); line += f" | {name} {us:.1f}"
+            except Exception as e:
+                line += f" | {name} n/a"
+        force(-1, -1)
+    if not geglu:
+        us = timeit(vendor, iters=max(20, ncopy)); line += f" | hipBLASLt {us:.1f} ({fl/us/1e6:.0f} TF/s)"
+    print(line, flush=True)
