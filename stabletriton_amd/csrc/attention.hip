@@ -89,8 +89,13 @@ __device__ __attribute__((aligned(16))) unsigned int g_att_zero16[4] = {0u, 0u, 
 __device__ __forceinline__ int swz_k16(int row) { return row & 7; }
 __device__ __forceinline__ int swz_v16(int row) { return ((row >> 1) & 3) << 1; }
 
-// ---- 16-row kernel, second generation: the softmax is cut to what the VALU cannot avoid ------------
-// At D = 64 the kernel is bound by the softmax arithmetic, not by the matrix pipe (per 16 x 64 score tile a wave
+// ---- 16-row kernel (v_mfma_f32_16x16x32_bf16), used for the 77-token text context: one wave owns 16 query rows -----
+//   S^T[key][q] = K Q^T : A = K rows (lane: key = l&15, d = 32ks + 8g..), B = Q^T (lane: q = l&15, same d);
+//                         D: lane (q = l&15, g = l>>4) holds keys 16kb + 4g + r
+//   O^T[d][q]  += V^T P^T: B = P^T straight from the S registers of key blocks (2kp, 2kp+1): k-slot 8g + j <-> key
+//                         32kp + 16(j>>2) + 4g + (j&3); A = V^T through two transposed 4x16 block reads per fragment
+//                         that follow the same key order.
+// The softmax is cut to what the VALU cannot avoid.  At D = 64 the kernel is bound by the softmax arithmetic, not by the matrix pipe (per 16 x 64 score tile a wave
 // issues 16-18 MFMAs = 290 pipe cycles, and the classic online softmax ~100 VALU instructions = 450 issue cycles).
 // What is left here per score: one v_exp_f32, half a v_max3_f32, half a v_cvt_pk_bf16_f32:
 //   * Q is pre-multiplied by scale * log2(e) once (bf16, like every MFMA operand), so scores are base-2 exponents;
@@ -103,7 +108,8 @@ __device__ __forceinline__ int swz_v16(int row) { return ((row >> 1) & 3) << 1; 
 //     sum_k P[k][q] to an accumulator (two MFMAs per tile instead of sixteen VALU adds), and being an accumulator
 //     like O it is rescaled with O;
 //   * the next tile's K Q^T is issued before this tile's softmax (runs under it).
-// K/V staging (LDS-DMA ring of three tiles, one barrier per tile) is that of attn16_bf16_kernel.
+// K/V tiles of 64 keys arrive by LDS-DMA into a ring of three swizzled buffers, one barrier per tile (the text context
+// is two tiles: both are requested in the prologue).
 // TAG only gives the cross-attention instantiation its own kernel name (profiles split the two).
 static constexpr float ATT_LAG = 6.0f;
 
