@@ -728,23 +728,19 @@ __device__ __forceinline__ bool splitk_combine(const GemmArgs& p, f32x4 (&acc)[T
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // every slab load is sc1 (bypasses this CU's L1, which other CUs' stores never refresh)
+    // Every slab load carries sc1 (served past this CU's L1, which other CUs' write-through stores never refresh), as a
+    // raw buffer load so that it stays compiler-visible: the destination of an inline-asm load may be copied or spilled by
+    // the compiler before the data has arrived (seen as soon as a 128-accumulator tile put the register file under
+    // pressure); here the compiler counts the loads itself.
+    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t slabs = __builtin_amdgcn_make_buffer_rsrc((void*)slab0, 0, (int)((size_t)p.splitk * TILE_ELEMS * 4), 0x00020000);
     for (int sl = 0; sl < p.splitk; ++sl) {
-        const float* src = slab0 + (size_t)sl * TILE_ELEMS + (size_t)wave * (TM * TN * 256) + lane * 4;
-        f32x4 part[TM][TN];
+        const int off = (sl * TILE_ELEMS + wave * (TM * TN * 256) + lane * 4) * 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const float* a_ = src + (i * TN + j) * 256;
-                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[i][j]) : "v"(a_) : "memory");
-            }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] += part[i][j];
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] += __builtin_bit_cast(f32x4, (u32x4_)__builtin_amdgcn_raw_buffer_load_b128(slabs, off + (i * TN + j) * 1024, 0, 16));
     }
     return true;
 }
