@@ -33,7 +33,7 @@ BOUND = {"linear": "mfma", "linear_fp8": "mfma", "quantize_fp8": "hbm", "conv2d"
          "group_norm": "hbm", "layer_norm": "hbm", "geglu": "hbm"}
 KERNEL = {"linear_fp8": "gemm_dma_kernel<f8, CONV=false>", "quantize_fp8": "quant_fp8_kernel",
           "linear": "gemm_dma_kernel / gemm8p_kernel <bf16, CONV=false>", "conv2d": "conv_halo_kernel / gemm_dma_kernel<bf16, CONV=true>",
-          "attention_self": "attn32i_kernel<8> / attn32i_kernel<4>", "attention_cross": "attn16v2_kernel<4, 1>",
+          "attention_self": "attn32i_kernel<8, false> / attn32i_kernel<4, true>", "attention_cross": "attn16v2_kernel<4, 1>",
           "group_norm": "gn_stats_nhwc+gn_finalize+gn_apply_nhwc", "layer_norm": "ln_kernel", "geglu": "geglu_kernel"}
 
 

@@ -5,8 +5,8 @@
 //
 // bf16 kernels (flash style):
 //   * attn32i_kernel - self-attention (S >= 256): a wave owns 32 query rows (v_mfma_f32_32x32x16_bf16), a block of
-//     eight (or four) waves walks the keys in tiles of 64 that arrive by LDS-DMA in a six-slot ring; the softmax
-//     instructions are placed in the gaps between the MFMAs of the same wave;
+//     eight waves (or four plus a loader wave) walks the keys in tiles of 64 that arrive by LDS-DMA in a six-slot ring;
+//     the softmax instructions are placed in the gaps between the MFMAs of the same wave;
 //   * attn16v2_kernel - the 77-token text context (S < 256): a wave owns 16 query rows (v_mfma_f32_16x16x32_bf16),
 //     so that the two-tile loop still has enough waves to fill the chip;
 //   * both compute the scores transposed, S^T = K Q^T, so a lane holds the scores of ONE query row; the S^T accumulator
@@ -327,8 +327,8 @@ __global__ __launch_bounds__(NW * 64) void attn16v2_kernel(const bf16* __restric
 //     PV phase, 12 MFMAs V^T(t) P(t) (+ ones block)  | exp + pack of the second half, max of the next scores | K(t+2) reads
 // then the counted DMA wait, one block barrier, and the (rare) branch that moves the lazy maximum.  Because P(t) is
 // multiplied in the trip that exponentiates it, nothing is pending when the maximum moves.
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void attn32i_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+template <int NW, bool LD>
+__global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                       const bf16* __restrict__ V, bf16* __restrict__ O,
                                                       int T, int S, long ldq, long ldk, long ldv, long ldo, float scale_log2e,
                                                       int H, unsigned long long* probe) {
@@ -366,6 +366,60 @@ __global__ __launch_bounds__(NW * 64) void attn32i_kernel(const bf16* __restrict
     const bf16* Vb = V + (size_t)b * S * ldv + (size_t)head * ATT_D;
     const bf16* zeros = reinterpret_cast<const bf16*>(g_att_zero16);
 
+    const int nkt = (S + ATT_KV - 1) / ATT_KV;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(att_lds_offset(lds));
+    if constexpr (LD) {
+        // ---- loader wave (wave NW): with one wave per SIMD nobody multiplies while a compute wave queues in the load path
+        //      (16 wave-instructions of 1 KiB per tile, 16 cycles each), so one extra wave issues every piece of every tile and
+        //      the compute waves issue none.  It keeps the compute waves' barrier sequence: three in the prologue (tile 0, 1, 2
+        //      landed), then one per trip (tile kt+3 landed, tile kt+4 in flight).
+        if (wave == NW) {
+            const int lr_ = lane >> 3, pc_ = lane & 7;
+            const bf16* src[16];
+#pragma unroll
+            for (int pce = 0; pce < 16; ++pce) {
+                const int isv = pce >> 3, row = (pce & 7) * 8 + lr_;
+                const int c = pc_ ^ (isv ? swz_v(row) : swz_k(row));
+                src[pce] = isv ? Vb + (size_t)row * ldv + c * 8 : Kb + (size_t)row * ldk + c * 8;
+            }
+            const long kstep = (long)ATT_KV * ldk, vstep = (long)ATT_KV * ldv;
+            int slot_i = 0;
+            auto load_tile = [&](int kt) {            // all sixteen pieces of tile kt (< nkt) into the next ring slot
+                const unsigned slot = lds0 + slot_i * BUF_B;
+                const bool whole = (kt + 1) * ATT_KV <= S;
+#pragma unroll
+                for (int pce = 0; pce < 16; ++pce) {
+                    const int isv = pce >> 3, rb = pce & 7;
+                    const bf16* sp = (whole || kt * ATT_KV + rb * 8 + lr_ < S) ? src[pce] : zeros;
+                    att_dma16(sp, slot + isv * TILE_B + rb * 1024);
+                    src[pce] += isv ? vstep : kstep;
+                }
+                slot_i = slot_i == RB - 1 ? 0 : slot_i + 1;
+            };
+            // prologue: tiles 0..2 requested, barrier when tile 0 / 1 / 2 has landed; tile 3 joins after the first barrier
+            // (at most 48 DMAs in flight: the vmcnt immediate ends at 63)
+            const int n0 = min(nkt, 3);
+            for (int kt = 0; kt < n0; ++kt) load_tile(kt);
+            if (n0 == 3) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (n0 == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (nkt > 3) { load_tile(3); asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); }      // tile 1 landed (2, 3 fly)
+            else if (n0 == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (nkt > 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                          // tile 2 landed (3 flies)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (int kt = 0; kt < nkt; ++kt) {
+                if (kt + 4 < nkt) { load_tile(kt + 4); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }   // tile kt+3 landed
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            return;
+        }
+    }
+
     // Q through asm loads: a compiler-counted wait would not know about the DMAs issued behind them and would drain those too
     typedef unsigned int q_raw_t __attribute__((ext_vector_type(4)));
     q_raw_t qraw[4];
@@ -377,7 +431,6 @@ __global__ __launch_bounds__(NW * 64) void attn32i_kernel(const bf16* __restrict
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (bf16)(r32 == 0 ? 1.0f : 0.0f);
 
-    const int nkt = (S + ATT_KV - 1) / ATT_KV;
     const int lr = lane >> 3, pc = lane & 7;
     const bf16* dsrc[PIECES];
     long dstep[PIECES];
@@ -392,9 +445,9 @@ __global__ __launch_bounds__(NW * 64) void attn32i_kernel(const bf16* __restrict
     // tiles are issued in order; past the last tile the pieces become dummies (a zero line into the dump area) so that
     // every trip issues the same number of DMAs and the counted waits stay valid
     int dbuf = 0;
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane(att_lds_offset(lds));
     const unsigned dump_off = lds0 + RB * BUF_B;
     auto dma_piece = [&](int kt, int i) {             // piece i of tile kt into ring slot dbuf
+        if constexpr (LD) return;                      // (the loader wave issues them)
         const unsigned slot = lds0 + dbuf * BUF_B;
         const int pce = wave * PIECES + i;
         const int isv = pce >> 3, rb = pce & 7;
@@ -452,7 +505,7 @@ __global__ __launch_bounds__(NW * 64) void attn32i_kernel(const bf16* __restrict
 
     // prologue: four tiles in flight, the first three landed; exact scores of tile 0; K fragments of tile 1
     dma_tile(0); dma_tile(1); dma_tile(2); dma_tile(3);
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(qraw[2]), "+v"(qraw[3]) : "n"(3 * PIECES) : "memory");   // Q and tile 0: start on them while the others fly
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(qraw[2]), "+v"(qraw[3]) : "n"(LD ? 0 : 3 * PIECES) : "memory");   // Q and tile 0: start on them while the others fly
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -707,12 +760,14 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
         // batch 1 is 80 such blocks; as 160 blocks of four waves every SIMD holds one wave (18 us against 21)
         int nw = (long)cdiv(T, 256) * H * B <= 128 ? 4 : 8;
         if (force_nw == 4 || force_nw == 8) nw = force_nw;
-        auto kfn = nw == 8 ? attn32i_kernel<8> : attn32i_kernel<4>;
-        static bool once = ((void)hipFuncSetAttribute((const void*)attn32i_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RING),
-                            (void)hipFuncSetAttribute((const void*)attn32i_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RING), true);
+        // four-wave blocks leave one wave per SIMD, with nobody to multiply while a wave queues in the load path: they
+        // get a fifth wave that issues every LDS-DMA (16.7 -> 12.4 us with the DMAs compiled out altogether)
+        auto kfn = nw == 8 ? attn32i_kernel<8, false> : attn32i_kernel<4, true>;
+        static bool once = ((void)hipFuncSetAttribute((const void*)attn32i_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RING),
+                            (void)hipFuncSetAttribute((const void*)attn32i_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RING), true);
         (void)once;
         ST_REQUIRE((long)cdiv(T, 32 * nw) * H * B < (1L << 31), "attention: too many blocks");
-        hipLaunchKernelGGL(kfn, dim3(cdiv(T, 32 * nw) * H * B), dim3(64 * nw), RING, st, (const bf16*)q, (const bf16*)k, (const bf16*)v,
+        hipLaunchKernelGGL(kfn, dim3(cdiv(T, 32 * nw) * H * B), dim3(nw == 8 ? 512 : 320), RING, st, (const bf16*)q, (const bf16*)k, (const bf16*)v,
                            (bf16*)out, T, S, ldq, ldk, ldv, ldo, c, H, ATT_PROBE_ARG);
     } else if (dtype == ST_F32) {
         hipLaunchKernelGGL(attn_f32_kernel, dim3(cdiv(T, 128), H, B), dim3(128), 0, st, (const float*)q, (const float*)k,
