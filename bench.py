@@ -29,10 +29,11 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (guide: ~2.5 PF)
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
-BOUND = {"linear": "mfma", "linear_fp8": "mfma", "quantize_fp8": "hbm", "conv2d": "mfma", "attention_self": "mfma", "attention_cross": "hbm",
+BOUND = {"linear": "mfma", "linear_xattn": "mfma", "linear_fp8": "mfma", "quantize_fp8": "hbm", "conv2d": "mfma", "attention_self": "mfma", "attention_cross": "hbm",
          "group_norm": "hbm", "layer_norm": "hbm", "geglu": "hbm"}
 KERNEL = {"linear_fp8": "gemm_dma_kernel<f8, CONV=false>", "quantize_fp8": "quant_fp8_kernel",
-          "linear": "gemm_dma_kernel / gemm8p_kernel <bf16, CONV=false>", "conv2d": "conv_halo_kernel / gemm_dma_kernel<bf16, CONV=true>",
+          "linear": "gemm_dma_kernel / gemm8p_kernel <bf16, CONV=false>",
+          "linear_xattn": "gemm_dma_kernel<bf16, 128, 64, ..., XA=true> (query projection + text-context attention in its epilogue)", "conv2d": "conv_halo_kernel / gemm_dma_kernel<bf16, CONV=true>",
           "attention_self": "attn32i_kernel<8, false> / attn32i_kernel<4, true>", "attention_cross": "attn16v2_kernel<4, 1>",
           "group_norm": "gn_stats_nhwc+gn_finalize+gn_apply_nhwc", "layer_norm": "ln_kernel", "geglu": "geglu_kernel"}
 

@@ -38,8 +38,9 @@ enum {
     ST_EPI_ROWBIAS   = 16   /* + rowbias[batch(m)][n]     (time-embedding add)    */
 };
 
-int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 8
-                                              (6: next-weights hint passed per call, st_timestep_sincos; 7: fp8 entry points; 8: GroupNorm partials from the producer) */
+int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 9
+                                              (6: next-weights hint passed per call, st_timestep_sincos; 7: fp8 entry points; 8: GroupNorm partials from the
+                                              producer; 9: st_ln_linear_xattn) */
 const char* st_last_error(void);           /* host string, thread-local     */
 
 /* GroupNorm (+SiLU).  Replaces reference group_norm_wrapper
@@ -122,6 +123,19 @@ int st_ln_linear(const void* x, const float* row_stats, int row_stats_chunks, co
                  const float* c, const float* d, void* y, int M, int N, int K, long lda,
                  long ldc, float eps, int epilogue, int dtype,
                  const void* next_weights, size_t next_weights_bytes, void* stream);
+
+/* The query projection of the text-context attention and that attention as ONE launch - the chain
+ * layer_norm_wrapper -> linear_wrapper (attn2.to_q) -> attention_wrapper of a transformer block (unet_pt.py:192-208,
+ * 133-142; replace_layernorm.py:17-24, replace_linear.py:20-34, replace_attention.py:60-68):
+ *   out[M, H*64] = softmax((LN(x) Wq^T + bias) k^T * scale) v   per head,
+ * LayerNorm folded as in st_ln_linear (Wg, c, d, row_stats), k / v the (batch, S, H*64) context projections with token
+ * strides ldk / ldv (S < 256), rows_per_batch query rows per batch entry (a multiple of 128).  The query tile never
+ * leaves the chip: results are bit-identical to st_ln_linear followed by st_attention.  bf16 only. */
+int st_ln_linear_xattn(const void* x, const float* row_stats, int row_stats_chunks, const void* Wg,
+                       const float* c, const float* d, const void* k, const void* v, void* out,
+                       int M, int N, int K, long lda, long ldo, float eps, int rows_per_batch, int S, int H,
+                       long ldk, long ldv, float scale,
+                       const void* next_weights, size_t next_weights_bytes, void* stream);
 
 /* Fused attention core: out = softmax(q k^T * scale) v per head, no mask.
  * Replaces attention_wrapper (optimizers/replace_attention.py:60-68); inputs

@@ -16,7 +16,7 @@ from .build import lib_path
 ST_F32, ST_BF16 = 0, 1
 ST_NCHW, ST_NHWC = 0, 1
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_RESIDUAL, EPI_ROWBIAS = 1, 2, 4, 8, 16
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _p, _i, _l, _f, _z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
@@ -30,6 +30,7 @@ SIGNATURES = {
     "st_geglu": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _i, _p]),
     "st_linear": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _p, _z, _p, _i, _p, _p, _i, _p, _p, _z, _p]),
     "st_ln_linear": (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _l, _l, _f, _i, _i, _p, _z, _p]),
+    "st_ln_linear_xattn": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _l, _l, _f, _i, _i, _i, _l, _l, _f, _p, _z, _p]),
     "st_attention": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _l, _l, _f, _i, _p]),
     "st_conv2d": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _i, _p, _p, _z, _p]),
     "st_group_norm_from_stats": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p, _i, _i, _p, _i, _i, _p, _p]),

@@ -46,7 +46,8 @@ def _sources():
 
 def _digest(path: str) -> str:
     h = hashlib.sha256()
-    for dep in [path, os.path.join(CSRC, "common.h"), os.path.join(PKG, "..", "include", "stabletriton_amd.h")]:
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))       # every internal header
+    for dep in [path] + headers + [os.path.join(PKG, "..", "include", "stabletriton_amd.h")]:
         with open(dep, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())

@@ -12,6 +12,7 @@
 // fragment as B), so each lane ends up with 4 consecutive output columns of
 // one row and the epilogue stores 8/16 contiguous bytes per lane.
 #include "common.h"
+#include "attention_core.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -44,6 +45,8 @@ struct GemmArgs {
     const float* row_scale; const float* col_scale;
     const void* next_w; size_t next_bytes;   // weights of the NEXT launch (host hint): touched during this epilogue
     int helper_blocks;           // > 0: that many extra blocks at the end of the grid (idle CUs) do the touching instead
+    // st_ln_linear_xattn: the tile is the query block of ONE head; its epilogue runs the text-context attention on it
+    const void* xa_k; const void* xa_v; long xa_ldk, xa_ldv; int xa_S, xa_T; float xa_scale_log2e;
     unsigned long long* probe;   // diagnostic builds only (-DST_PROBE): per-wave phase cycle sums
 };
 
@@ -745,7 +748,7 @@ __device__ __forceinline__ bool splitk_combine(const GemmArgs& p, f32x4 (&acc)[T
     return true;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV, bool GEGLU, bool LNF = false>
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV, bool GEGLU, bool LNF = false, bool XA = false>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs p) {
     constexpr int NW = WGM * WGN;
     constexpr int VEC = 16 / (int)sizeof(T);
@@ -1139,7 +1142,44 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
             return;
         }
     }
-    if constexpr (LNF) {
+    if constexpr (XA) {
+        // Query projection of the text-context attention: the tile is 128 queries x the 64 columns of ONE head.  Leave it
+        // in LDS as bf16 (exactly what the unfused path stores and reads back) and run the 16-row attention core on it:
+        // the attention launch, its Q round trip through HBM and one kernel boundary disappear (70 per denoise step).
+        static_assert(LNF && !GEGLU && !CONV && BM == 128 && BN == 64 && NW == 8 && std::is_same<T, bf16>::value, "xattn epilogue: 128 x 64 tile, 8 waves");
+        static_assert(STAGES * STAGE >= 16384 + 3 * 16384, "xattn epilogue: Q tile + K/V ring fit the GEMM's ring");
+        const float2* lnst = reinterpret_cast<const float2*>(lds + STAGES * STAGE);
+        float mean[TM], rstd[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float2 v = lnst[wm * WTM + i * 16 + r16];
+            mean[i] = v.x; rstd[i] = v.y;
+        }
+        __syncthreads();                               // every wave has read its last fragments: the ring is free
+        bf16* qt = reinterpret_cast<bf16*>(lds);       // [128][64]
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * WTN + j * 16 + 4 * q;
+            const f32x4 cv = *reinterpret_cast<const f32x4*>(p.ln_c + n0 + col), dv = *reinterpret_cast<const f32x4*>(p.ln_d + n0 + col);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * WTM + i * 16 + r16;
+                bf16x4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = (bf16)(rstd[i] * (acc[i][j][e] - mean[i] * cv[e]) + dv[e]);
+                *reinterpret_cast<bf16x4*>(qt + row * 64 + col) = o4;
+            }
+        }
+        __syncthreads();
+        const int bimg = m0 / p.xa_T, head = tile_n;
+        const bf16* Kb = (const bf16*)p.xa_k + (size_t)bimg * p.xa_S * p.xa_ldk + (size_t)head * 64;
+        const bf16* Vb = (const bf16*)p.xa_v + (size_t)bimg * p.xa_S * p.xa_ldv + (size_t)head * 64;
+        attn16_core<8>(qt, 64, 128, Kb, Vb, p.xa_ldk, p.xa_ldv, p.xa_S, (bf16*)p.C + (size_t)m0 * p.ldc + (size_t)head * 64, p.ldc,
+                       min(BM, p.M - m0), p.xa_scale_log2e, lds + 16384, wave, lane);
+        unsigned int sink = 0;
+        touch_next_weights(p, sink);
+        retire_touches(sink);
+    } else if constexpr (LNF) {
         float mean[TM], rstd[TM];
         const float2* lnst = reinterpret_cast<const float2*>(lds + STAGES * STAGE);
 #pragma unroll
@@ -1677,11 +1717,11 @@ static bool colstats_ok(const GemmArgs& a, int bm, bool lnf) {
     return ok;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV, bool GEGLU, bool LNF>
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool CONV, bool GEGLU, bool LNF, bool XA = false>
 static void launch_dma_one(const GemmArgs& a, hipStream_t st, int tiles_n) {
     const size_t lds = (size_t)STAGES * U * (BM + BN) * 128 + (size_t)BM * 8 + 1024;      // ring + LayerNorm (mean, rstd) per row + DMA dump
     const int sk = a.splitk > 1 ? a.splitk : 1;
-    auto kfn = gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, U, CONV, GEGLU, LNF>;
+    auto kfn = gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, U, CONV, GEGLU, LNF, XA>;
     const bool emit_cols = colstats_ok(a, BM, LNF);
     static bool once = (allow_big_lds(kfn, lds), true);
     (void)once;
@@ -1969,6 +2009,31 @@ extern "C" int st_ln_linear(const void* x, const float* row_stats, int row_stats
     take_hint(a, next_weights, next_weights_bytes);
     hipStream_t st = (hipStream_t)stream;
     return dtype == ST_BF16 ? gemm_dispatch<bf16, false>(a, st) : gemm_dispatch<float, false>(a, st);
+}
+
+// The query projection of the text-context attention and that attention as ONE launch (transformer block:
+// norm2 -> attn2.to_q -> attention over the 77 hoisted context keys, unet_pt.py:133-142,192-208):
+//   out = softmax(LN(x) Wq^T (+bias) . K^T * scale) V  per head, with LN folded exactly as in st_ln_linear.
+extern "C" int st_ln_linear_xattn(const void* x, const float* row_stats, int row_stats_chunks, const void* Wg, const float* c,
+                                  const float* d, const void* k, const void* v, void* out, int M, int N, int K, long lda, long ldo,
+                                  float eps, int rows_per_batch, int S, int H, long ldk, long ldv, float scale,
+                                  const void* next_weights, size_t next_weights_bytes, void* stream) {
+    ST_REQUIRE(x && Wg && c && d && k && v && out && row_stats, "ln_linear_xattn: null pointer");
+    ST_REQUIRE(row_stats_chunks > 0, "ln_linear_xattn: the producer emitted no row statistics");
+    ST_REQUIRE(M > 0 && N > 0 && K > 0 && S > 0 && H > 0, "ln_linear_xattn: bad shape M=%d N=%d K=%d S=%d H=%d", M, N, K, S, H);
+    ST_REQUIRE(N == H * 64, "ln_linear_xattn: N=%d must be H*64 (H=%d)", N, H);
+    ST_REQUIRE(rows_per_batch > 0 && rows_per_batch % 128 == 0 && M % rows_per_batch == 0,
+               "ln_linear_xattn: %d rows per batch: query tiles of 128 rows must not straddle batches", rows_per_batch);
+    ST_REQUIRE(K % 64 == 0 && lda % 8 == 0 && ldo % 4 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "ln_linear_xattn: K, strides must keep 16-byte alignment");
+    ST_REQUIRE(((uintptr_t)x | (uintptr_t)Wg | (uintptr_t)out | (uintptr_t)k | (uintptr_t)v | (uintptr_t)c | (uintptr_t)d) % 16 == 0,
+               "ln_linear_xattn: pointers must be 16-byte aligned");
+    GemmArgs a = {};
+    a.A = x; a.W = Wg; a.C = out; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldo; a.epi = 0;
+    a.ln_c = c; a.ln_d = d; a.ln_eps = eps; a.splitk = 1; a.ln_stats = row_stats; a.ln_chunks = row_stats_chunks;
+    a.xa_k = k; a.xa_v = v; a.xa_ldk = ldk; a.xa_ldv = ldv; a.xa_S = S; a.xa_T = rows_per_batch; a.xa_scale_log2e = scale * 1.4426950408889634f;
+    take_hint(a, next_weights, next_weights_bytes);
+    launch_dma_one<bf16, 128, 64, 4, 2, 4, 1, false, false, true, true>(a, (hipStream_t)stream, N / 64);
+    return st_check_launch("ln_linear_xattn");
 }
 
 // fp8 projections (seed: the reference's fp8-stored projection weights, kernels/attention_proj.py:36-39,

@@ -465,6 +465,41 @@ def ln_linear(x: torch.Tensor, stats: "RowStats", w_folded: torch.Tensor, c: tor
     return out
 
 
+def xattn_fusable(x: torch.Tensor, k: torch.Tensor, heads: int) -> bool:
+    """Shapes `ln_linear_xattn` takes: bf16, a short context (the 16-row attention kernel's range) and query blocks of
+    128 rows that do not straddle batch entries."""
+    rows = x.shape[-2] if x.dim() >= 3 else x.shape[0]
+    return (x.dtype == torch.bfloat16 and k.dim() == 3 and k.shape[1] < 256 and rows % 128 == 0 and k.shape[-1] == heads * 64
+            and k.stride(-1) == 1)
+
+
+def ln_linear_xattn(x: torch.Tensor, stats: "RowStats", w_folded: torch.Tensor, c: torch.Tensor, d: torch.Tensor, eps: float,
+                    k: torch.Tensor, v: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """attention(LayerNorm(x) @ Wq.T (+bias), k, v) over a short context as ONE launch (st_ln_linear_xattn): the query
+    projection's epilogue runs the attention core on the tile it has just computed.  Bit-identical to
+    `attention(ln_linear(x, ...), k, v, heads, scale)`."""
+    _C.require_device(x, w_folded, c, d, stats.buf, k, v)
+    lib = _C.load()
+    K = x.shape[-1]
+    N = w_folded.shape[0]
+    if w_folded.shape[1] != K or w_folded.dtype != x.dtype or c.dtype != torch.float32 or d.dtype != torch.float32:
+        raise BackendError("ln_linear_xattn: folded operands do not match the input")
+    if x.dim() != 3 or k.dim() != 3 or v.shape != k.shape or k.shape[0] != x.shape[0] or N != heads * 64 or k.shape[-1] != N:
+        raise BackendError(f"ln_linear_xattn: shapes x={tuple(x.shape)} k={tuple(k.shape)} v={tuple(v.shape)} heads={heads}")
+    if not xattn_fusable(x, k, heads) or v.stride(-1) != 1 or k.stride(0) != k.shape[1] * k.stride(1) or v.stride(0) != v.shape[1] * v.stride(1):
+        raise BackendError("ln_linear_xattn: layout not supported (bf16, context < 256 tokens, 128 | rows per batch, dense batches)")
+    x2, M, lda = _rows2d(x)
+    out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+    nxt_p, nxt_b = _next_weights(w_folded)
+    S = k.shape[1]
+    _label(f"M={M} N={N} K={K} ln xattn S={S}")
+    _C.check(_timed("linear_xattn", 2.0 * M * N * K + 4.0 * M * S * N, float((M * K + w_folded.numel() + M * N + 2 * k.shape[0] * S * N) * x.element_size()),
+                    lib.st_ln_linear_xattn, x2.data_ptr(), stats.buf.data_ptr(), stats.chunks, w_folded.data_ptr(),
+                    c.data_ptr(), d.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), M, N, K, lda, N, float(eps),
+                    x.shape[1], S, heads, k.stride(1), v.stride(1), float(scale), nxt_p, nxt_b, _C.stream_ptr()), "ln_linear_xattn")
+    return out
+
+
 @torch.no_grad()
 def fold_layer_norm(gamma: torch.Tensor, beta: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]):
     """(W * diag(gamma) in the weight dtype, c = row sums of that rounded matrix, d = W beta + bias), fp32 c/d."""

@@ -17,7 +17,7 @@ import torch
 from torch import fx, nn
 
 from . import _C, ops
-from .optimizers import (dedupe_pure_calls, fuse_token_residual, fuse_attention, fuse_geglu, fuse_geglu_into_linear, fuse_groupnorm_stats, fuse_layernorm_into_linear, fuse_residual_adds,
+from .optimizers import (dedupe_pure_calls, fuse_token_residual, fuse_attention, fuse_geglu, fuse_geglu_into_linear, fuse_groupnorm_stats, fuse_layernorm_into_linear, fuse_query_projection_into_attention, fuse_residual_adds,
                          fuse_shared_input_linears,
                          fuse_temb_add, fuse_timesteps, split_context, split_region, keep_channels_last, make_dynamic_graphed_callable, quantize_projections_fp8, remove_dropout,
                          replace_conv, replace_group_norm, replace_group_norm_activation, replace_layer_norm,
@@ -50,6 +50,7 @@ def replace_backend(gm: fx.GraphModule, fuse: bool = True, fp8: bool = False) ->
         if fp8:      # transformer-block projections on the fp8 matrix pipe (claims its LayerNorms before the bf16 folding does)
             stats["fp8_projections"] = quantize_projections_fp8(gm)
         stats["layer_norm_in_gemm"] = fuse_layernorm_into_linear(gm)
+        stats["query_projection_in_attention"] = 0 if os.environ.get("ST_NO_XATTN_FUSION") else fuse_query_projection_into_attention(gm)   # (env: developer A/B)
         stats["group_norm_stats"] = 0 if os.environ.get("ST_NO_GN_STATS") else fuse_groupnorm_stats(gm)      # (env: developer A/B)
     stats["channels_last_views"] = keep_channels_last(gm)
     gm.graph.eliminate_dead_code()

@@ -114,6 +114,36 @@ def fuse_layernorm_into_linear(gm: fx.GraphModule) -> int:
     return count
 
 
+def fuse_query_projection_into_attention(gm: fx.GraphModule) -> int:
+    """ln_linear_wrapper with ONE projection whose only consumer is the `q` of an attention_wrapper (the cross-attention
+    query path: self-attention takes its q from the fused q|k|v GEMM through a slice) becomes
+    `ln_linear_attention_wrapper`: the projection GEMM runs the attention core as its epilogue."""
+    from .wrappers import attention_wrapper, ln_linear_attention_wrapper
+    count = 0
+    for att in list(gm.graph.nodes):
+        if not (att.op == "call_function" and att.target is attention_wrapper) or att.kwargs:
+            continue
+        qn = att.args[0]
+        if not (isinstance(qn, fx.Node) and qn.op == "call_function" and qn.target is ln_linear_wrapper and len(qn.users) == 1):
+            continue
+        x0, st, ln, linears = qn.args[0], qn.args[1], qn.args[2], qn.args[3]
+        geglu = qn.args[4] if len(qn.args) > 4 else qn.kwargs.get("geglu", False)
+        if geglu or len(linears) != 1 or att.args[1] is qn or att.args[2] is qn:
+            continue
+        with gm.graph.inserting_before(att):
+            new = gm.graph.call_function(ln_linear_attention_wrapper,
+                                         (x0, st, ln, linears[0], att.args[1], att.args[2], att.args[4], att.args[5], att.args[6]))
+        att.replace_all_uses_with(new)
+        gm.graph.erase_node(att)
+        gm.graph.erase_node(qn)
+        count += 1
+    if count:
+        gm.graph.eliminate_dead_code()
+        gm.graph.lint()
+        gm.recompile()
+    return count
+
+
 def split_context(gm: fx.GraphModule, context_arg: str = "encoder_hidden_states") -> Optional[fx.GraphModule]:
     """Move the sub-graph that depends only on `context_arg` into its own GraphModule.
 

@@ -60,6 +60,7 @@ def test_pass_counts_match_reference_probe_on_sdxl():
     assert gm.rewrite_stats["geglu_in_gemm"] == 70 and gm.rewrite_stats["temb_rowbias"] == 17
     assert gm.rewrite_stats["layer_norm_in_gemm"] == 210 and gm.rewrite_stats["shared_input_gemms"] == 72
     assert gm.rewrite_stats["group_norm_stats"] == 46          # every GroupNorm reads a conv / GEMM output or a cat of two
+    assert gm.rewrite_stats["query_projection_in_attention"] == 70     # every cross-attention: to_q's GEMM runs the attention
     _install_context_split(gm)
     assert gm.rewrite_stats["context_outputs"] == 140 and gm.rewrite_stats["time_outputs"] == 1
     # no M=batch GEMM is left in the per-step graph: the whole time path lives in gm.time_module

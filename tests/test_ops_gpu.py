@@ -223,6 +223,29 @@ def test_attention_is_bit_stable_when_another_stream_shares_the_cus(gpu, B, T, S
     del a2
 
 
+@pytest.mark.parametrize("B,T,C,H,S", [(1, 1024, 1280, 20, 77), (2, 256, 640, 10, 77), (1, 4096, 640, 10, 77), (1, 128, 128, 2, 5), (3, 384, 192, 3, 200)])
+def test_query_projection_with_text_context_attention_in_its_epilogue(gpu, B, T, C, H, S):
+    """st_ln_linear_xattn == st_ln_linear followed by st_attention, bit for bit (the query tile is rounded to bf16 in LDS
+    exactly as the unfused path rounds it in HBM), and both match the oracle."""
+    dtype = torch.bfloat16
+    x = rnd("xa.x", (B, T, C)) * 1.3 + 0.2
+    g, be = rnd("xa.g", (C,)) * 0.2 + 1.0, rnd("xa.b", (C,)) * 0.2
+    w, b = rnd("xa.w", (C, C)) * C ** -0.5, rnd("xa.bias", (C,))
+    kv = rnd("xa.kv", (B, S, 2 * C))
+    xr, gr, br, wr, bbr, kvr = (rounded(t, dtype) for t in (x, g, be, w, b, kv))
+    qref = rounded(F.linear(F.layer_norm(xr, (C,), gr, br, 1e-5), wr, bbr), dtype)
+    ref = orc.attention_core(qref, kvr[..., :C], kvr[..., C:], H)
+    xg, stats = ops.linear(x.to(gpu, dtype), torch.eye(C).to(gpu, dtype), None, emit_stats=True)
+    wf, c, d = ops.fold_layer_norm(g.to(gpu, dtype), be.to(gpu, dtype), w.to(gpu, dtype), b.to(gpu, dtype))
+    kvg = kv.to(gpu, dtype)
+    kg, vg = kvg[..., :C], kvg[..., C:]                    # strided halves of the fused k|v projection, as in the compiled graph
+    q = ops.ln_linear(xg, stats, wf, c, d, 1e-5)
+    two = ops.attention(q, kg, vg, H, 0.125)
+    one = ops.ln_linear_xattn(xg, stats, wf, c, d, 1e-5, kg, vg, H, 0.125)
+    assert torch.equal(one, two)
+    assert_close(one, ref, dtype, "query projection + text-context attention", factor=2.0)
+
+
 CONVS = [  # N, Cin, H, W, Cout, k, stride, pad, upsample
     (1, 320, 32, 32, 320, 3, 1, 1, False), (2, 64, 16, 16, 128, 3, 1, 1, False), (1, 640, 32, 32, 640, 3, 2, 1, False),
     (1, 960, 16, 16, 320, 1, 1, 0, False), (1, 128, 16, 16, 128, 3, 1, 1, True), (1, 4, 32, 32, 320, 3, 1, 1, False),
