@@ -1,5 +1,5 @@
 """Run ONE operator shape a few times (target of the rocprofv3 --pmc passes in tools/pmc_ops.sh).
-usage: one_op.py linear M K N [g|ln|lng] | attn B T S H | conv N Cin H Cout k stride ups | gn N C H silu"""
+usage: one_op.py linear M K N [g|ln|lng] | xattn B T C H S | attn B T S H | conv N Cin H Cout k stride ups | gn N C H silu"""
 import os
 import sys
 
@@ -31,6 +31,16 @@ if kind == "linear":
         fn = lambda: ops.ln_linear(x, st, wf, c, d, 1e-5, geglu=geglu)
     else:
         fn = lambda: ops.linear(x, w, b, geglu=geglu)
+elif kind == "xattn":                  # the cross-attention query projection with the attention in its epilogue
+    B, T, C, H, S = (int(v) for v in a[:5])
+    x, w, b = rnd(B, T, C), rnd(C, C) * C ** -0.5, rnd(C)
+    g, be = rnd(C), rnd(C)
+    wf, c, d = ops.fold_layer_norm(g, be, w, b)
+    wp, res = rnd(C, C) * C ** -0.5, rnd(B, T, C)
+    xin, st = ops.linear(x, wp, None, residual=res, emit_stats=True)
+    kv = rnd(B, S, 2 * C)
+    k, v = kv[..., :C], kv[..., C:]
+    fn = lambda: ops.ln_linear_xattn(xin, st, wf, c, d, 1e-5, k, v, H, 0.125)
 elif kind == "attn":
     B, T, S, H = (int(v) for v in a[:4])
     q, k, v = rnd(B, T, H * 64), rnd(B, S, H * 64), rnd(B, S, H * 64)

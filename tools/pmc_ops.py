@@ -20,7 +20,7 @@ import sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "pmc_ops")
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
-KEEP = ("attn", "gemm", "conv_halo", "conv_thin", "gn_", "mfma_peak")
+KEEP = ("attn", "gemm", "conv_halo", "conv_thin", "gn_", "mfma_peak")      # (the xattn launches are gemm_dma_kernel<..., XA>)
 
 # shape -> (family, algorithmic flops, algorithmic bytes, launches per denoise step at bs=1 / latent 128)
 def meta(name):
@@ -32,6 +32,11 @@ def meta(name):
         fam = "attention_self" if "self" in name else "attention_cross"
         cnt = {"attn_self_4096": 10, "attn_self_1024": 60, "attn_cross_4096": 10, "attn_cross_1024": 60}.get(name, 0)
         return fam, 4.0 * b * H * T * S * 64, 2.0 * b * H * 64 * (2 * T + 2 * S), cnt
+    if name.startswith("xattn"):
+        M, C = (int(v) for v in p[1].split("x"))
+        H = C // 64
+        cnt = {"xattn_1024x1280": 60, "xattn_4096x640": 10}.get(name, 0)
+        return "linear_xattn", 2.0 * M * C * C + 4.0 * M * 77 * C, 2.0 * (M * C + C * C + M * C + 2 * 77 * C), cnt
     if name.startswith("linear"):
         M, K, N = (int(v) for v in p[1].split("x"))
         g = 2 if "g" in (p[2] if len(p) > 2 else "") else 1
@@ -64,7 +69,9 @@ shapes = sorted({os.path.basename(d).rsplit("__", 1)[0] for d in glob.glob(os.pa
 per, fam_acc = {}, {}
 for name in shapes:
     fam, flops, nbytes, cnt = meta(name)
-    sq = read(os.path.join(src, name + "__sq", "*", "*counter_collection.csv"))
+    # (one_op.py runs the producer GEMM once before the LayerNorm-folded launches: keep only the kernel under study)
+    only = (lambda ds: [d for d in ds if "ELb1ELb1EEv" in d["kernel"]]) if fam == "linear_xattn" else (lambda ds: ds)
+    sq = only(read(os.path.join(src, name + "__sq", "*", "*counter_collection.csv")))
     if not sq:
         continue
     # one launch of an operator may be several kernels (GroupNorm: three): launches = dispatches / kernels per call
@@ -81,8 +88,8 @@ for name in shapes:
     if flops:
         rec["algorithmic_flops"] = flops
         rec["flops_over_peak"] = round(flops / (ns * 1e-9) / 2.5e15, 4)
-    fetch = read(os.path.join(src, name + "__fetch", "*", "*counter_collection.csv"))
-    write = read(os.path.join(src, name + "__write", "*", "*counter_collection.csv"))
+    fetch = only(read(os.path.join(src, name + "__fetch", "*", "*counter_collection.csv")))
+    write = only(read(os.path.join(src, name + "__write", "*", "*counter_collection.csv")))
     if fetch and write:
         fs = sum(d.get("FETCH_SIZE", 0.0) for d in fetch) / calls
         wsz = sum(d.get("WRITE_SIZE", 0.0) for d in write) / calls

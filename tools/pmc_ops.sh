@@ -34,6 +34,8 @@ attn_self_1024 attn 1 1024 1024 20
 attn_cross_4096 attn 1 4096 77 10
 attn_cross_1024 attn 1 1024 77 20
 attn_self_1024_b4 attn 4 1024 1024 20
+xattn_1024x1280 xattn 1 1024 1280 20 77
+xattn_4096x640 xattn 1 4096 640 10 77
 attn_self_4096_b4 attn 4 4096 4096 10
 linear_1024x1280x5120_lng linear 1024 1280 5120 lng
 linear_1024x5120x1280 linear 1024 5120 1280
