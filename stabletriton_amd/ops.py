@@ -473,6 +473,14 @@ def xattn_fusable(x: torch.Tensor, k: torch.Tensor, heads: int) -> bool:
             and k.stride(-1) == 1)
 
 
+def xattn_fusion_pays(x: torch.Tensor, heads: int) -> bool:
+    """The fused launch projects the queries in 128 x 64 tiles (one head per tile).  That is the projection's own best tile
+    while the launch is one round of tiles (SDXL's 1024-token level at batch 1: 160); beyond that the wider tiles the
+    dispatch would pick win back more than the saved launch (measured: 24.9 against 20.4 us at the 4096-token level,
+    -1 % per step at batch 2 and 4), so the two-launch route is taken."""
+    return (x.numel() // x.shape[-1] // 128) * heads <= 256
+
+
 def ln_linear_xattn(x: torch.Tensor, stats: "RowStats", w_folded: torch.Tensor, c: torch.Tensor, d: torch.Tensor, eps: float,
                     k: torch.Tensor, v: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
     """attention(LayerNorm(x) @ Wq.T (+bias), k, v) over a short context as ONE launch (st_ln_linear_xattn): the query

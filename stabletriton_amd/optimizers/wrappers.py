@@ -165,10 +165,10 @@ def ln_linear_attention_wrapper(v: torch.Tensor, stats, layernorm: nn.LayerNorm,
                                 sm_scale: float, num_heads: int, head_dim: int) -> torch.Tensor:
     """attention_wrapper(ln_linear_wrapper(v, stats, layernorm, (linear,)), k, v_ctx, None, sm_scale, num_heads, head_dim)
     - the cross-attention query path of a transformer block (norm2 -> attn2.to_q -> attention over the hoisted text
-    context) - as ONE launch when the shapes allow it (bf16, head_dim 64, context < 256 tokens, 128 | tokens), else as
-    those two calls.  Both routes give the same bits."""
+    context) - as ONE launch when the shapes allow it (bf16, head_dim 64, context < 256 tokens, 128 | tokens) and the
+    launch is at most one round of its 128 x 64 tiles, else as those two calls.  Both routes give the same bits."""
     wf, c, d = _ln_fold(layernorm, (linear,))
-    if head_dim == 64 and ops.xattn_fusable(v, k, num_heads):
+    if head_dim == 64 and ops.xattn_fusable(v, k, num_heads) and ops.xattn_fusion_pays(v, num_heads):
         return ops.ln_linear_xattn(v, stats, wf, c, d, layernorm.eps, k, v_ctx, num_heads, sm_scale)
     q = ops.ln_linear(v, stats, wf, c, d, layernorm.eps)
     return ops.attention(q, k, v_ctx, num_heads, sm_scale)
