@@ -77,12 +77,19 @@ def self_launch(args, cmd=None) -> int:
         procs.append((subprocess.Popen(cmd, env=env, stdout=out, stderr=err), out, err))
     rc = 0
     deadline = time.time() + 3000
-    for p, out, err in procs:
-        try:
-            code = p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            code = -9
-        rc = rc or code
+    while True:                          # a rank that dies leaves the others stuck in the rendezvous or a collective: stop at the first failure
+        codes = [p.poll() for p, _, _ in procs]
+        failed = [c for c in codes if c not in (None, 0)]
+        if failed:
+            rc = failed[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            rc = -9
+            break
+        time.sleep(0.2)
+    for _, out, err in procs:
         out.close(); err.close()
     if rc != 0:
         for p, _, _ in procs:          # a failed rank leaves the others stuck in a collective: end exactly our children
@@ -310,6 +317,8 @@ def main():
         os.environ.setdefault("NCCL_DEBUG", "INFO")
         os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,P2P,NET")
         os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
+    if args.same_device:                 # rehearsal on one card: RCCL cannot put two ranks on one device
+        args.backend = "gloo"
     rank, world, local = parallel.init_from_env(args.backend)
     if args.same_device:
         local = 0
