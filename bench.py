@@ -34,7 +34,7 @@ BOUND = {"linear": "mfma", "linear_xattn": "mfma", "linear_fp8": "mfma", "quanti
 KERNEL = {"linear_fp8": "gemm_dma_kernel<f8, CONV=false>", "quantize_fp8": "quant_fp8_kernel",
           "linear": "gemm_dma_kernel / gemm8p_kernel <bf16, CONV=false>",
           "linear_xattn": "gemm_dma_kernel<bf16, 128, 64, ..., XA=true> (query projection + text-context attention in its epilogue)", "conv2d": "conv_halo_kernel / gemm_dma_kernel<bf16, CONV=true>",
-          "attention_self": "attn32i_kernel<8, false> / attn32i_kernel<4, true>", "attention_cross": "attn16v2_kernel<4, 1>",
+          "attention_self": "attn32i_kernel<7, true> / attn32i_kernel<4, true>", "attention_cross": "attn16v2_kernel<4, 1>",
           "group_norm": "gn_stats_nhwc+gn_finalize+gn_apply_nhwc", "layer_norm": "ln_kernel", "geglu": "geglu_kernel"}
 
 

@@ -5,7 +5,7 @@
 //
 // bf16 kernels (flash style):
 //   * attn32i_kernel - self-attention (S >= 256): a wave owns 32 query rows (v_mfma_f32_32x32x16_bf16), a block of
-//     eight waves (or four plus a loader wave) walks the keys in tiles of 64 that arrive by LDS-DMA in a six-slot ring;
+//     seven (or four) such waves plus a loader wave walks the keys in tiles of 64 that arrive by LDS-DMA in a six-slot ring;
 //     the softmax instructions are placed in the gaps between the MFMAs of the same wave;
 //   * attn16v2_kernel - the 77-token text context (S < 256): a wave owns 16 query rows (v_mfma_f32_16x16x32_bf16),
 //     so that the two-tile loop still has enough waves to fill the chip;
@@ -469,18 +469,21 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
             return st_check_launch("attention");
         }
         constexpr size_t RING = 6 * 2 * ATT_KV * 128 + 1024;      // six (K, V) tile slots + the dump line of the dummy DMAs
-        // eight waves (256 query rows) share a K/V ring unless that leaves half the CUs idle: SDXL's 32x32 level at
-        // batch 1 is 80 such blocks; as 160 blocks of four waves every SIMD holds one wave (18 us against 21)
-        int nw = (long)cdiv(T, 256) * H * B <= 128 ? 4 : 8;
-        if (force_nw == 4 || force_nw == 8) nw = force_nw;
-        // four-wave blocks leave one wave per SIMD, with nobody to multiply while a wave queues in the load path: they
-        // get a fifth wave that issues every LDS-DMA (16.7 -> 12.4 us with the DMAs compiled out altogether)
-        auto kfn = nw == 8 ? attn32i_kernel<8, false> : attn32i_kernel<4, true>;
+        // Compute waves per block, each with one extra wave that issues every LDS-DMA of every tile (a compute wave that
+        // queues in the CU's load path multiplies nothing meanwhile: 16 wave-instructions of 1 KiB per tile, 16 cycles each).
+        // Seven compute waves (224 query rows; with the loader two waves per SIMD) share a K/V ring unless that leaves half
+        // the CUs idle: SDXL's 32x32 level at batch 1 is then 160 blocks of four waves, one per SIMD (15.4 us against 20.2).
+        // Against eight self-loading waves: 4096 tokens 73 -> 70 us (batch 1), 215 -> 206 us (batch 4); 1024 tokens at
+        // batch 4 43.8 -> 39.2 us.
+        int nw = (long)cdiv(T, 256) * H * B <= 128 ? 4 : 7;
+        if (force_nw == 4 || force_nw == 8 || force_nw == 7) nw = force_nw;
+        auto kfn = nw == 8 ? attn32i_kernel<8, false> : nw == 7 ? attn32i_kernel<7, true> : attn32i_kernel<4, true>;
         static bool once = ((void)hipFuncSetAttribute((const void*)attn32i_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RING),
+                            (void)hipFuncSetAttribute((const void*)attn32i_kernel<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RING),
                             (void)hipFuncSetAttribute((const void*)attn32i_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RING), true);
         (void)once;
         ST_REQUIRE((long)cdiv(T, 32 * nw) * H * B < (1L << 31), "attention: too many blocks");
-        hipLaunchKernelGGL(kfn, dim3(cdiv(T, 32 * nw) * H * B), dim3(nw == 8 ? 512 : 320), RING, st, (const bf16*)q, (const bf16*)k, (const bf16*)v,
+        hipLaunchKernelGGL(kfn, dim3(cdiv(T, 32 * nw) * H * B), dim3(nw == 4 ? 320 : 512), RING, st, (const bf16*)q, (const bf16*)k, (const bf16*)v,
                            (bf16*)out, T, S, ldq, ldk, ldv, ldo, c, H, ATT_PROBE_ARG);
     } else if (dtype == ST_F32) {
         hipLaunchKernelGGL(attn_f32_kernel, dim3(cdiv(T, 128), H, B), dim3(128), 0, st, (const float*)q, (const float*)k,

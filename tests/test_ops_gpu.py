@@ -147,7 +147,7 @@ def test_ln_linear(gpu, dtype, M, K, N, geglu):
 @pytest.mark.parametrize("B,T,S,H", [(1, 256, 256, 10), (2, 128, 77, 5), (1, 1024, 1024, 20), (1, 100, 33, 2),
                                      (1, 64, 1, 1), (1, 4096, 77, 10), (1, 256, 640, 2), (1, 200, 1000, 3),
                                      (1, 4096, 320, 10), (2, 300, 333, 3), (1, 513, 257, 2)])
-# S >= 256: attn32i_kernel (four waves per block; (1, 4096, 320, 10) is 160 blocks of eight); S < 256: attn16v2_kernel
+# S >= 256: attn32i_kernel (four compute waves per block; (1, 4096, 320, 10) takes the seven-wave blocks); S < 256: attn16v2_kernel
 def test_attention(gpu, dtype, B, T, S, H):
     C = H * 64
     q, k, v = rnd("att.q", (B, T, C)), rnd("att.k", (B, S, C)), rnd("att.v", (B, S, C))
@@ -187,9 +187,10 @@ def test_attention_lazy_reference_maximum(gpu, T, S):
     assert_close(out, ref, dtype, "attention lazy maximum")
 
 
-def test_attention_eight_wave_blocks_lazy_maximum(gpu):
-    """attn32i_kernel<8> (more than 128 blocks of 256 rows): rows whose maximum outruns the lag in a late tile, in the
-    masked last tile, and rows that start from a very negative first tile."""
+def test_attention_seven_wave_blocks_lazy_maximum(gpu):
+    """attn32i_kernel<7, loader> (more than 128 blocks of 256 rows would be needed: 224-row blocks, T = 512 leaves a ragged
+    last block): rows whose maximum outruns the lag in a late tile, in the masked last tile, and rows that start from a
+    very negative first tile."""
     B, T, S, H = 9, 512, 330, 8
     q, k, v = rnd("att8.q", (B, T, H * 64)), rnd("att8.k", (B, S, H * 64)), rnd("att8.v", (B, S, H * 64))
     k[:, 329] = q[:, 2] * 8.0
@@ -199,7 +200,7 @@ def test_attention_eight_wave_blocks_lazy_maximum(gpu):
     dtype = torch.bfloat16
     ref = orc.attention_core(rounded(q, dtype), rounded(k, dtype), rounded(v, dtype), H)
     out = ops.attention(q.to(gpu, dtype), k.to(gpu, dtype), v.to(gpu, dtype), H, 0.125)
-    assert_close(out, ref, dtype, "attention, eight-wave blocks")
+    assert_close(out, ref, dtype, "attention, seven-wave blocks")
 
 
 @pytest.mark.parametrize("B,T,S,H", [(1, 1024, 1024, 10), (1, 4096, 4096, 10), (2, 1024, 1024, 20), (1, 1024, 77, 20)])
