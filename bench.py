@@ -35,7 +35,7 @@ KERNEL = {"linear_fp8": "gemm_dma_kernel<f8, CONV=false>", "quantize_fp8": "quan
           "linear": "gemm_dma_kernel / gemm8p_kernel <bf16, CONV=false>",
           "linear_xattn": "gemm_dma_kernel<bf16, 128, 64, ..., XA=true> (query projection + text-context attention in its epilogue)", "conv2d": "conv_halo_kernel / gemm_dma_kernel<bf16, CONV=true>",
           "attention_self": "attn32i_kernel<7, true> / attn32i_kernel<4, true>", "attention_cross": "attn16v2_kernel<4, 1>",
-          "group_norm": "gn_stats_nhwc+gn_finalize+gn_apply_nhwc", "layer_norm": "ln_kernel", "geglu": "geglu_kernel"}
+          "group_norm": "gn_cols_finalize+gn_apply_nhwc (statistics from the producer's epilogue; standalone: gn_stats_nhwc+gn_finalize+gn_apply_nhwc)", "layer_norm": "ln_kernel", "geglu": "geglu_kernel"}
 
 
 def parse_args():
@@ -46,6 +46,10 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--latent", type=int, default=128)
     ap.add_argument("--mode", choices=["auto", "loop", "step", "eager"], default="auto")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
+                    help="compute / storage type of the timed run (same matrix-pipe rate; fp16 is the reference call site's own type)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements of the N=1 line (loop-graph replay when the "
+                                                             "timed mode is 'step', the other 16-bit type, strict fp32)")
     ap.add_argument("--fp8", action="store_true", help="transformer-block projections on the fp8 matrix pipe (BASELINE config #5 mode; "
                                                        "a separate line with dtype fp8, never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -135,10 +139,9 @@ def census(loop):
     event record removed (kernel-only time), the step's kernel-only time including the torch glue kernels
     between the operator launches, the per-record cost and the glue time."""
     import torch
-    from stabletriton_amd import ops
-    store = []
+    from stabletriton_amd import _C
+    from tools.census import Census        # wraps the C-ABI entry points of the loaded library (nothing in the product knows)
     loop_mode, loop.mode = loop.mode, "eager"
-    ops.set_census(None)
     loop.run_steps(1)                      # warm the eager path
     torch.cuda.synchronize()
     step0 = int(loop.step.item())
@@ -147,9 +150,9 @@ def census(loop):
     empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
     for a, b in empty:
         a.record(); b.record()
-    ops.set_census(store)
-    loop._step_const(step0 % loop.n_steps)
-    ops.set_census(None)
+    with Census(_C.load()) as c:
+        loop._step_const(step0 % loop.n_steps)
+    store = c.records
     torch.cuda.synchronize()
     loop.mode = loop_mode
     # cost of one event record: between two operator launches with no torch kernel in between, the gap e1(i) -> e0(i+1)
@@ -226,6 +229,68 @@ def roofline_of(name, f, boundary_ms):
     return r
 
 
+def _time_loop(loop, steps, warmup, dev):
+    import torch
+    loop.capture()
+    if warmup:
+        loop.run_steps(warmup)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    loop.run_steps(steps)
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def extras(args, model, gm, loop, mode, dtype, dev, n_sched, cond, x):
+    """Side measurements printed beside the headline (never `value`): the same build in the other modes a reader asks about.
+      loop_graph_it_per_s   - one replay of the 50-step loop hipGraph (north_star's form) when the timed run was step mode
+                              (the driver's --steps 20 --warmup 5 is not a whole number of loops);
+      other16_it_per_s      - the other 16-bit type (fp16 <-> bf16), same protocol;
+      strict_fp32_it_per_s  - the fp32 storage / exact-fp32-MFMA mode, the one that meets north_star's 1e-3 abs gate."""
+    import torch
+    from stabletriton_amd import synth
+    from stabletriton_amd.optimization import optimize_model
+    from stabletriton_amd.pipeline import DenoiseLoop
+    from stabletriton_amd.scheduler import euler_discrete_tables
+    from stabletriton_amd.unet import SDXL_BASE, UNet2DConditionModel
+    out = {}
+
+    def make(g, dt, md):
+        lp = DenoiseLoop(g, args.batch, args.latent, dt, dev, euler_discrete_tables(n_sched), mode=md)
+        lp.set_conditioning(*(c.to(dt) for c in cond))
+        lp.set_noise(x["latent"])
+        return lp
+
+    with torch.no_grad():
+        if mode == "step" and not args.fp8:
+            lp = make(gm, dtype, "loop")
+            ms = _time_loop(lp, n_sched, n_sched, dev)
+            out["loop_graph_it_per_s"] = round(args.batch * 1e3 / ms, 3)
+            del lp
+        if not args.fp8:
+            other = torch.float16 if dtype == torch.bfloat16 else torch.bfloat16
+            with torch.device("meta"):
+                m2 = UNet2DConditionModel(SDXL_BASE)
+            m2 = m2.to_empty(device=dev).to(other).eval().requires_grad_(False)
+            m2.load_state_dict({k: v.to(other) for k, v in model.state_dict().items()})
+            lp = make(optimize_model(m2, cuda_graph=False), other, "step")
+            ms = _time_loop(lp, 20, 5, dev)
+            out["other16_it_per_s"] = {"dtype": "fp16" if other == torch.float16 else "bf16", "value": round(args.batch * 1e3 / ms, 3),
+                                       "finite": bool(torch.isfinite(lp.latent).all())}
+            del lp, m2
+            torch.cuda.empty_cache()
+            with torch.device("meta"):
+                m3 = UNet2DConditionModel(SDXL_BASE)
+            m3 = m3.to_empty(device=dev).float().eval().requires_grad_(False)
+            synth.fill_module_(m3, 0)
+            lp = make(optimize_model(m3, cuda_graph=False), torch.float32, "step")
+            ms = _time_loop(lp, 5, 2, dev)
+            out["strict_fp32_it_per_s"] = round(args.batch * 1e3 / ms, 3)
+            del lp, m3
+            torch.cuda.empty_cache()
+    return out
+
+
 def host_cores():
     """(threads to use, description): physical cores of the host, capped by this process's affinity mask and cgroup CPU quota."""
     logical = os.cpu_count() or 1
@@ -299,6 +364,16 @@ def rccl_report(path):
             "channels": len(set(re.findall(r"Channel (\d+)", txt)))}
 
 
+def rccl_self_check(report, world):
+    """Under backend=nccl the communicator RCCL built must span every rank: a mismatch (or no init record at all) fails
+    the run - the caller exits non-zero, which `self_launch` / torchrun turn into a failed job.  Returns the message or None."""
+    if report is None:
+        return "RCCL wrote no init log (NCCL_DEBUG_FILE missing): the communicator cannot be verified"
+    if report.get("nranks_logged") != world:
+        return f"RCCL logged a communicator of {report.get('nranks_logged')} ranks, the job has {world}"
+    return None
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -311,7 +386,7 @@ def main():
     from stabletriton_amd.scheduler import euler_discrete_tables
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    rccl_log = None
+    rccl_log = rccl_problem = None
     if world_env > 1 and args.backend == "nccl":
         rccl_log = os.path.join(tempfile.gettempdir(), f"st_rccl_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('RANK', '0')}.log")
         os.environ.setdefault("NCCL_DEBUG", "INFO")
@@ -326,7 +401,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    dtype = torch.bfloat16
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    if args.fp8 and dtype != torch.bfloat16:
+        raise SystemExit("--fp8 runs on a bf16 model")
     n_sched = 50
 
     model, t_fill, t_bcast, n_bcast = build_model(dev, dtype, rank, world)
@@ -376,7 +453,7 @@ def main():
             "value": round(world * args.batch * args.steps / elapsed, 3),
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "fp8" if args.fp8 else "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "fp8" if args.fp8 else args.dtype, "data": "synthetic",
             "config": {"workload": f"SDXL-base UNet, latent {args.latent}x{args.latent} (1024x1024 px), bs={args.batch}/GPU, "
                                    f"{n_sched}-step Euler-discrete loop, hipGraph mode={mode}, no CFG"
                                    + (", transformer projections e4m3 x e4m3 (everything else bf16)" if args.fp8 else ""),
@@ -392,6 +469,7 @@ def main():
             result["backend"] = args.backend
             if rccl_log:
                 result["rccl"] = rccl_report(rccl_log)
+                rccl_problem = rccl_self_check(result["rccl"], world) if rank == 0 else None
         if rank == 0 and world == 1:
             if not args.no_census:
                 fam, census_ms, marker_ms, glue_ms = census(loop)
@@ -404,12 +482,17 @@ def main():
                 result["census"] = {"kernel_only_step_ms": round(census_ms, 3), "graph_step_ms": round(ms_per_step, 3),
                                     "launches_per_step": n_launch, "boundary_us_per_launch": round(boundary_ms * 1e3, 3),
                                     "torch_glue_ms": round(glue_ms, 3), "event_record_us": round(marker_ms * 1e3, 2)}
+            if not args.no_extras:
+                result.update(extras(args, model, gm, loop, mode, dtype, dev, n_sched, cond, x))
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(model, args.latent)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+    if rccl_problem:
+        sys.stderr.write(f"bench.py: {rccl_problem}\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

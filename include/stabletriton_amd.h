@@ -23,8 +23,10 @@
 extern "C" {
 #endif
 
-/* element types of activations/weights; accumulation is always fp32 */
-enum { ST_F32 = 0, ST_BF16 = 1 };
+/* element types of activations/weights; accumulation is always fp32.  ST_F16 (IEEE half) is the type the reference's
+ * own call site computes in (implementations/Diffusers/load_sdxl_pipeline.py:17-28 passes a .half() module;
+ * optimizers/replace_attention.py:91 casts q/k/v to fp16): same matrix-pipe rate as bf16, 10 mantissa bits. */
+enum { ST_F32 = 0, ST_BF16 = 1, ST_F16 = 2 };
 
 /* activation-tensor layouts for the image-shaped ops */
 enum { ST_NCHW = 0, ST_NHWC = 1 };
@@ -38,9 +40,10 @@ enum {
     ST_EPI_ROWBIAS   = 16   /* + rowbias[batch(m)][n]     (time-embedding add)    */
 };
 
-int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 9
+int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 10
                                               (6: next-weights hint passed per call, st_timestep_sincos; 7: fp8 entry points; 8: GroupNorm partials from the
-                                              producer; 9: st_ln_linear_xattn) */
+                                              producer; 9: st_ln_linear_xattn; 10: ST_F16 accepted by every entry point
+                                              that takes a dtype, st_ln_linear_xattn takes a dtype) */
 const char* st_last_error(void);           /* host string, thread-local     */
 
 /* GroupNorm (+SiLU).  Replaces reference group_norm_wrapper
@@ -130,11 +133,12 @@ int st_ln_linear(const void* x, const float* row_stats, int row_stats_chunks, co
  *   out[M, H*64] = softmax((LN(x) Wq^T + bias) k^T * scale) v   per head,
  * LayerNorm folded as in st_ln_linear (Wg, c, d, row_stats), k / v the (batch, S, H*64) context projections with token
  * strides ldk / ldv (S < 256), rows_per_batch query rows per batch entry (a multiple of 128).  The query tile never
- * leaves the chip: results are bit-identical to st_ln_linear followed by st_attention.  bf16 only. */
+ * leaves the chip: results are bit-identical to st_ln_linear followed by st_attention.  k / v batches are dense
+ * (batch stride = S * ldk / S * ldv).  dtype: ST_BF16 or ST_F16. */
 int st_ln_linear_xattn(const void* x, const float* row_stats, int row_stats_chunks, const void* Wg,
                        const float* c, const float* d, const void* k, const void* v, void* out,
                        int M, int N, int K, long lda, long ldo, float eps, int rows_per_batch, int S, int H,
-                       long ldk, long ldv, float scale,
+                       long ldk, long ldv, float scale, int dtype,
                        const void* next_weights, size_t next_weights_bytes, void* stream);
 
 /* Fused attention core: out = softmax(q k^T * scale) v per head, no mask.
@@ -186,7 +190,7 @@ int st_timestep_features(const float* t, long t_stride, const int* step, void* o
  * weights, up-converted before the product (kernels/attention_proj.py:36-39, 105-155); here both operands stay OCP
  * e4m3 ("e4m3fn") down to the matrix pipe (v_mfma_f32_16x16x32_fp8_fp8), accumulation fp32, output bf16.
  *
- * st_quantize_fp8: x (rows, C) of `dtype`, row stride ldx elements -> xq (rows, C) e4m3 bytes, contiguous, and
+ * st_quantize_fp8: x (rows, C) of `dtype` (any of the three), row stride ldx elements -> xq (rows, C) e4m3 bytes, contiguous, and
  *   row_scale[m] = max_k |x[m][k]| / 448 (fp32), xq[m][k] = e4m3(x[m][k] / row_scale[m]), round to nearest even.
  * st_layer_norm_quantize_fp8: the same on LayerNorm(x) (the layer_norm_wrapper -> linear_wrapper pair of the
  *   transformer blocks as one pass over x); x (rows, C) contiguous.

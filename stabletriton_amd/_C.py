@@ -13,10 +13,10 @@ import torch  # noqa: F401  (loads torch's libamdhip64 first so ours binds to th
 
 from .build import lib_path
 
-ST_F32, ST_BF16 = 0, 1
+ST_F32, ST_BF16, ST_F16 = 0, 1, 2
 ST_NCHW, ST_NHWC = 0, 1
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_RESIDUAL, EPI_ROWBIAS = 1, 2, 4, 8, 16
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _p, _i, _l, _f, _z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
@@ -30,7 +30,7 @@ SIGNATURES = {
     "st_geglu": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _i, _p]),
     "st_linear": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _p, _z, _p, _i, _p, _p, _i, _p, _p, _z, _p]),
     "st_ln_linear": (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _l, _l, _f, _i, _i, _p, _z, _p]),
-    "st_ln_linear_xattn": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _l, _l, _f, _i, _i, _i, _l, _l, _f, _p, _z, _p]),
+    "st_ln_linear_xattn": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _l, _l, _f, _i, _i, _i, _l, _l, _f, _i, _p, _z, _p]),
     "st_attention": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _l, _l, _f, _i, _p]),
     "st_conv2d": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _i, _p, _p, _z, _p]),
     "st_group_norm_from_stats": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p, _i, _i, _p, _i, _i, _p, _p]),
@@ -50,12 +50,15 @@ class BackendError(RuntimeError):
     pass
 
 
-def load():
-    """Load (once) and return the operator library; raise if it is not built."""
+def load(path=None):
+    """Load (once) and return the operator library; raise if it is not built.  `path`: developer tools (tools/*.py A/B runs
+    on -D variant builds) name another build of the same ABI explicitly, before anything else has loaded the product one."""
     global _lib
     if _lib is not None:
+        if path is not None and os.path.abspath(path) != _lib._name:
+            raise BackendError(f"operator library already loaded from {_lib._name}")
         return _lib
-    path = lib_path()
+    path = os.path.abspath(path) if path is not None else lib_path()
     if not os.path.exists(path):
         raise BackendError(
             f"{path} not found: the HIP operator library is not built. "
@@ -80,9 +83,11 @@ def check(status: int, what: str) -> None:
 def dtype_code(dt: torch.dtype) -> int:
     if dt == torch.bfloat16:
         return ST_BF16
+    if dt == torch.float16:
+        return ST_F16
     if dt == torch.float32:
         return ST_F32
-    raise BackendError(f"unsupported dtype {dt}: the HIP operators take bfloat16 or float32")
+    raise BackendError(f"unsupported dtype {dt}: the HIP operators take bfloat16, float16 or float32")
 
 
 def stream_ptr() -> int:

@@ -26,10 +26,6 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
 
 
 def lib_path() -> str:
-    # ST_LIB_VARIANT=<dir under lib/> selects an alternative build (developer A/B runs only)
-    variant = os.environ.get("ST_LIB_VARIANT")
-    if variant:
-        return os.path.join(LIBDIR, variant, LIBNAME)
     return os.path.join(LIBDIR, LIBNAME)
 
 
@@ -82,7 +78,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             f.write(dg)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(jobs))) as ex:
         objs = list(ex.map(compile_one, jobs))
     out = lib_path()
     if force or not os.path.exists(out) or any(not j[4] for j in jobs):

@@ -17,16 +17,16 @@
 #define ST_ATTENTION_TU 1
 #include "attention_core.h"
 
-template <int NW, int TAG>
-__global__ __launch_bounds__(NW * 64) void attn16v2_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
-                                                           const bf16* __restrict__ V, bf16* __restrict__ O,
+template <typename E, int NW, int TAG>
+__global__ __launch_bounds__(NW * 64) void attn16v2_kernel(const E* __restrict__ Q, const E* __restrict__ K,
+                                                           const E* __restrict__ V, E* __restrict__ O,
                                                            int T, int S, long ldq, long ldk, long ldv, long ldo, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) char lds[3 * 2 * ATT_KV * 128];
     const int t_ = threadIdx.x, lane = t_ & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t_ >> 6);
     const int head = blockIdx.y, b = blockIdx.z;
     const int row0 = blockIdx.x * NW * 16;
-    attn16_core<NW>(Q + (size_t)b * T * ldq + (size_t)row0 * ldq + (size_t)head * ATT_D, ldq, T - row0,
+    attn16_core<E, NW>(Q + (size_t)b * T * ldq + (size_t)row0 * ldq + (size_t)head * ATT_D, ldq, T - row0,
                     K + (size_t)b * S * ldk + (size_t)head * ATT_D, V + (size_t)b * S * ldv + (size_t)head * ATT_D, ldk, ldv, S,
                     O + (size_t)b * T * ldo + (size_t)row0 * ldo + (size_t)head * ATT_D, ldo, T - row0, scale_log2e, lds, wave, lane);
 }
@@ -40,11 +40,13 @@ __global__ __launch_bounds__(NW * 64) void attn16v2_kernel(const bf16* __restric
 //     PV phase, 12 MFMAs V^T(t) P(t) (+ ones block)  | exp + pack of the second half, max of the next scores | K(t+2) reads
 // then the counted DMA wait, one block barrier, and the (rare) branch that moves the lazy maximum.  Because P(t) is
 // multiplied in the trip that exponentiates it, nothing is pending when the maximum moves.
-template <int NW, bool LD>
-__global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
-                                                      const bf16* __restrict__ V, bf16* __restrict__ O,
+template <typename E, int NW, bool LD>
+__global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const E* __restrict__ Q, const E* __restrict__ K,
+                                                      const E* __restrict__ V, E* __restrict__ O,
                                                       int T, int S, long ldq, long ldk, long ldv, long ldo, float scale_log2e,
                                                       int H, unsigned long long* probe) {
+    typedef typename V16<E>::x8 E8;
+    typedef typename V16<E>::x4 E4;
     constexpr int TILE_B = ATT_KV * 128;
     constexpr int BUF_B = 2 * TILE_B;
     constexpr int RB = 6;                             // ring buffers
@@ -74,10 +76,10 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
     const int q0 = (xblk * NW + wave) * 32;
     const int qrow = min(q0 + r32, T - 1);
 
-    const bf16* Qb = Q + (size_t)b * T * ldq + (size_t)head * ATT_D;
-    const bf16* Kb = K + (size_t)b * S * ldk + (size_t)head * ATT_D;
-    const bf16* Vb = V + (size_t)b * S * ldv + (size_t)head * ATT_D;
-    const bf16* zeros = reinterpret_cast<const bf16*>(g_att_zero16);
+    const E* Qb = Q + (size_t)b * T * ldq + (size_t)head * ATT_D;
+    const E* Kb = K + (size_t)b * S * ldk + (size_t)head * ATT_D;
+    const E* Vb = V + (size_t)b * S * ldv + (size_t)head * ATT_D;
+    const E* zeros = reinterpret_cast<const E*>(g_att_zero16);
 
     const int nkt = (S + ATT_KV - 1) / ATT_KV;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(att_lds_offset(lds));
@@ -88,7 +90,7 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
         //      landed), then one per trip (tile kt+3 landed, tile kt+4 in flight).
         if (wave == NW) {
             const int lr_ = lane >> 3, pc_ = lane & 7;
-            const bf16* src[16];
+            const E* src[16];
 #pragma unroll
             for (int pce = 0; pce < 16; ++pce) {
                 const int isv = pce >> 3, row = (pce & 7) * 8 + lr_;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
 #pragma unroll
                 for (int pce = 0; pce < 16; ++pce) {
                     const int isv = pce >> 3, rb = pce & 7;
-                    const bf16* sp = (whole || kt * ATT_KV + rb * 8 + lr_ < S) ? src[pce] : zeros;
+                    const E* sp = (whole || kt * ATT_KV + rb * 8 + lr_ < S) ? src[pce] : zeros;
                     att_dma16(sp, slot + isv * TILE_B + rb * 1024);
                     src[pce] += isv ? vstep : kstep;
                 }
@@ -139,13 +141,13 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
         asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(qraw[ks]) : "v"(Qb + (size_t)qrow * ldq + 16 * ks + 8 * h) : "memory");
-    bf16x8 qf[4];
-    bf16x8 ones;
+    E8 qf[4];
+    E8 ones;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (bf16)(r32 == 0 ? 1.0f : 0.0f);
+    for (int j = 0; j < 8; ++j) ones[j] = (E)(r32 == 0 ? 1.0f : 0.0f);
 
     const int lr = lane >> 3, pc = lane & 7;
-    const bf16* dsrc[PIECES];
+    const E* dsrc[PIECES];
     long dstep[PIECES];
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
@@ -168,7 +170,7 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
             att_dma16(dsrc[i], slot + isv * TILE_B + rb * 1024);
         } else {
             const bool live = kt < nkt;
-            const bf16* src = (live && kt * ATT_KV + rb * 8 + lr < S) ? dsrc[i] : zeros;
+            const E* src = (live && kt * ATT_KV + rb * 8 + lr < S) ? dsrc[i] : zeros;
             att_dma16(src, live ? slot + isv * TILE_B + rb * 1024 : dump_off);
         }
         dsrc[i] += dstep[i];
@@ -197,7 +199,7 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
     }
     f32x16 negm;                                       // -m_ref of this lane's query row in every register: the C operand of a tile's first MFMAs
     f32x16 o0 = {0}, o1 = {0}, o2 = {0};
-    bf16x8 kf0[4], kf1[4], vf[4][2], pb[4];
+    E8 kf0[4], kf1[4], vf[4][2], pb[4];
     auto mask_tail = [&](f32x16& s0, f32x16& s1, int kt) {
         const int kbase = kt * ATT_KV + 4 * h;
 #pragma unroll
@@ -222,23 +224,23 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 raw = __builtin_bit_cast(bf16x8, qraw[ks]);
+        const E8 raw = __builtin_bit_cast(E8, qraw[ks]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[ks][j] = (bf16)((float)raw[j] * scale_log2e);
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (E)((float)raw[j] * scale_log2e);
     }
     f32x16 sa0, sa1, sb0, sb1;
     {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            kf0[ks] = *reinterpret_cast<const bf16x8*>(lds + k_off[ks][0]);
-            kf1[ks] = *reinterpret_cast<const bf16x8*>(lds + k_off[ks][1]);
+            kf0[ks] = *reinterpret_cast<const E8*>(lds + k_off[ks][0]);
+            kf1[ks] = *reinterpret_cast<const E8*>(lds + k_off[ks][1]);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sa0[r] = 0.f; sa1[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], sa0, 0, 0, 0);
-            sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], sa1, 0, 0, 0);
+            sa0 = AttMma<E>::m32(kf0[ks], qf[ks], sa0);
+            sa1 = AttMma<E>::m32(kf1[ks], qf[ks], sa1);
         }
         if (ATT_KV > S) mask_tail(sa0, sa1, 0);
         const float rmx = xmax32(max32(sa0, sa1));
@@ -250,8 +252,8 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            kf0[ks] = *reinterpret_cast<const bf16x8*>(lds + BUF_B + k_off[ks][0]);
-            kf1[ks] = *reinterpret_cast<const bf16x8*>(lds + BUF_B + k_off[ks][1]);
+            kf0[ks] = *reinterpret_cast<const E8*>(lds + BUF_B + k_off[ks][0]);
+            kf1[ks] = *reinterpret_cast<const E8*>(lds + BUF_B + k_off[ks][1]);
         }
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");           // tile 2: its K fragments are read in the first trip
         __builtin_amdgcn_s_barrier();
@@ -267,11 +269,11 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const int ks = g >> 1;
-            if ((g & 1) == 0) n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], ks == 0 ? negm : n0, 0, 0, 0);
-            else              n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], ks == 0 ? negm : n1, 0, 0, 0);
+            if ((g & 1) == 0) n0 = AttMma<E>::m32(kf0[ks], qf[ks], ks == 0 ? negm : n0);
+            else              n1 = AttMma<E>::m32(kf1[ks], qf[ks], ks == 0 ? negm : n1);
             const float e0 = fast_exp2(s0[2 * g]), e1 = fast_exp2(s0[2 * g + 1]);
-            pb[g >> 2][2 * (g & 3)] = (bf16)e0; pb[g >> 2][2 * (g & 3) + 1] = (bf16)e1;
-            vf[g >> 1][g & 1] = v_frag(vb, ((g & 1) ? v_base1 : v_base0) + (g >> 1) * 2048, ((g & 1) ? v_base1 : v_base0) + (g >> 1) * 2048 + 1024);
+            pb[g >> 2][2 * (g & 3)] = (E)e0; pb[g >> 2][2 * (g & 3) + 1] = (E)e1;
+            vf[g >> 1][g & 1] = v_frag<E>(vb, ((g & 1) ? v_base1 : v_base0) + (g >> 1) * 2048, ((g & 1) ? v_base1 : v_base0) + (g >> 1) * 2048 + 1024);
             __builtin_amdgcn_sched_barrier(0);
         }
         AP_STAMP(tq)
@@ -280,12 +282,12 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
 #pragma unroll
         for (int p = 0; p < 12; ++p) {
             const int s_ = p / 3, w = p % 3;
-            if (w == 0)      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s_][0], pb[s_], o0, 0, 0, 0);
-            else if (w == 1) o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s_][1], pb[s_], o1, 0, 0, 0);
-            else             o2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb[s_], o2, 0, 0, 0);
+            if (w == 0)      o0 = AttMma<E>::m32(vf[s_][0], pb[s_], o0);
+            else if (w == 1) o1 = AttMma<E>::m32(vf[s_][1], pb[s_], o1);
+            else             o2 = AttMma<E>::m32(ones, pb[s_], o2);
             if (p < 8) {
                 const float e0 = fast_exp2(s1[2 * p]), e1 = fast_exp2(s1[2 * p + 1]);
-                pb[2 + (p >> 2)][2 * (p & 3)] = (bf16)e0; pb[2 + (p >> 2)][2 * (p & 3) + 1] = (bf16)e1;
+                pb[2 + (p >> 2)][2 * (p & 3)] = (E)e0; pb[2 + (p >> 2)][2 * (p & 3) + 1] = (E)e1;
             }
             if (p >= 2 && p < 6) {                     // one chain start per gap
                 const int c = p - 2;
@@ -313,8 +315,8 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
             if (p >= 12 - PIECES) dma_piece(kt + 4, p - (12 - PIECES));
             if (p >= 4) {
                 const int i = p - 4, ks = i >> 1;
-                if ((i & 1) == 0) kf0[ks] = *reinterpret_cast<const bf16x8*>(kb + k_off[ks][0]);
-                else              kf1[ks] = *reinterpret_cast<const bf16x8*>(kb + k_off[ks][1]);
+                if ((i & 1) == 0) kf0[ks] = *reinterpret_cast<const E8*>(kb + k_off[ks][0]);
+                else              kf1[ks] = *reinterpret_cast<const E8*>(kb + k_off[ks][1]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -361,14 +363,14 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
     const float l = __shfl(o2[0], r32, 64);
     const float inv = 1.0f / l;
     if (q0 + r32 < T) {
-        bf16* orow = O + (size_t)b * T * ldo + (size_t)(q0 + r32) * ldo + (size_t)head * ATT_D;
+        E* orow = O + (size_t)b * T * ldo + (size_t)(q0 + r32) * ldo + (size_t)head * ATT_D;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            bf16x4 a_, c_;
+            E4 a_, c_;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { a_[e] = (bf16)(o0[4 * g + e] * inv); c_[e] = (bf16)(o1[4 * g + e] * inv); }
-            *reinterpret_cast<bf16x4*>(orow + 8 * g + 4 * h) = a_;
-            *reinterpret_cast<bf16x4*>(orow + 32 + 8 * g + 4 * h) = c_;
+            for (int e = 0; e < 4; ++e) { a_[e] = (E)(o0[4 * g + e] * inv); c_[e] = (E)(o1[4 * g + e] * inv); }
+            *reinterpret_cast<E4*>(orow + 8 * g + 4 * h) = a_;
+            *reinterpret_cast<E4*>(orow + 32 + 8 * g + 4 * h) = c_;
         }
     }
 }
@@ -446,46 +448,51 @@ __global__ __launch_bounds__(128) void attn_f32_kernel(const float* __restrict__
 }
 
 
+template <typename E>
+static int attention16_launch(const void* q, const void* k, const void* v, void* out, int B, int T, int S, int H,
+                              long ldq, long ldk, long ldv, long ldo, float scale, hipStream_t st) {
+    const float c = scale * 1.4426950408889634f;
+    static const int force_nw = att_dev_env_int("ST_ATT_NW", 0);       // dev knob: waves per block of the self-attention kernel
+    static const int force_16 = att_dev_env_int("ST_ATT_R16", -1);     // dev knob: 1 = 16-row kernel for every S, 0 = never
+    const bool rows16 = force_16 >= 0 ? force_16 != 0 : S < 256;
+    if (rows16) {
+        // measured (tools/op_bench.py): 16-row waves win for the 77-key text context (more waves for a two-tile loop);
+        // TAG 1 only gives these launches their own kernel name in the profiles
+        hipLaunchKernelGGL((attn16v2_kernel<E, 4, 1>), dim3(cdiv(T, 64), H, B), dim3(256), 0, st, (const E*)q, (const E*)k,
+                           (const E*)v, (E*)out, T, S, ldq, ldk, ldv, ldo, c);
+        return st_check_launch("attention");
+    }
+    constexpr size_t RING = 6 * 2 * ATT_KV * 128 + 1024;      // six (K, V) tile slots + the dump line of the dummy DMAs
+    // Compute waves per block, each with one extra wave that issues every LDS-DMA of every tile (a compute wave that
+    // queues in the CU's load path multiplies nothing meanwhile: 16 wave-instructions of 1 KiB per tile, 16 cycles each).
+    // Seven compute waves (224 query rows; with the loader two waves per SIMD) share a K/V ring unless that leaves half
+    // the CUs idle: SDXL's 32x32 level at batch 1 is then 160 blocks of four waves, one per SIMD (15.4 us against 20.2).
+    // Against eight self-loading waves: 4096 tokens 73 -> 70 us (batch 1), 215 -> 206 us (batch 4); 1024 tokens at
+    // batch 4 43.8 -> 39.2 us.
+    int nw = (long)cdiv(T, 256) * H * B <= 128 ? 4 : 7;
+    if (force_nw == 4 || force_nw == 8 || force_nw == 7) nw = force_nw;
+    auto kfn = nw == 8 ? attn32i_kernel<E, 8, false> : nw == 7 ? attn32i_kernel<E, 7, true> : attn32i_kernel<E, 4, true>;
+    static unsigned long long lds_ok[3] = {0, 0, 0};          // per kernel: bit mask over device ordinals
+    ensure_dynamic_lds(kfn, RING, &lds_ok[nw == 8 ? 0 : nw == 7 ? 1 : 2]);
+    ST_REQUIRE((long)cdiv(T, 32 * nw) * H * B < (1L << 31), "attention: too many blocks");
+    hipLaunchKernelGGL(kfn, dim3(cdiv(T, 32 * nw) * H * B), dim3(nw == 4 ? 320 : 512), RING, st, (const E*)q, (const E*)k, (const E*)v,
+                       (E*)out, T, S, ldq, ldk, ldv, ldo, c, H, ATT_PROBE_ARG);
+    return st_check_launch("attention");
+}
+
 extern "C" int st_attention(const void* q, const void* k, const void* v, void* out, int B, int T, int S, int H, int D,
                             long ldq, long ldk, long ldv, long ldo, float scale, int dtype, void* stream) {
     ST_REQUIRE(q && k && v && out, "attention: null pointer");
     ST_REQUIRE(B > 0 && T > 0 && S > 0 && H > 0, "attention: bad shape B=%d T=%d S=%d H=%d", B, T, S, H);
     ST_REQUIRE(D == ATT_D, "attention: head_dim %d not supported (only %d)", D, ATT_D);
     ST_REQUIRE(H <= 65535 && B <= 65535, "attention: too many heads/batches for one launch");
-    const int vec = dtype == ST_BF16 ? 8 : 4;
+    const int vec = st_dtype_is16(dtype) ? 8 : 4;
     ST_REQUIRE(ldq % vec == 0 && ldk % vec == 0 && ldv % vec == 0 && ldo % 4 == 0, "attention: strides must keep 16-byte alignment");
     ST_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 == 0, "attention: pointers must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == ST_BF16) {
-        const float c = scale * 1.4426950408889634f;
-        static const int force_nw = att_dev_env_int("ST_ATT_NW", 0);       // dev knob: waves per block of the self-attention kernel
-        static const int force_16 = att_dev_env_int("ST_ATT_R16", -1);     // dev knob: 1 = 16-row kernel for every S, 0 = never
-        const bool rows16 = force_16 >= 0 ? force_16 != 0 : S < 256;
-        if (rows16) {
-            // measured (tools/op_bench.py): 16-row waves win for the 77-key text context (more waves for a two-tile loop);
-            // TAG 1 only gives these launches their own kernel name in the profiles
-            hipLaunchKernelGGL((attn16v2_kernel<4, 1>), dim3(cdiv(T, 64), H, B), dim3(256), 0, st, (const bf16*)q, (const bf16*)k,
-                               (const bf16*)v, (bf16*)out, T, S, ldq, ldk, ldv, ldo, c);
-            return st_check_launch("attention");
-        }
-        constexpr size_t RING = 6 * 2 * ATT_KV * 128 + 1024;      // six (K, V) tile slots + the dump line of the dummy DMAs
-        // Compute waves per block, each with one extra wave that issues every LDS-DMA of every tile (a compute wave that
-        // queues in the CU's load path multiplies nothing meanwhile: 16 wave-instructions of 1 KiB per tile, 16 cycles each).
-        // Seven compute waves (224 query rows; with the loader two waves per SIMD) share a K/V ring unless that leaves half
-        // the CUs idle: SDXL's 32x32 level at batch 1 is then 160 blocks of four waves, one per SIMD (15.4 us against 20.2).
-        // Against eight self-loading waves: 4096 tokens 73 -> 70 us (batch 1), 215 -> 206 us (batch 4); 1024 tokens at
-        // batch 4 43.8 -> 39.2 us.
-        int nw = (long)cdiv(T, 256) * H * B <= 128 ? 4 : 7;
-        if (force_nw == 4 || force_nw == 8 || force_nw == 7) nw = force_nw;
-        auto kfn = nw == 8 ? attn32i_kernel<8, false> : nw == 7 ? attn32i_kernel<7, true> : attn32i_kernel<4, true>;
-        static bool once = ((void)hipFuncSetAttribute((const void*)attn32i_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RING),
-                            (void)hipFuncSetAttribute((const void*)attn32i_kernel<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RING),
-                            (void)hipFuncSetAttribute((const void*)attn32i_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RING), true);
-        (void)once;
-        ST_REQUIRE((long)cdiv(T, 32 * nw) * H * B < (1L << 31), "attention: too many blocks");
-        hipLaunchKernelGGL(kfn, dim3(cdiv(T, 32 * nw) * H * B), dim3(nw == 4 ? 320 : 512), RING, st, (const bf16*)q, (const bf16*)k, (const bf16*)v,
-                           (bf16*)out, T, S, ldq, ldk, ldv, ldo, c, H, ATT_PROBE_ARG);
-    } else if (dtype == ST_F32) {
+    if (dtype == ST_BF16) return attention16_launch<bf16>(q, k, v, out, B, T, S, H, ldq, ldk, ldv, ldo, scale, st);
+    if (dtype == ST_F16) return attention16_launch<f16>(q, k, v, out, B, T, S, H, ldq, ldk, ldv, ldo, scale, st);
+    if (dtype == ST_F32) {
         hipLaunchKernelGGL(attn_f32_kernel, dim3(cdiv(T, 128), H, B), dim3(128), 0, st, (const float*)q, (const float*)k,
                            (const float*)v, (float*)out, T, S, ldq, ldk, ldv, ldo, scale);
     } else {

@@ -104,18 +104,33 @@ static constexpr float ATT_LAG = 6.0f;
 
 // V^T fragments through the compiler's own transposed LDS read (it places the two 8-byte halves of an MFMA operand
 // in adjacent registers and counts the reads itself; the inline-asm form needed a v_mov per half)
-typedef __attribute__((address_space(3))) bf16x4 att_lds_bf16x4;
-__device__ __forceinline__ bf16x8 v_frag(const char* lds_base, int off_lo, int off_hi) {
-    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((att_lds_bf16x4*)(lds_base + off_lo));
-    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((att_lds_bf16x4*)(lds_base + off_hi));
-    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+// (the 16-bit-integer form of the builtin: the read moves bits, so one form serves bf16 and f16)
+typedef __attribute__((ext_vector_type(4))) short att_s16x4;
+typedef __attribute__((ext_vector_type(8))) short att_s16x8;
+typedef __attribute__((address_space(3))) att_s16x4 att_lds_s16x4;
+template <typename E>
+__device__ __forceinline__ typename V16<E>::x8 v_frag(const char* lds_base, int off_lo, int off_hi) {
+    const att_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s16x4*)(lds_base + off_lo));
+    const att_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s16x4*)(lds_base + off_hi));
+    return __builtin_bit_cast(typename V16<E>::x8, (att_s16x8)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
-// eight probabilities -> one MFMA operand: four v_cvt_pk_bf16_f32
-__device__ __forceinline__ bf16x8 pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
-    bf16x8 r;
-    r[0] = (bf16)a0; r[1] = (bf16)a1; r[2] = (bf16)a2; r[3] = (bf16)a3; r[4] = (bf16)a4; r[5] = (bf16)a5; r[6] = (bf16)a6; r[7] = (bf16)a7;
+// eight probabilities -> one MFMA operand: four packed conversions (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)
+template <typename E>
+__device__ __forceinline__ typename V16<E>::x8 pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+    typename V16<E>::x8 r;
+    r[0] = (E)a0; r[1] = (E)a1; r[2] = (E)a2; r[3] = (E)a3; r[4] = (E)a4; r[5] = (E)a5; r[6] = (E)a6; r[7] = (E)a7;
     return r;
 }
+// the two MFMA shapes of the attention kernels, per 16-bit element type (same cycles for bf16 and f16)
+template <typename E> struct AttMma;
+template <> struct AttMma<bf16> {
+    static __device__ __forceinline__ f32x4 m16(const bf16x8& a, const bf16x8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x16 m32(const bf16x8& a, const bf16x8& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct AttMma<f16> {
+    static __device__ __forceinline__ f32x4 m16(const f16x8& a, const f16x8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x16 m32(const f16x8& a, const f16x8& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 
 // Three-way maximum, deliberately NOT inline asm: the scores it reads come straight out of MFMAs, and the hardware does
 // not interlock an MFMA result against a VALU read - the compiler inserts the wait states, but only for instructions it
@@ -127,9 +142,11 @@ __device__ __forceinline__ float att_max3(float a, float b, float c) { return fm
 // attention can run it as its epilogue on the Q tile it has just left in LDS (gemm.hip, st_ln_linear_xattn).
 //   Qb / Ob: row 0 of this block's NW*16 queries / outputs of ONE head (global or LDS for Qb); rows >= q_rows are clamped,
 //   rows >= o_rows not stored; Kb / Vb: key 0 of that head; lds: 3 * 16 KiB ring, 16-byte aligned.
-template <int NW>
-__device__ __forceinline__ void attn16_core(const bf16* Qb, long ldq, int q_rows, const bf16* Kb, const bf16* Vb, long ldk, long ldv,
-                                            int S, bf16* Ob, long ldo, int o_rows, float scale_log2e, char* lds, int wave, int lane) {
+template <typename E, int NW>
+__device__ __forceinline__ void attn16_core(const E* Qb, long ldq, int q_rows, const E* Kb, const E* Vb, long ldk, long ldv,
+                                            int S, E* Ob, long ldo, int o_rows, float scale_log2e, char* lds, int wave, int lane) {
+    typedef typename V16<E>::x8 E8;
+    typedef typename V16<E>::x4 E4;
     constexpr int TILE_B = ATT_KV * 128;
     constexpr int BUF_B = 2 * TILE_B;
     constexpr int PIECES = 16 / NW;
@@ -137,24 +154,24 @@ __device__ __forceinline__ void attn16_core(const bf16* Qb, long ldq, int q_rows
     const int c16 = lane & 15, g = lane >> 4;
     const int q0 = wave * 16;
     const int qrow = min(q0 + c16, q_rows - 1);
-    const bf16* zeros = reinterpret_cast<const bf16*>(g_att_zero16);
+    const E* zeros = reinterpret_cast<const E*>(g_att_zero16);
 
-    bf16x8 qf[2];
+    E8 qf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 raw = *reinterpret_cast<const bf16x8*>(Qb + (size_t)qrow * ldq + 32 * ks + 8 * g);
+        const E8 raw = *reinterpret_cast<const E8*>(Qb + (size_t)qrow * ldq + 32 * ks + 8 * g);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[ks][j] = (bf16)((float)raw[j] * scale_log2e);
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (E)((float)raw[j] * scale_log2e);
     }
     // V^T "row 64": ones for the lanes that hold d = 0 of the extra block, zeros elsewhere
-    bf16x8 ones;
+    E8 ones;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (bf16)(c16 == 0 ? 1.0f : 0.0f);
+    for (int j = 0; j < 8; ++j) ones[j] = (E)(c16 == 0 ? 1.0f : 0.0f);
 
     // LDS-DMA sources: one running pointer per piece, advanced by 64 keys per tile (no per-tile address arithmetic);
     // only a tile that reaches past S takes the checked form (rows beyond S read a zero line)
     const int lr = lane >> 3, pc = lane & 7;
-    const bf16* dsrc[PIECES];
+    const E* dsrc[PIECES];
     long dstep[PIECES];
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
@@ -170,7 +187,7 @@ __device__ __forceinline__ void attn16_core(const bf16* Qb, long ldq, int q_rows
         for (int i = 0; i < PIECES; ++i) {
             const int pce = wave * PIECES + i;
             const int isv = pce >> 3, rb = pce & 7;
-            const bf16* src = dsrc[i];
+            const E* src = dsrc[i];
             if (tail && kt * ATT_KV + rb * 8 + lr >= S) src = zeros;
             __builtin_amdgcn_global_load_lds((att_gbl_cvoid_t*)src, (att_lds_void_t*)(lds + buf * BUF_B + isv * TILE_B + rb * 1024), 16, 0, 0);
             dsrc[i] += dstep[i];
@@ -190,11 +207,11 @@ __device__ __forceinline__ void attn16_core(const bf16* Qb, long ldq, int q_rows
         const char* kb_ = lds + buf * BUF_B;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kb_ + kb * 2048 + k_off0);
-            const bf16x8 kc = *reinterpret_cast<const bf16x8*>(kb_ + kb * 2048 + k_off1);
+            const E8 ka = *reinterpret_cast<const E8*>(kb_ + kb * 2048 + k_off0);
+            const E8 kc = *reinterpret_cast<const E8*>(kb_ + kb * 2048 + k_off1);
             f32x4 acc = {-m_ref, -m_ref, -m_ref, -m_ref};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[0], acc, 0, 0, 0);
-            s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc, qf[1], acc, 0, 0, 0);
+            acc = AttMma<E>::m16(ka, qf[0], acc);
+            s[kb] = AttMma<E>::m16(kc, qf[1], acc);
         }
     };
 
@@ -217,15 +234,15 @@ __device__ __forceinline__ void attn16_core(const bf16* Qb, long ldq, int q_rows
         __builtin_amdgcn_s_barrier();                              // ... and everyone's; tile kt-1 is dead
         if (kt + 2 < nkt) dma_tile(kt + 2, fb);
         // V^T fragments of this tile [key pair-block kp][d block]: issued now, first used after the softmax
-        bf16x8 vf[2][4];
+        E8 vf[2][4];
         {
             const char* vb = lds + cur * BUF_B + TILE_B;
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {
-                vf[kp][0] = v_frag(vb, v_off0 + kp * 4096, v_off0 + kp * 4096 + 2048);
-                vf[kp][1] = v_frag(vb, v_off1 + kp * 4096, v_off1 + kp * 4096 + 2048);
-                vf[kp][2] = v_frag(vb, v_off2 + kp * 4096, v_off2 + kp * 4096 + 2048);
-                vf[kp][3] = v_frag(vb, v_off3 + kp * 4096, v_off3 + kp * 4096 + 2048);
+                vf[kp][0] = v_frag<E>(vb, v_off0 + kp * 4096, v_off0 + kp * 4096 + 2048);
+                vf[kp][1] = v_frag<E>(vb, v_off1 + kp * 4096, v_off1 + kp * 4096 + 2048);
+                vf[kp][2] = v_frag<E>(vb, v_off2 + kp * 4096, v_off2 + kp * 4096 + 2048);
+                vf[kp][3] = v_frag<E>(vb, v_off3 + kp * 4096, v_off3 + kp * 4096 + 2048);
             }
         }
         // scores of the next tile: the matrix pipe works on them under this softmax (after the last tile the ring
@@ -270,11 +287,11 @@ __device__ __forceinline__ void attn16_core(const bf16* Qb, long ldq, int q_rows
             for (int r = 0; r < 4; ++r) s[kb][r] = fast_exp2(s[kb][r]);
 #pragma unroll
         for (int kp = 0; kp < 2; ++kp) {
-            const bf16x8 pb = pack8(s[2 * kp][0], s[2 * kp][1], s[2 * kp][2], s[2 * kp][3],
+            const E8 pb = pack8<E>(s[2 * kp][0], s[2 * kp][1], s[2 * kp][2], s[2 * kp][3],
                                     s[2 * kp + 1][0], s[2 * kp + 1][1], s[2 * kp + 1][2], s[2 * kp + 1][3]);
 #pragma unroll
-            for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kp][db], pb, o[db], 0, 0, 0);
-            o[4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb, o[4], 0, 0, 0);
+            for (int db = 0; db < 4; ++db) o[db] = AttMma<E>::m16(vf[kp][db], pb, o[db]);
+            o[4] = AttMma<E>::m16(ones, pb, o[4]);
         }
     };
     int cur = 0;
@@ -290,13 +307,13 @@ __device__ __forceinline__ void attn16_core(const bf16* Qb, long ldq, int q_rows
     const float l = __shfl(o[4][0], c16, 64);
     const float inv = 1.0f / l;
     if (q0 + c16 < o_rows) {
-        bf16* orow = Ob + (size_t)(q0 + c16) * ldo;
+        E* orow = Ob + (size_t)(q0 + c16) * ldo;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-            bf16x4 a_;
+            E4 a_;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a_[e] = (bf16)(o[db][e] * inv);
-            *reinterpret_cast<bf16x4*>(orow + 16 * db + 4 * g) = a_;
+            for (int e = 0; e < 4; ++e) a_[e] = (E)(o[db][e] * inv);
+            *reinterpret_cast<E4*>(orow + 16 * db + 4 * g) = a_;
         }
     }
 }

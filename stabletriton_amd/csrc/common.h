@@ -10,6 +10,9 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef _Float16 f16;                    // IEEE half: the reference's own compute type (load_sdxl_pipeline.py:17-28 hands optimize_model a .half() module)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -34,6 +37,16 @@ template <> struct Elem<bf16> {
     static __device__ __forceinline__ bf16 from_f(float v) { return (bf16)v; }
 };
 
+template <> struct Elem<f16> {
+    static constexpr int VEC = 8;
+    static __device__ __forceinline__ float to_f(f16 v) { return (float)v; }
+    static __device__ __forceinline__ f16 from_f(float v) { return (f16)v; }
+};
+// 8- and 4-element vectors of a 16-bit element type (MFMA operands, 8-byte stores)
+template <typename T> struct V16;
+template <> struct V16<bf16> { typedef bf16x8 x8; typedef bf16x4 x4; };
+template <> struct V16<f16> { typedef f16x8 x8; typedef f16x4 x4; };
+
 // 16-byte vector of T, unpacked to floats and back
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
@@ -47,6 +60,13 @@ template <> struct Vec16<bf16> {
     static constexpr int N = 8;
     __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
     __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16)x; }
+};
+
+template <> struct Vec16<f16> {
+    f16x8 v;
+    static constexpr int N = 8;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (f16)x; }
 };
 
 template <typename T>
@@ -94,3 +114,21 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Kernels that need more than 64 KiB of dynamic LDS have that limit raised with hipFuncSetAttribute, which is PER DEVICE:
+// `done` is the caller's bit mask over device ordinals (one static per kernel instantiation), so a process that drives
+// several devices raises it on each of them, once.
+template <typename K>
+static inline void ensure_dynamic_lds(K kernel, size_t bytes, unsigned long long* done) {
+    if (bytes <= 64 * 1024) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(done, __ATOMIC_RELAXED) & bit) return;
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    __atomic_fetch_or(done, bit, __ATOMIC_RELAXED);
+}
+
+// dtype code of the C ABI -> element size / checks shared by the entry points
+static inline bool st_dtype_is16(int dtype) { return dtype == ST_BF16 || dtype == ST_F16; }
+static inline bool st_dtype_ok(int dtype) { return dtype == ST_F32 || st_dtype_is16(dtype); }

@@ -98,6 +98,7 @@ extern "C" int st_quantize_fp8(const void* x, long ldx, void* xq, float* row_sca
     ST_REQUIRE(((uintptr_t)x | (uintptr_t)xq) % 16 == 0, "quantize_fp8: pointers must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ST_BF16) return quant_launch<bf16, false>(x, ldx, nullptr, nullptr, xq, row_scale, rows, C, 0.f, st);
+    if (dtype == ST_F16) return quant_launch<f16, false>(x, ldx, nullptr, nullptr, xq, row_scale, rows, C, 0.f, st);
     if (dtype == ST_F32) return quant_launch<float, false>(x, ldx, nullptr, nullptr, xq, row_scale, rows, C, 0.f, st);
     return st_fail("quantize_fp8: unsupported dtype %d", dtype);
 }
@@ -108,6 +109,7 @@ extern "C" int st_layer_norm_quantize_fp8(const void* x, const void* gamma, cons
     ST_REQUIRE(((uintptr_t)x | (uintptr_t)xq) % 16 == 0, "layer_norm_quantize_fp8: pointers must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ST_BF16) return quant_launch<bf16, true>(x, C, gamma, beta, xq, row_scale, rows, C, eps, st);
+    if (dtype == ST_F16) return quant_launch<f16, true>(x, C, gamma, beta, xq, row_scale, rows, C, eps, st);
     if (dtype == ST_F32) return quant_launch<float, true>(x, C, gamma, beta, xq, row_scale, rows, C, eps, st);
     return st_fail("layer_norm_quantize_fp8: unsupported dtype %d", dtype);
 }

@@ -1,0 +1,160 @@
+// extern "C" entry points of the GEMM-shaped operators (st_linear, st_ln_linear, st_ln_linear_xattn, st_linear_fp8,
+// st_conv2d): argument checks and GemmArgs plumbing; the kernels live in gemm_core.h and are instantiated per element
+// type in gemm_dense_*.hip / gemm_conv_*.hip / gemm_f32.hip / gemm_fp8.hip.
+#include "gemm_core.h"
+
+#ifdef ST_DEV_CONFIGS
+int g_dbg_cfg = -1, g_dbg_fusek = -1;
+extern "C" void st_debug_force_gemm(int cfg, int fusek) { g_dbg_cfg = cfg; g_dbg_fusek = fusek; }
+#endif
+#ifdef ST_PROBE
+static unsigned long long* g_probe = nullptr;
+extern "C" void st_debug_set_probe(void* p) { g_probe = (unsigned long long*)p; }
+#endif
+
+static int run_dense(const GemmArgs& a, int dtype, hipStream_t st) {
+    switch (dtype) {
+        case ST_BF16: return gemm_dense_bf16(a, st);
+        case ST_F16: return gemm_dense_f16(a, st);
+        default: return gemm_dense_f32(a, st);
+    }
+}
+
+extern "C" int st_linear(const void* x, const void* W, const void* bias, const void* residual, const void* rowbias, void* y,
+                         int M, int N, int K, long lda, long ldc, long ldr, int rows_per_batch, int epilogue, int dtype,
+                         void* workspace, size_t workspace_bytes, float* row_stats, int row_stats_capacity,
+                         int* row_stats_chunks, float* col_stats, int col_stats_tiles, int* col_stats_rows,
+                         const void* next_weights, size_t next_weights_bytes, void* stream) {
+    if (col_stats_rows) *col_stats_rows = 0;
+    ST_REQUIRE(x && W && y, "linear: null pointer");
+    ST_REQUIRE(M > 0 && N > 0 && K > 0, "linear: bad shape M=%d N=%d K=%d", M, N, K);
+    ST_REQUIRE(st_dtype_ok(dtype), "linear: unsupported dtype %d", dtype);
+    const int vec = st_dtype_is16(dtype) ? 8 : 4;
+    ST_REQUIRE(K % vec == 0 && lda % vec == 0, "linear: K=%d and lda=%ld must be multiples of %d", K, lda, vec);
+    ST_REQUIRE(ldc % 4 == 0 && (!(epilogue & ST_EPI_RESIDUAL) || ldr % 4 == 0), "linear: ldc/ldr must be multiples of 4");
+    ST_REQUIRE(((uintptr_t)x | (uintptr_t)W) % 16 == 0 && (uintptr_t)y % 16 == 0, "linear: pointers must be 16-byte aligned");
+    GemmArgs a = {};
+    a.A = x; a.W = W; a.bias = bias; a.residual = residual; a.rowbias = rowbias; a.C = y;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.rows_per_batch = rows_per_batch; a.epi = epilogue;
+    a.splitk = 1; a.partial = (float*)workspace; a.partial_bytes = workspace ? workspace_bytes : 0;
+    ST_REQUIRE(!row_stats || !(epilogue & ST_EPI_GEGLU), "linear: row_stats with GEGLU is not supported");
+    a.row_stats = row_stats; a.stats_capacity = row_stats_capacity; a.stats_chunks_out = row_stats_chunks;
+    a.col_stats = col_stats; a.col_tiles_cap = col_stats_tiles; a.col_rows_out = col_stats_rows;
+#ifdef ST_PROBE
+    a.probe = g_probe;
+#endif
+    take_hint(a, next_weights, next_weights_bytes);
+    if (int e = check_epilogue("linear", a)) return e;
+    return run_dense(a, dtype, (hipStream_t)stream);
+}
+
+// LayerNorm folded into the following Linear (or GEGLU projection): see GemmArgs::ln_c.
+extern "C" int st_ln_linear(const void* x, const float* row_stats, int row_stats_chunks, const void* Wg, const float* c,
+                            const float* d, void* y, int M, int N, int K, long lda, long ldc, float eps, int epilogue,
+                            int dtype, const void* next_weights, size_t next_weights_bytes, void* stream) {
+    ST_REQUIRE(x && Wg && c && d && y && row_stats, "ln_linear: null pointer");
+    ST_REQUIRE(row_stats_chunks > 0, "ln_linear: the producer emitted no row statistics");
+    ST_REQUIRE(M > 0 && N > 0 && K > 0, "ln_linear: bad shape M=%d N=%d K=%d", M, N, K);
+    ST_REQUIRE(st_dtype_ok(dtype), "ln_linear: unsupported dtype %d", dtype);
+    const int kb = st_dtype_is16(dtype) ? 64 : 32;
+    ST_REQUIRE(K % kb == 0 && lda % (kb / 8) == 0, "ln_linear: K=%d must be a multiple of %d", K, kb);
+    ST_REQUIRE(ldc % 4 == 0, "ln_linear: ldc must be a multiple of 4");
+    ST_REQUIRE((epilogue & ~ST_EPI_GEGLU) == 0, "ln_linear: only the GEGLU epilogue flag is accepted (bias lives in d)");
+    ST_REQUIRE(((uintptr_t)x | (uintptr_t)Wg | (uintptr_t)y) % 16 == 0, "ln_linear: pointers must be 16-byte aligned");
+    GemmArgs a = {};
+    a.A = x; a.W = Wg; a.C = y; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.epi = epilogue;
+    a.ln_c = c; a.ln_d = d; a.ln_eps = eps; a.splitk = 1; a.ln_stats = row_stats; a.ln_chunks = row_stats_chunks;
+    take_hint(a, next_weights, next_weights_bytes);
+    return run_dense(a, dtype, (hipStream_t)stream);
+}
+
+// The query projection of the text-context attention and that attention as ONE launch (transformer block:
+// norm2 -> attn2.to_q -> attention over the 77 hoisted context keys, unet_pt.py:133-142,192-208):
+//   out = softmax(LN(x) Wq^T (+bias) . K^T * scale) V  per head, with LN folded exactly as in st_ln_linear.
+extern "C" int st_ln_linear_xattn(const void* x, const float* row_stats, int row_stats_chunks, const void* Wg, const float* c,
+                                  const float* d, const void* k, const void* v, void* out, int M, int N, int K, long lda, long ldo,
+                                  float eps, int rows_per_batch, int S, int H, long ldk, long ldv, float scale, int dtype,
+                                  const void* next_weights, size_t next_weights_bytes, void* stream) {
+    ST_REQUIRE(st_dtype_is16(dtype), "ln_linear_xattn: dtype %d not supported (bf16 / f16)", dtype);
+    ST_REQUIRE(x && Wg && c && d && k && v && out && row_stats, "ln_linear_xattn: null pointer");
+    ST_REQUIRE(row_stats_chunks > 0, "ln_linear_xattn: the producer emitted no row statistics");
+    ST_REQUIRE(M > 0 && N > 0 && K > 0 && S > 0 && H > 0, "ln_linear_xattn: bad shape M=%d N=%d K=%d S=%d H=%d", M, N, K, S, H);
+    ST_REQUIRE(N == H * 64, "ln_linear_xattn: N=%d must be H*64 (H=%d)", N, H);
+    ST_REQUIRE(S < 256, "ln_linear_xattn: context of %d keys (the fused epilogue runs the short-context attention core: S < 256)", S);
+    ST_REQUIRE(rows_per_batch > 0 && rows_per_batch % 128 == 0 && M % rows_per_batch == 0,
+               "ln_linear_xattn: %d rows per batch: query tiles of 128 rows must not straddle batches", rows_per_batch);
+    ST_REQUIRE(K % 64 == 0 && lda % 8 == 0 && ldo % 4 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "ln_linear_xattn: K, strides must keep 16-byte alignment");
+    ST_REQUIRE(((uintptr_t)x | (uintptr_t)Wg | (uintptr_t)out | (uintptr_t)k | (uintptr_t)v | (uintptr_t)c | (uintptr_t)d) % 16 == 0,
+               "ln_linear_xattn: pointers must be 16-byte aligned");
+    GemmArgs a = {};
+    a.A = x; a.W = Wg; a.C = out; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldo; a.epi = 0;
+    a.ln_c = c; a.ln_d = d; a.ln_eps = eps; a.splitk = 1; a.ln_stats = row_stats; a.ln_chunks = row_stats_chunks;
+    a.xa_k = k; a.xa_v = v; a.xa_ldk = ldk; a.xa_ldv = ldv; a.xa_S = S; a.xa_T = rows_per_batch; a.xa_scale_log2e = scale * 1.4426950408889634f;
+    take_hint(a, next_weights, next_weights_bytes);
+    return dtype == ST_BF16 ? gemm_xattn_bf16(a, (hipStream_t)stream) : gemm_xattn_f16(a, (hipStream_t)stream);
+}
+
+// fp8 projections (seed: the reference's fp8-stored projection weights, kernels/attention_proj.py:36-39,
+// 105-155, which it up-converts before the product - here both operands go to the fp8 matrix pipe):
+//   y = epilogue((xq Wq^T) * row_scale[m] * w_scale[n]),  xq / Wq OCP e4m3 bytes, fp32 accumulation, bf16 out.
+extern "C" int st_linear_fp8(const void* xq, const float* row_scale, const void* Wq, const float* w_scale, const void* bias,
+                             const void* residual, void* y, int M, int N, int K, long lda, long ldc, long ldr, int epilogue,
+                             void* workspace, size_t workspace_bytes, const void* next_weights, size_t next_weights_bytes,
+                             void* stream) {
+    ST_REQUIRE(xq && row_scale && Wq && w_scale && y, "linear_fp8: null pointer");
+    ST_REQUIRE(M > 0 && N > 0 && K > 0, "linear_fp8: bad shape M=%d N=%d K=%d", M, N, K);
+    ST_REQUIRE(K % 128 == 0 && lda % 16 == 0, "linear_fp8: K=%d must be a multiple of 128 and lda=%ld of 16", K, lda);
+    ST_REQUIRE(N % 4 == 0 && ldc % 4 == 0 && (!(epilogue & ST_EPI_RESIDUAL) || ldr % 4 == 0), "linear_fp8: N, ldc, ldr must be multiples of 4");
+    ST_REQUIRE(!(epilogue & ST_EPI_ROWBIAS), "linear_fp8: the row-bias epilogue is not supported");
+    ST_REQUIRE(((uintptr_t)xq | (uintptr_t)Wq | (uintptr_t)y | (uintptr_t)w_scale) % 16 == 0, "linear_fp8: pointers must be 16-byte aligned");
+    GemmArgs a = {};
+    a.A = xq; a.W = Wq; a.bias = bias; a.residual = residual; a.C = y;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.epi = epilogue;
+    a.row_scale = row_scale; a.col_scale = w_scale;
+    a.splitk = 1; a.partial = (float*)workspace; a.partial_bytes = workspace ? workspace_bytes : 0;
+    take_hint(a, next_weights, next_weights_bytes);
+    if (int e = check_epilogue("linear_fp8", a)) return e;
+    return gemm_dense_fp8(a, (hipStream_t)stream);
+}
+
+extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const void* residual, const void* rowbias, void* y,
+                         int N, int Hin, int Win, int Cin, int Cout, int R, int S, int stride, int pad, int upsample2x,
+                         int epilogue, int dtype, void* workspace, size_t workspace_bytes,
+                         float* col_stats, int col_stats_tiles, int* col_stats_rows,
+                         const void* next_weights, size_t next_weights_bytes, void* stream) {
+    if (col_stats_rows) *col_stats_rows = 0;
+    ST_REQUIRE(x && W && y, "conv2d: null pointer");
+    ST_REQUIRE(N > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0,
+               "conv2d: bad geometry");
+    ST_REQUIRE(st_dtype_ok(dtype), "conv2d: unsupported dtype %d", dtype);
+    ST_REQUIRE(!(epilogue & ST_EPI_GEGLU), "conv2d: GEGLU epilogue not supported");
+    ST_REQUIRE(Cout % 4 == 0, "conv2d: Cout=%d must be a multiple of 4", Cout);
+    const int He = upsample2x ? 2 * Hin : Hin, We = upsample2x ? 2 * Win : Win;
+    GemmArgs a = {};
+    a.A = x; a.W = W; a.bias = bias; a.residual = residual; a.rowbias = rowbias; a.C = y;
+    a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.S = S; a.stride = stride; a.pad = pad; a.ups = upsample2x ? 1 : 0;
+    {
+        static const int korder_env = dev_env_int("ST_CONV_KORDER", -1);
+        a.R_ = R; a.korder = korder_env >= 0 ? korder_env : 0;
+    }
+    a.Hout = (He + 2 * pad - R) / stride + 1;
+    a.Wout = (We + 2 * pad - S) / stride + 1;
+    ST_REQUIRE(a.Hout > 0 && a.Wout > 0, "conv2d: empty output");
+    a.M = N * a.Hout * a.Wout; a.N = Cout; a.K = R * S * Cin;
+    a.lda = 0; a.ldc = Cout; a.ldr = Cout; a.rows_per_batch = a.Hout * a.Wout; a.epi = epilogue;
+    a.splitk = 1; a.partial = (float*)workspace; a.partial_bytes = workspace ? workspace_bytes : 0;
+    a.col_stats = col_stats; a.col_tiles_cap = col_stats_tiles; a.col_rows_out = col_stats_rows;
+    take_hint(a, next_weights, next_weights_bytes);
+    if (int e = check_epilogue("conv2d", a)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    const int kb = st_dtype_is16(dtype) ? 64 : 32;
+    if (Cin % kb == 0) {
+        ST_REQUIRE(((uintptr_t)x | (uintptr_t)W | (uintptr_t)y) % 16 == 0, "conv2d: pointers must be 16-byte aligned");
+        if (dtype == ST_BF16) return gemm_conv_bf16(a, R, upsample2x, st);
+        if (dtype == ST_F16) return gemm_conv_f16(a, R, upsample2x, st);
+        return gemm_conv_f32(a, st);
+    }
+    // thin-input path: K = R*S*Cin small enough to keep one pixel's inputs in registers
+    ST_REQUIRE(a.K <= 64 && Cout % 16 == 0, "conv2d: Cin=%d is neither a multiple of %d (implicit GEMM) nor thin (R*S*Cin <= 64, Cout %% 16 == 0)", Cin, kb);
+    return conv_thin_run(a, R, dtype, st);
+}

@@ -11,6 +11,7 @@
 // The MFMA is issued "swapped" (W fragment as the A operand, activation
 // fragment as B), so each lane ends up with 4 consecutive output columns of
 // one row and the epilogue stores 8/16 contiguous bytes per lane.
+#pragma once
 #include "common.h"
 #include "attention_core.h"
 #include <stdlib.h>
@@ -62,13 +63,19 @@ static inline int dev_env_int(const char* name, int dflt) {
 #endif
 }
 
-static bool colstats_ok(const GemmArgs& a, int bm, bool lnf);      // (defined with the launchers)
+static inline bool colstats_ok(const GemmArgs& a, int bm, bool lnf);      // (defined with the launchers)
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
     typedef bf16x8 Frag;
     static __device__ __forceinline__ void run(f32x4& acc, const Frag& a, const Frag& b) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<f16> {
+    typedef f16x8 Frag;
+    static __device__ __forceinline__ void run(f32x4& acc, const Frag& a, const Frag& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
     }
 };
 template <> struct Mma<float> {
@@ -110,6 +117,19 @@ template <> struct Out4<bf16> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = (bf16)f[i];
         *reinterpret_cast<bf16x4*>(p) = v;
+    }
+};
+template <> struct Out4<f16> {
+    static __device__ __forceinline__ void load(const f16* p, float* f) {
+        f16x4 v = *reinterpret_cast<const f16x4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = (float)v[i];
+    }
+    static __device__ __forceinline__ void store(f16* p, const float* f) {
+        f16x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (f16)f[i];
+        *reinterpret_cast<f16x4*>(p) = v;
     }
 };
 template <> struct Out4<float> {
@@ -162,7 +182,9 @@ __device__ __forceinline__ void touch_next_weights(const GemmArgs& p, unsigned i
 // handed back once they have returned.
 __device__ __forceinline__ void retire_touches(unsigned int& sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory"); }
 
-template <typename T> struct Raw4 { typedef bf16x4 type; };
+template <typename T> struct Raw4;
+template <> struct Raw4<bf16> { typedef bf16x4 type; };
+template <> struct Raw4<f16> { typedef f16x4 type; };
 template <> struct Raw4<float> { typedef f32x4 type; };
 template <typename T> __device__ __forceinline__ typename Raw4<T>::type ld_raw4(const T* p) {
     return *reinterpret_cast<const typename Raw4<T>::type*>(p);
@@ -661,7 +683,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
 // s_barrier (a __syncthreads() would drain the DMA queue).  Rows outside M / N
 // and padded conv taps read from a 16-byte zero buffer, so no lane is masked.
 // =============================================================================
-__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+static __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};      // (one per translation unit)
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
@@ -1146,7 +1168,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         // Query projection of the text-context attention: the tile is 128 queries x the 64 columns of ONE head.  Leave it
         // in LDS as bf16 (exactly what the unfused path stores and reads back) and run the 16-row attention core on it:
         // the attention launch, its Q round trip through HBM and one kernel boundary disappear (70 per denoise step).
-        static_assert(LNF && !GEGLU && !CONV && BM == 128 && BN == 64 && NW == 8 && std::is_same<T, bf16>::value, "xattn epilogue: 128 x 64 tile, 8 waves");
+        static_assert(LNF && !GEGLU && !CONV && BM == 128 && BN == 64 && NW == 8 && sizeof(T) == 2, "xattn epilogue: 128 x 64 tile, 8 waves, 16-bit elements");
         static_assert(STAGES * STAGE >= 16384 + 3 * 16384, "xattn epilogue: Q tile + K/V ring fit the GEMM's ring");
         const float2* lnst = reinterpret_cast<const float2*>(lds + STAGES * STAGE);
         float mean[TM], rstd[TM];
@@ -1156,7 +1178,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
             mean[i] = v.x; rstd[i] = v.y;
         }
         __syncthreads();                               // every wave has read its last fragments: the ring is free
-        bf16* qt = reinterpret_cast<bf16*>(lds);       // [128][64]
+        T* qt = reinterpret_cast<T*>(lds);             // [128][64]
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = wn * WTN + j * 16 + 4 * q;
@@ -1164,17 +1186,17 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = wm * WTM + i * 16 + r16;
-                bf16x4 o4;
+                typename V16<T>::x4 o4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o4[e] = (bf16)(rstd[i] * (acc[i][j][e] - mean[i] * cv[e]) + dv[e]);
-                *reinterpret_cast<bf16x4*>(qt + row * 64 + col) = o4;
+                for (int e = 0; e < 4; ++e) o4[e] = (T)(rstd[i] * (acc[i][j][e] - mean[i] * cv[e]) + dv[e]);
+                *reinterpret_cast<typename V16<T>::x4*>(qt + row * 64 + col) = o4;
             }
         }
         __syncthreads();
         const int bimg = m0 / p.xa_T, head = tile_n;
-        const bf16* Kb = (const bf16*)p.xa_k + (size_t)bimg * p.xa_S * p.xa_ldk + (size_t)head * 64;
-        const bf16* Vb = (const bf16*)p.xa_v + (size_t)bimg * p.xa_S * p.xa_ldv + (size_t)head * 64;
-        attn16_core<8>(qt, 64, 128, Kb, Vb, p.xa_ldk, p.xa_ldv, p.xa_S, (bf16*)p.C + (size_t)m0 * p.ldc + (size_t)head * 64, p.ldc,
+        const T* Kb = (const T*)p.xa_k + (size_t)bimg * p.xa_S * p.xa_ldk + (size_t)head * 64;
+        const T* Vb = (const T*)p.xa_v + (size_t)bimg * p.xa_S * p.xa_ldv + (size_t)head * 64;
+        attn16_core<T, 8>(qt, 64, 128, Kb, Vb, p.xa_ldk, p.xa_ldv, p.xa_S, (T*)p.C + (size_t)m0 * p.ldc + (size_t)head * 64, p.ldc,
                        min(BM, p.M - m0), p.xa_scale_log2e, lds + 16384, wave, lane);
         unsigned int sink = 0;
         touch_next_weights(p, sink);
@@ -1227,9 +1249,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
 // Epilogue, LayerNorm folding, row statistics, next-weights touches and the XCD-aware tile order are the
 // ones of gemm_dma_kernel.  No K split (the shapes that come here have >= 160 tiles).
 // =============================================================================
-template <bool GEGLU, bool LNF>
+template <typename T, bool GEGLU, bool LNF>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
-    typedef bf16 T;
+    static_assert(sizeof(T) == 2, "16-bit elements (bf16 / f16)");
     constexpr int BM = 256, BN = 256, KB = 64, WGM = 2, WGN = 4, NW = 8;
     constexpr int WTM = 128, WTN = 64, TM = 8, TN = 4;
     constexpr int HALF_B = 128 * 128;                 // bytes of one half tile (128 rows x 128 B)
@@ -1453,18 +1475,18 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     }
 }
 
-static bool gemm8p_applies(const GemmArgs& a) {
+static inline bool gemm8p_applies(const GemmArgs& a) {
     const long n_rows = (a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N;
     return a.M % 256 == 0 && n_rows % 256 == 0 && a.K % 64 == 0 && a.K >= 256 && a.N % 4 == 0 &&
            !(a.epi & ST_EPI_ROWBIAS) && (!a.row_stats || !(a.epi & ST_EPI_GEGLU));
 }
 
-template <bool GEGLU, bool LNF>
+template <typename T, bool GEGLU, bool LNF>
 static void gemm8p_go(const GemmArgs& a, hipStream_t st) {
     constexpr size_t lds = 2 * 4 * 128 * 128 + 256 * 8 + 1024;
-    auto kfn = gemm8p_kernel<GEGLU, LNF>;
-    static bool once = (allow_big_lds(kfn, lds), true);
-    (void)once;
+    auto kfn = gemm8p_kernel<T, GEGLU, LNF>;
+    static unsigned long long lds_ok = 0;
+    ensure_dynamic_lds(kfn, lds, &lds_ok);
     GemmArgs b = a;
     const int tiles_m = a.M / 256, tiles_n = (int)(((a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N) / 256);
     {   // XCD partition of the tile order: bytes from beyond L2 ~ A * (8 / panels) + W * panels
@@ -1486,10 +1508,11 @@ static void gemm8p_go(const GemmArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(kfn, dim3(main_blocks + b.helper_blocks), dim3(512), lds, st, b);
 }
 
+template <typename T>
 static void gemm8p_launch(const GemmArgs& a, hipStream_t st) {
     const bool geglu = a.epi & ST_EPI_GEGLU;
-    if (a.ln_c) { if (geglu) gemm8p_go<true, true>(a, st); else gemm8p_go<false, true>(a, st); }
-    else { if (geglu) gemm8p_go<true, false>(a, st); else gemm8p_go<false, false>(a, st); }
+    if (a.ln_c) { if (geglu) gemm8p_go<T, true, true>(a, st); else gemm8p_go<T, false, true>(a, st); }
+    else { if (geglu) gemm8p_go<T, true, false>(a, st); else gemm8p_go<T, false, false>(a, st); }
 }
 
 // =============================================================================
@@ -1506,9 +1529,9 @@ static void gemm8p_launch(const GemmArgs& a, hipStream_t st) {
 // =============================================================================
 // UPS: the nearest-2x upsample folded in (W, TH count OUTPUT pixels; the patch holds INPUT pixels: output
 // (oy, ox) tap (r, s) reads input ((oy + r - 1) >> 1, (ox + s - 1) >> 1), zero outside).
-template <int WL2, int TH, int BN, int WGM, int WGN, bool UPS = false>
+template <typename T, int WL2, int TH, int BN, int WGM, int WGN, bool UPS = false>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
-    typedef bf16 T;
+    static_assert(sizeof(T) == 2, "16-bit elements (bf16 / f16)");
     constexpr int W = 1 << WL2, BM = TH * W, NW = WGM * WGN;
     static_assert(NW == 8 && BM % (16 * WGM) == 0 && BN % (16 * WGN) == 0 && W >= 16, "tile / wave layout");
     static_assert(!UPS || TH % 2 == 0, "upsampled tiles start on an even output row");
@@ -1689,11 +1712,6 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
     gemm_epilogue<T, TM, TN, WTM, WTN, false, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n);
 }
 
-template <typename K>
-static void allow_big_lds(K kernel, size_t bytes) {
-    if (bytes > 64 * 1024) hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
-
 template <typename T, int BM, int BN, int WGM, int WGN, bool CONV>
 static void launch_cfg(const GemmArgs& a, hipStream_t st) {
     const size_t lds = 2 * (size_t)(BM + BN) * 128;
@@ -1710,7 +1728,7 @@ static void launch_cfg(const GemmArgs& a, hipStream_t st) {
 
 // Can a launch with BM-row tiles emit GroupNorm partials?  (tile rows must not straddle images; the LayerNorm-folded
 // kernels have no scratch for it.)  Tells the host through *col_rows_out.
-static bool colstats_ok(const GemmArgs& a, int bm, bool lnf) {
+static inline bool colstats_ok(const GemmArgs& a, int bm, bool lnf) {
     const bool ok = a.col_stats && !lnf && (a.N & 3) == 0 && a.rows_per_batch > 0 && a.rows_per_batch % bm == 0 &&
                     cdiv(a.M, bm) <= a.col_tiles_cap;
     if (a.col_rows_out) *a.col_rows_out = ok ? bm : 0;
@@ -1723,8 +1741,8 @@ static void launch_dma_one(const GemmArgs& a, hipStream_t st, int tiles_n) {
     const int sk = a.splitk > 1 ? a.splitk : 1;
     auto kfn = gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, U, CONV, GEGLU, LNF, XA>;
     const bool emit_cols = colstats_ok(a, BM, LNF);
-    static bool once = (allow_big_lds(kfn, lds), true);
-    (void)once;
+    static unsigned long long lds_ok = 0;
+    ensure_dynamic_lds(kfn, lds, &lds_ok);
     // XCD partition: bytes from beyond L2 ~ A * (8 / panels) + W * panels (A = activations, all of K)
     GemmArgs b = a;
     {
@@ -1777,7 +1795,7 @@ enum { CFG_64x64_S4 = 0, CFG_64x64_S8 = 1, CFG_64x64_S4_U2 = 2, CFG_128x64_S4 = 
        CFG_128x128_S3 = 5, CFG_64x64_S3 = 6, CFG_64x64_W8 = 7, CFG_128x64_W8 = 8, CFG_128x128_W8 = 9,
        CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_128x320_W8 = 23, CFG_128x256_W8 = 24, CFG_64x320_W8 = 25, CFG_64x80_W4 = 26, CFG_128x80_W8 = 27, CFG_128x160_W8 = 28, CFG_COUNT, CFG_256x256_8P = 100 };
 
-static int cfg_bn(int cfg) {
+static inline int cfg_bn(int cfg) {
     switch (cfg) {
         case CFG_64x64_S4: case CFG_64x64_S8: case CFG_64x64_S4_U2: case CFG_128x64_S4: case CFG_128x64_S3_U2: case CFG_64x64_S3:
         case CFG_64x64_W8: case CFG_128x64_W8: case CFG_128x64_W8_S6: case CFG_64x64_W8_S8: case CFG_128x64_W8_U2:
@@ -1791,10 +1809,9 @@ static int cfg_bn(int cfg) {
 }
 
 #ifdef ST_DEV_CONFIGS
-static int g_dbg_cfg = -1, g_dbg_fusek = -1;
-extern "C" void st_debug_force_gemm(int cfg, int fusek) { g_dbg_cfg = cfg; g_dbg_fusek = fusek; }
+extern int g_dbg_cfg, g_dbg_fusek;             // (gemm_api.hip: st_debug_force_gemm)
 #endif
-static int forced_cfg() {
+static inline int forced_cfg() {
     static int v = dev_env_int("ST_GEMM_FORCE", -1);
 #ifdef ST_DEV_CONFIGS
     if (g_dbg_cfg >= 0) return g_dbg_cfg;
@@ -1858,7 +1875,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
                 if (cost < best) { best = cost; cfg = c.cfg; sk = k_; }
             }
         }
-        if constexpr (!CONV && std::is_same<T, bf16>::value) {
+        if constexpr (!CONV && sizeof(T) == 2) {
             // the 256 x 256 eight-phase kernel: no K split, whole rounds of 256 blocks
             if (gemm8p_applies(a)) {
                 const long nt = tiles(256, 256);
@@ -1868,7 +1885,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
                 // the per-trip constants above were fitted on one-round launches and run 25-45 % optimistic once a launch
                 // takes several rounds (tools/gemm_sweep.py: FF1 of the 1280-channel level 51 us predicted 35, this kernel 39
                 // predicted 37; QKV at batch 4 72 us against 55), so this kernel also takes the near ties
-                if ((cost < 1.3 * best && f < 0) || f == CFG_256x256_8P) { gemm8p_launch(a, st); return st_check_launch(who); }
+                if ((cost < 1.3 * best && f < 0) || f == CFG_256x256_8P) { gemm8p_launch<T>(a, st); return st_check_launch(who); }
             }
         }
         GemmArgs b = a;
@@ -1941,19 +1958,15 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
     }
 }
 
-#ifdef ST_PROBE
-static unsigned long long* g_probe = nullptr;
-extern "C" void st_debug_set_probe(void* p) { g_probe = (unsigned long long*)p; }
-#endif
 
 // `next_weights` (optional argument of the three GEMM-shaped entry points): the weight matrix the launch AFTER this one
 // will read; this launch touches it (one dword per 128-byte line, spread over its blocks) so it waits in the memory-side cache.
-static void take_hint(GemmArgs& a, const void* next_w, size_t next_bytes) {
+static inline void take_hint(GemmArgs& a, const void* next_w, size_t next_bytes) {
     a.next_w = next_bytes ? next_w : nullptr;
     a.next_bytes = next_w ? next_bytes : 0;
 }
 
-static int check_epilogue(const char* who, const GemmArgs& a) {
+static inline int check_epilogue(const char* who, const GemmArgs& a) {
     ST_REQUIRE(!(a.epi & ST_EPI_BIAS) || a.bias, "%s: ST_EPI_BIAS without bias pointer", who);
     ST_REQUIRE(!(a.epi & ST_EPI_RESIDUAL) || a.residual, "%s: ST_EPI_RESIDUAL without residual pointer", who);
     ST_REQUIRE(!(a.epi & ST_EPI_ROWBIAS) || (a.rowbias && a.rows_per_batch > 0), "%s: ST_EPI_ROWBIAS needs rowbias and rows_per_batch", who);
@@ -1961,106 +1974,8 @@ static int check_epilogue(const char* who, const GemmArgs& a) {
     return 0;
 }
 
-extern "C" int st_linear(const void* x, const void* W, const void* bias, const void* residual, const void* rowbias, void* y,
-                         int M, int N, int K, long lda, long ldc, long ldr, int rows_per_batch, int epilogue, int dtype,
-                         void* workspace, size_t workspace_bytes, float* row_stats, int row_stats_capacity,
-                         int* row_stats_chunks, float* col_stats, int col_stats_tiles, int* col_stats_rows,
-                         const void* next_weights, size_t next_weights_bytes, void* stream) {
-    if (col_stats_rows) *col_stats_rows = 0;
-    ST_REQUIRE(x && W && y, "linear: null pointer");
-    ST_REQUIRE(M > 0 && N > 0 && K > 0, "linear: bad shape M=%d N=%d K=%d", M, N, K);
-    const int vec = dtype == ST_BF16 ? 8 : 4;
-    ST_REQUIRE(dtype == ST_BF16 || dtype == ST_F32, "linear: unsupported dtype %d", dtype);
-    ST_REQUIRE(K % vec == 0 && lda % vec == 0, "linear: K=%d and lda=%ld must be multiples of %d", K, lda, vec);
-    ST_REQUIRE(ldc % 4 == 0 && (!(epilogue & ST_EPI_RESIDUAL) || ldr % 4 == 0), "linear: ldc/ldr must be multiples of 4");
-    ST_REQUIRE(((uintptr_t)x | (uintptr_t)W) % 16 == 0 && (uintptr_t)y % 16 == 0, "linear: pointers must be 16-byte aligned");
-    GemmArgs a = {};
-    a.A = x; a.W = W; a.bias = bias; a.residual = residual; a.rowbias = rowbias; a.C = y;
-    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.rows_per_batch = rows_per_batch; a.epi = epilogue;
-    a.splitk = 1; a.partial = (float*)workspace; a.partial_bytes = workspace ? workspace_bytes : 0;
-    ST_REQUIRE(!row_stats || !(epilogue & ST_EPI_GEGLU), "linear: row_stats with GEGLU is not supported");
-    a.row_stats = row_stats; a.stats_capacity = row_stats_capacity; a.stats_chunks_out = row_stats_chunks;
-    a.col_stats = col_stats; a.col_tiles_cap = col_stats_tiles; a.col_rows_out = col_stats_rows;
-#ifdef ST_PROBE
-    a.probe = g_probe;
-#endif
-    take_hint(a, next_weights, next_weights_bytes);
-    if (int e = check_epilogue("linear", a)) return e;
-    hipStream_t st = (hipStream_t)stream;
-    return dtype == ST_BF16 ? gemm_dispatch<bf16, false>(a, st) : gemm_dispatch<float, false>(a, st);
-}
-
-// LayerNorm folded into the following Linear (or GEGLU projection): see GemmArgs::ln_c.
-extern "C" int st_ln_linear(const void* x, const float* row_stats, int row_stats_chunks, const void* Wg, const float* c,
-                            const float* d, void* y, int M, int N, int K, long lda, long ldc, float eps, int epilogue,
-                            int dtype, const void* next_weights, size_t next_weights_bytes, void* stream) {
-    ST_REQUIRE(x && Wg && c && d && y && row_stats, "ln_linear: null pointer");
-    ST_REQUIRE(row_stats_chunks > 0, "ln_linear: the producer emitted no row statistics");
-    ST_REQUIRE(M > 0 && N > 0 && K > 0, "ln_linear: bad shape M=%d N=%d K=%d", M, N, K);
-    ST_REQUIRE(dtype == ST_BF16 || dtype == ST_F32, "ln_linear: unsupported dtype %d", dtype);
-    const int kb = dtype == ST_BF16 ? 64 : 32;
-    ST_REQUIRE(K % kb == 0 && lda % (kb / 8) == 0, "ln_linear: K=%d must be a multiple of %d", K, kb);
-    ST_REQUIRE(ldc % 4 == 0, "ln_linear: ldc must be a multiple of 4");
-    ST_REQUIRE((epilogue & ~ST_EPI_GEGLU) == 0, "ln_linear: only the GEGLU epilogue flag is accepted (bias lives in d)");
-    ST_REQUIRE(((uintptr_t)x | (uintptr_t)Wg | (uintptr_t)y) % 16 == 0, "ln_linear: pointers must be 16-byte aligned");
-    GemmArgs a = {};
-    a.A = x; a.W = Wg; a.C = y; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.epi = epilogue;
-    a.ln_c = c; a.ln_d = d; a.ln_eps = eps; a.splitk = 1; a.ln_stats = row_stats; a.ln_chunks = row_stats_chunks;
-    take_hint(a, next_weights, next_weights_bytes);
-    hipStream_t st = (hipStream_t)stream;
-    return dtype == ST_BF16 ? gemm_dispatch<bf16, false>(a, st) : gemm_dispatch<float, false>(a, st);
-}
-
-// The query projection of the text-context attention and that attention as ONE launch (transformer block:
-// norm2 -> attn2.to_q -> attention over the 77 hoisted context keys, unet_pt.py:133-142,192-208):
-//   out = softmax(LN(x) Wq^T (+bias) . K^T * scale) V  per head, with LN folded exactly as in st_ln_linear.
-extern "C" int st_ln_linear_xattn(const void* x, const float* row_stats, int row_stats_chunks, const void* Wg, const float* c,
-                                  const float* d, const void* k, const void* v, void* out, int M, int N, int K, long lda, long ldo,
-                                  float eps, int rows_per_batch, int S, int H, long ldk, long ldv, float scale,
-                                  const void* next_weights, size_t next_weights_bytes, void* stream) {
-    ST_REQUIRE(x && Wg && c && d && k && v && out && row_stats, "ln_linear_xattn: null pointer");
-    ST_REQUIRE(row_stats_chunks > 0, "ln_linear_xattn: the producer emitted no row statistics");
-    ST_REQUIRE(M > 0 && N > 0 && K > 0 && S > 0 && H > 0, "ln_linear_xattn: bad shape M=%d N=%d K=%d S=%d H=%d", M, N, K, S, H);
-    ST_REQUIRE(N == H * 64, "ln_linear_xattn: N=%d must be H*64 (H=%d)", N, H);
-    ST_REQUIRE(rows_per_batch > 0 && rows_per_batch % 128 == 0 && M % rows_per_batch == 0,
-               "ln_linear_xattn: %d rows per batch: query tiles of 128 rows must not straddle batches", rows_per_batch);
-    ST_REQUIRE(K % 64 == 0 && lda % 8 == 0 && ldo % 4 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "ln_linear_xattn: K, strides must keep 16-byte alignment");
-    ST_REQUIRE(((uintptr_t)x | (uintptr_t)Wg | (uintptr_t)out | (uintptr_t)k | (uintptr_t)v | (uintptr_t)c | (uintptr_t)d) % 16 == 0,
-               "ln_linear_xattn: pointers must be 16-byte aligned");
-    GemmArgs a = {};
-    a.A = x; a.W = Wg; a.C = out; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldo; a.epi = 0;
-    a.ln_c = c; a.ln_d = d; a.ln_eps = eps; a.splitk = 1; a.ln_stats = row_stats; a.ln_chunks = row_stats_chunks;
-    a.xa_k = k; a.xa_v = v; a.xa_ldk = ldk; a.xa_ldv = ldv; a.xa_S = S; a.xa_T = rows_per_batch; a.xa_scale_log2e = scale * 1.4426950408889634f;
-    take_hint(a, next_weights, next_weights_bytes);
-    launch_dma_one<bf16, 128, 64, 4, 2, 4, 1, false, false, true, true>(a, (hipStream_t)stream, N / 64);
-    return st_check_launch("ln_linear_xattn");
-}
-
-// fp8 projections (seed: the reference's fp8-stored projection weights, kernels/attention_proj.py:36-39,
-// 105-155, which it up-converts before the product - here both operands go to the fp8 matrix pipe):
-//   y = epilogue((xq Wq^T) * row_scale[m] * w_scale[n]),  xq / Wq OCP e4m3 bytes, fp32 accumulation, bf16 out.
-extern "C" int st_linear_fp8(const void* xq, const float* row_scale, const void* Wq, const float* w_scale, const void* bias,
-                             const void* residual, void* y, int M, int N, int K, long lda, long ldc, long ldr, int epilogue,
-                             void* workspace, size_t workspace_bytes, const void* next_weights, size_t next_weights_bytes,
-                             void* stream) {
-    ST_REQUIRE(xq && row_scale && Wq && w_scale && y, "linear_fp8: null pointer");
-    ST_REQUIRE(M > 0 && N > 0 && K > 0, "linear_fp8: bad shape M=%d N=%d K=%d", M, N, K);
-    ST_REQUIRE(K % 128 == 0 && lda % 16 == 0, "linear_fp8: K=%d must be a multiple of 128 and lda=%ld of 16", K, lda);
-    ST_REQUIRE(N % 4 == 0 && ldc % 4 == 0 && (!(epilogue & ST_EPI_RESIDUAL) || ldr % 4 == 0), "linear_fp8: N, ldc, ldr must be multiples of 4");
-    ST_REQUIRE(!(epilogue & ST_EPI_ROWBIAS), "linear_fp8: the row-bias epilogue is not supported");
-    ST_REQUIRE(((uintptr_t)xq | (uintptr_t)Wq | (uintptr_t)y | (uintptr_t)w_scale) % 16 == 0, "linear_fp8: pointers must be 16-byte aligned");
-    GemmArgs a = {};
-    a.A = xq; a.W = Wq; a.bias = bias; a.residual = residual; a.C = y;
-    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.epi = epilogue;
-    a.row_scale = row_scale; a.col_scale = w_scale;
-    a.splitk = 1; a.partial = (float*)workspace; a.partial_bytes = workspace ? workspace_bytes : 0;
-    take_hint(a, next_weights, next_weights_bytes);
-    if (int e = check_epilogue("linear_fp8", a)) return e;
-    return gemm_dispatch<f8, false>(a, (hipStream_t)stream);
-}
-
 // ---- host side of conv_halo_kernel --------------------------------------------------------------
-static bool conv_halo_applies(const GemmArgs& a, int R, int ups) {
+static inline bool conv_halo_applies(const GemmArgs& a, int R, int ups) {
     static const bool off = dev_env_int("ST_CONV_HALO", 1) == 0;
     if (off) return false;
     if (R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1) return false;
@@ -2074,20 +1989,21 @@ static bool conv_halo_applies(const GemmArgs& a, int R, int ups) {
     return a.Hin == a.Hout && a.Win == a.Wout && a.Hin % th == 0 && a.M % bm == 0;
 }
 
-template <int WL2, int TH, int BN, int WGM, int WGN, bool UPS = false>
+template <typename T, int WL2, int TH, int BN, int WGM, int WGN, bool UPS = false>
 static void conv_halo_go(const GemmArgs& b, int blocks, hipStream_t st) {
     constexpr int W = 1 << WL2;
     constexpr int PPX = UPS ? (TH / 2 + 2) * (W / 2 + 2) : (TH + 2) * (W + 2);
     constexpr size_t lds = 2 * (size_t)((PPX + 7) / 8) * 1024 + 3 * BN * 128 + 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kfn = conv_halo_kernel<WL2, TH, BN, WGM, WGN, UPS>;
-    static bool once = (allow_big_lds(kfn, lds), true);
-    (void)once;
+    auto kfn = conv_halo_kernel<T, WL2, TH, BN, WGM, WGN, UPS>;
+    static unsigned long long lds_ok = 0;
+    ensure_dynamic_lds(kfn, lds, &lds_ok);
     GemmArgs c = b;
     if (!colstats_ok(b, TH * W, false)) c.col_stats = nullptr;
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, st, c);
 }
 
+template <typename T>
 static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
     GemmArgs b = a;
     // 256 pixels x 128 channels at the 32- and 64-pixel levels; one 128-pixel row x 160 channels at the 128-pixel level
@@ -2108,11 +2024,11 @@ static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
     b.stats_chunks = cdiv(a.N, bn);
     if (a.row_stats && b.stats_chunks > a.stats_capacity) return st_fail("conv2d: row_stats buffer holds %d chunks, %d needed", a.stats_capacity, b.stats_chunks);
     if (a.stats_chunks_out) *a.stats_chunks_out = a.row_stats ? b.stats_chunks : 0;
-    if (ups && a.Wout == 64) conv_halo_go<6, 4, 160, 4, 2, true>(b, tiles * sk, st);
-    else if (ups) conv_halo_go<7, 2, 160, 4, 2, true>(b, tiles * sk, st);
-    else if (a.Win == 32) conv_halo_go<5, 8, 128, 4, 2>(b, tiles * sk, st);
-    else if (a.Win == 64) conv_halo_go<6, 4, 128, 4, 2>(b, tiles * sk, st);
-    else conv_halo_go<7, 1, 160, 4, 2>(b, tiles * sk, st);
+    if (ups && a.Wout == 64) conv_halo_go<T, 6, 4, 160, 4, 2, true>(b, tiles * sk, st);
+    else if (ups) conv_halo_go<T, 7, 2, 160, 4, 2, true>(b, tiles * sk, st);
+    else if (a.Win == 32) conv_halo_go<T, 5, 8, 128, 4, 2>(b, tiles * sk, st);
+    else if (a.Win == 64) conv_halo_go<T, 6, 4, 128, 4, 2>(b, tiles * sk, st);
+    else conv_halo_go<T, 7, 1, 160, 4, 2>(b, tiles * sk, st);
     return st_check_launch("conv2d(halo)");
 }
 
@@ -2208,56 +2124,30 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GemmArgs p, int R,
     }
 }
 
-extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const void* residual, const void* rowbias, void* y,
-                         int N, int Hin, int Win, int Cin, int Cout, int R, int S, int stride, int pad, int upsample2x,
-                         int epilogue, int dtype, void* workspace, size_t workspace_bytes,
-                         float* col_stats, int col_stats_tiles, int* col_stats_rows,
-                         const void* next_weights, size_t next_weights_bytes, void* stream) {
-    if (col_stats_rows) *col_stats_rows = 0;
-    ST_REQUIRE(x && W && y, "conv2d: null pointer");
-    ST_REQUIRE(N > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0,
-               "conv2d: bad geometry");
-    ST_REQUIRE(dtype == ST_BF16 || dtype == ST_F32, "conv2d: unsupported dtype %d", dtype);
-    ST_REQUIRE(!(epilogue & ST_EPI_GEGLU), "conv2d: GEGLU epilogue not supported");
-    ST_REQUIRE(Cout % 4 == 0, "conv2d: Cout=%d must be a multiple of 4", Cout);
-    const int He = upsample2x ? 2 * Hin : Hin, We = upsample2x ? 2 * Win : Win;
-    GemmArgs a = {};
-    a.A = x; a.W = W; a.bias = bias; a.residual = residual; a.rowbias = rowbias; a.C = y;
-    a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.S = S; a.stride = stride; a.pad = pad; a.ups = upsample2x ? 1 : 0;
-    {
-        static const int korder_env = dev_env_int("ST_CONV_KORDER", -1);
-        a.R_ = R; a.korder = korder_env >= 0 ? korder_env : 0;
-    }
-    a.Hout = (He + 2 * pad - R) / stride + 1;
-    a.Wout = (We + 2 * pad - S) / stride + 1;
-    ST_REQUIRE(a.Hout > 0 && a.Wout > 0, "conv2d: empty output");
-    a.M = N * a.Hout * a.Wout; a.N = Cout; a.K = R * S * Cin;
-    a.lda = 0; a.ldc = Cout; a.ldr = Cout; a.rows_per_batch = a.Hout * a.Wout; a.epi = epilogue;
-    a.splitk = 1; a.partial = (float*)workspace; a.partial_bytes = workspace ? workspace_bytes : 0;
-    a.col_stats = col_stats; a.col_tiles_cap = col_stats_tiles; a.col_rows_out = col_stats_rows;
-    take_hint(a, next_weights, next_weights_bytes);
-    if (int e = check_epilogue("conv2d", a)) return e;
-    hipStream_t st = (hipStream_t)stream;
-    const int kb = dtype == ST_BF16 ? 64 : 32;
-    if (Cin % kb == 0) {
-        ST_REQUIRE(((uintptr_t)x | (uintptr_t)W | (uintptr_t)y) % 16 == 0, "conv2d: pointers must be 16-byte aligned");
-        if (dtype == ST_BF16 && conv_halo_applies(a, R, upsample2x)) return conv_halo_launch(a, st);
-        return dtype == ST_BF16 ? gemm_dispatch<bf16, true>(a, st) : gemm_dispatch<float, true>(a, st);
-    }
-    // thin-input path: K = R*S*Cin small enough to keep one pixel's inputs in registers
-    ST_REQUIRE(a.K <= 64 && Cout % 16 == 0, "conv2d: Cin=%d is neither a multiple of %d (implicit GEMM) nor thin (R*S*Cin <= 64, Cout %% 16 == 0)", Cin, kb);
+template <typename T>
+static int conv_thin_launch(const GemmArgs& a, int R, hipStream_t st) {
     // split the output channels over blockIdx.y until the launch has a few blocks per CU
     const int bx = cdiv(a.M, 256);
     int ny = cdiv(1024, bx);
-    if (ny > Cout / 16) ny = Cout / 16;
+    if (ny > a.N / 16) ny = a.N / 16;
     if (ny < 1) ny = 1;
-    const int chunk = cdiv(cdiv(Cout, ny), 16) * 16;
-    ny = cdiv(Cout, chunk);
+    const int chunk = cdiv(cdiv(a.N, ny), 16) * 16;
+    ny = cdiv(a.N, chunk);
     const size_t lds = (size_t)a.K * chunk * sizeof(float);
     ST_REQUIRE(lds <= 64 * 1024, "conv2d(thin): weights do not fit LDS");
-    if (dtype == ST_BF16)
-        hipLaunchKernelGGL((conv_thin_kernel<bf16, 64>), dim3(bx, ny), dim3(256), lds, st, a, R, chunk);
-    else
-        hipLaunchKernelGGL((conv_thin_kernel<float, 64>), dim3(bx, ny), dim3(256), lds, st, a, R, chunk);
+    hipLaunchKernelGGL((conv_thin_kernel<T, 64>), dim3(bx, ny), dim3(256), lds, st, a, R, chunk);
     return st_check_launch("conv2d(thin)");
 }
+
+// ---- per-element-type runners: each is defined in exactly one translation unit (gemm_<what>_<type>.hip), so the kernels
+// of one type compile beside those of the others; gemm_api.hip (the extern "C" entry points) only calls these.
+int gemm_dense_bf16(const GemmArgs& a, hipStream_t st);
+int gemm_dense_f16(const GemmArgs& a, hipStream_t st);
+int gemm_dense_f32(const GemmArgs& a, hipStream_t st);
+int gemm_dense_fp8(const GemmArgs& a, hipStream_t st);
+int gemm_xattn_bf16(const GemmArgs& a, hipStream_t st);
+int gemm_xattn_f16(const GemmArgs& a, hipStream_t st);
+int gemm_conv_bf16(const GemmArgs& a, int R, int ups, hipStream_t st);      // halo kernel when it applies, else implicit GEMM
+int gemm_conv_f16(const GemmArgs& a, int R, int ups, hipStream_t st);
+int gemm_conv_f32(const GemmArgs& a, hipStream_t st);
+int conv_thin_run(const GemmArgs& a, int R, int dtype, hipStream_t st);

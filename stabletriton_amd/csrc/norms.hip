@@ -251,6 +251,7 @@ extern "C" int st_group_norm(const void* x, const void* gamma, const void* beta,
     ST_REQUIRE(layout == ST_NCHW || layout == ST_NHWC, "group_norm: bad layout %d", layout);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ST_BF16) return gn_launch<bf16>(x, gamma, beta, y, N, C, HW, groups, eps, silu, layout, workspace, st);
+    if (dtype == ST_F16) return gn_launch<f16>(x, gamma, beta, y, N, C, HW, groups, eps, silu, layout, workspace, st);
     if (dtype == ST_F32) return gn_launch<float>(x, gamma, beta, y, N, C, HW, groups, eps, silu, layout, workspace, st);
     return st_fail("group_norm: unsupported dtype %d", dtype);
 }
@@ -330,6 +331,7 @@ extern "C" int st_group_norm_from_stats(const void* x, const void* gamma, const 
     GnSource s1 = {(const float2*)stats1, C1, stats1 ? HW / rows1 : 0};
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ST_BF16) return gn_from_stats_launch<bf16>(x, gamma, beta, y, N, C, HW, groups, eps, silu, s0, s1, workspace, st);
+    if (dtype == ST_F16) return gn_from_stats_launch<f16>(x, gamma, beta, y, N, C, HW, groups, eps, silu, s0, s1, workspace, st);
     if (dtype == ST_F32) return gn_from_stats_launch<float>(x, gamma, beta, y, N, C, HW, groups, eps, silu, s0, s1, workspace, st);
     return st_fail("group_norm_from_stats: unsupported dtype %d", dtype);
 }
@@ -399,6 +401,7 @@ extern "C" int st_layer_norm(const void* x, const void* gamma, const void* beta,
     ST_REQUIRE(rows > 0 && C > 0, "layer_norm: bad shape rows=%d C=%d", rows, C);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ST_BF16) return ln_launch<bf16>(x, gamma, beta, y, rows, C, eps, st);
+    if (dtype == ST_F16) return ln_launch<f16>(x, gamma, beta, y, rows, C, eps, st);
     if (dtype == ST_F32) return ln_launch<float>(x, gamma, beta, y, rows, C, eps, st);
     return st_fail("layer_norm: unsupported dtype %d", dtype);
 }
@@ -439,6 +442,7 @@ extern "C" int st_geglu(const void* state, const void* gate, void* out, int rows
     ST_REQUIRE(rows > 0 && F > 0, "geglu: bad shape rows=%d F=%d", rows, F);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ST_BF16) return geglu_launch<bf16>(state, gate, out, rows, F, ld_state, ld_gate, ld_out, st);
+    if (dtype == ST_F16) return geglu_launch<f16>(state, gate, out, rows, F, ld_state, ld_gate, ld_out, st);
     if (dtype == ST_F32) return geglu_launch<float>(state, gate, out, rows, F, ld_state, ld_gate, ld_out, st);
     return st_fail("geglu: unsupported dtype %d", dtype);
 }

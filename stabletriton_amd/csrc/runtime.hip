@@ -19,7 +19,7 @@ int st_check_launch(const char* what) {
 }
 
 extern "C" const char* st_last_error(void) { return g_err; }
-extern "C" int st_abi_version(void) { return 9; }
+extern "C" int st_abi_version(void) { return 10; }
 
 // ---- Euler-discrete update ---------------------------------------------------
 template <typename T>
@@ -45,6 +45,8 @@ extern "C" int st_euler_step(float* latent, const void* eps, void* next_in, cons
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ST_BF16)
         hipLaunchKernelGGL(euler_kernel<bf16>, dim3(grid), dim3(256), 0, st, latent, (const bf16*)eps, (bf16*)next_in, dsigma, in_scale, step, n, n_steps);
+    else if (dtype == ST_F16)
+        hipLaunchKernelGGL(euler_kernel<f16>, dim3(grid), dim3(256), 0, st, latent, (const f16*)eps, (f16*)next_in, dsigma, in_scale, step, n, n_steps);
     else if (dtype == ST_F32)
         hipLaunchKernelGGL(euler_kernel<float>, dim3(grid), dim3(256), 0, st, latent, (const float*)eps, (float*)next_in, dsigma, in_scale, step, n, n_steps);
     else
@@ -88,6 +90,8 @@ extern "C" int st_timestep_features(const float* t, long t_stride, const int* st
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ST_BF16)
         hipLaunchKernelGGL(timestep_kernel<bf16>, dim3(cdiv(n, 256)), dim3(256), 0, st, t, t_stride, step, (bf16*)out, batch, dim);
+    else if (dtype == ST_F16)
+        hipLaunchKernelGGL(timestep_kernel<f16>, dim3(cdiv(n, 256)), dim3(256), 0, st, t, t_stride, step, (f16*)out, batch, dim);
     else if (dtype == ST_F32)
         hipLaunchKernelGGL(timestep_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, t, t_stride, step, (float*)out, batch, dim);
     else

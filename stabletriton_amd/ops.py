@@ -8,7 +8,6 @@ launch goes to torch's current stream, so the ops are capturable.
 """
 from __future__ import annotations
 
-import os
 import threading
 from typing import Optional
 
@@ -16,39 +15,6 @@ import torch
 
 from . import _C
 from ._C import BackendError
-
-# Optional per-launch census used by bench.py's roofline leg: when a list is
-# installed, every launcher appends (family, flops, bytes, start_event, end_event)
-# with the events recorded on the launch stream around the C call.
-_census = None
-
-
-def set_census(store) -> None:
-    global _census
-    _census = store
-
-
-_tag = None          # shape label of the launch being timed (census runs only)
-
-
-def _timed(family: str, flops: float, nbytes: float, fn, *args) -> int:
-    global _tag
-    if _census is None:
-        return fn(*args)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    status = fn(*args)
-    e1.record()
-    _census.append((family, flops, nbytes, e0, e1, _tag))
-    _tag = None
-    return status
-
-
-def _label(text: str) -> None:
-    global _tag
-    if _census is not None:
-        _tag = text
-
 
 # ---- execution context: the mutable host state of one compiled module ------------------------------
 # split-K scratch for st_linear / st_conv2d: a fixed-size slab, allocated once per context and never
@@ -141,7 +107,7 @@ class ExecContext:
     several streams at once give each stream its own ExecContext."""
 
     def __init__(self, hints: bool = True):
-        self.plan = WeightPlan() if hints and not os.environ.get("ST_NO_WEIGHT_HINTS") else None
+        self.plan = WeightPlan() if hints else None
         self.hinting = False         # True only inside step(): one-off passes (context / time tables) stay out of the plan
         self._ws = {}
         self.derived = {}
@@ -274,8 +240,7 @@ def group_norm(x: torch.Tensor, num_groups: int, weight: torch.Tensor, bias: tor
     # scratch for the partial statistics: allocated per call from torch's caching allocator (stream-ordered; under
     # graph capture it belongs to the graph's private pool, so replays never alias a buffer somebody else owns)
     ws = torch.empty(lib.st_group_norm_workspace_bytes(N, Cc, HW, num_groups), dtype=torch.uint8, device=x.device)
-    _label(f"N={N} C={Cc} HW={HW} silu={int(bool(silu))}")
-    _C.check(_timed("group_norm", 0.0, 2.0 * x.numel() * x.element_size(), lib.st_group_norm, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups,
+    _C.check(lib.st_group_norm(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups,
                                float(eps), int(bool(silu)), layout, _C.dtype_code(x.dtype), ws.data_ptr(),
                                _C.stream_ptr()), "group_norm")
     return y
@@ -318,8 +283,7 @@ def group_norm_from_stats(x: torch.Tensor, sources, num_groups: int, weight: tor
     ws = torch.empty(lib.st_group_norm_workspace_bytes(N, Cc, HW, num_groups), dtype=torch.uint8, device=x.device)
     s0 = sources[0]
     s1 = sources[1] if len(sources) == 2 else None
-    _label(f"N={N} C={Cc} HW={HW} silu={int(bool(silu))} from-stats")
-    _C.check(_timed("group_norm", 0.0, 2.0 * x.numel() * x.element_size(), lib.st_group_norm_from_stats, x.data_ptr(), w.data_ptr(),
+    _C.check(lib.st_group_norm_from_stats(x.data_ptr(), w.data_ptr(),
                     b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups, float(eps), int(bool(silu)), _C.dtype_code(x.dtype),
                     s0.buf.data_ptr(), s0.channels, s0.rows, None if s1 is None else s1.buf.data_ptr(),
                     0 if s1 is None else s1.channels, 0 if s1 is None else s1.rows, ws.data_ptr(), _C.stream_ptr()),
@@ -337,7 +301,7 @@ def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: f
     y = torch.empty_like(xc)
     w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
     b = bias if bias.dtype == x.dtype else bias.to(x.dtype)
-    _C.check(_timed("layer_norm", 0.0, 2.0 * xc.numel() * xc.element_size(), lib.st_layer_norm, xc.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), xc.numel() // Cc, Cc,
+    _C.check(lib.st_layer_norm(xc.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), xc.numel() // Cc, Cc,
                                float(eps), _C.dtype_code(x.dtype), _C.stream_ptr()), "layer_norm")
     return y
 
@@ -360,7 +324,7 @@ def geglu(state: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
     s, lds = rows(state)
     g, ldg = rows(gate)
     out = torch.empty(state.shape, dtype=state.dtype, device=state.device)
-    _C.check(_timed("geglu", 0.0, 3.0 * state.numel() * state.element_size(), lib.st_geglu, s.data_ptr(), g.data_ptr(), out.data_ptr(), state.numel() // F, F, lds, ldg, F,
+    _C.check(lib.st_geglu(s.data_ptr(), g.data_ptr(), out.data_ptr(), state.numel() // F, F, lds, ldg, F,
                           _C.dtype_code(state.dtype), _C.stream_ptr()), "geglu")
     return out
 
@@ -422,19 +386,18 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     rows_per_image = 0
     if emit_colstats:
         import ctypes
-        if x.dim() != 3:
-            raise BackendError("linear: emit_colstats needs a (batch, tokens, K) input")
-        rows_per_image = x.shape[1]
-        cbuf, ctiles, crows = _colstats_buffer(M, N, x.device)
-    _label(f"M={M} N={N} K={K} epi={epi}{' stats' if emit_stats else ''}{' colstats' if emit_colstats else ''}")
-    _C.check(_timed("linear", 2.0 * M * w.shape[0] * K, float((M * K + w.numel() + M * N) * x.element_size()),
-                    lib.st_linear, x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
+        if x.dim() == 3:
+            rows_per_image = x.shape[1]
+            cbuf, ctiles, crows = _colstats_buffer(M, N, x.device)
+        # (any other rank: tokens were flattened, the image boundaries are unknown - no partials, the consumer
+        # GroupNorm takes its own statistics pass, as for every other producer that cannot emit them)
+    _C.check(lib.st_linear(x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
                     lda, N, ldr, rows_per_image, epi, _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(),
                     _ptr(stats), 0 if stats is None else stats.shape[1],
                     None if chunks is None else ctypes.byref(chunks), _ptr(cbuf), ctiles or 0,
                     None if crows is None else ctypes.byref(crows), nxt_p, nxt_b, _C.stream_ptr()), "linear")
     if emit_colstats:
-        return out, (ColStats(cbuf, crows.value, N) if crows.value > 0 else None)
+        return out, (ColStats(cbuf, crows.value, N) if crows is not None and crows.value > 0 else None)
     if emit_stats:
         if chunks.value <= 0:
             raise BackendError("linear: this shape cannot emit LayerNorm row statistics (K must be a multiple of the K tile)")
@@ -457,19 +420,17 @@ def ln_linear(x: torch.Tensor, stats: "RowStats", w_folded: torch.Tensor, c: tor
     N = w_folded.shape[0] // 2 if geglu else w_folded.shape[0]
     out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
     nxt_p, nxt_b = _next_weights(w_folded)
-    _label(f"M={M} N={N} K={K} ln{' geglu' if geglu else ''}")
-    _C.check(_timed("linear", 2.0 * M * w_folded.shape[0] * K, float((M * K + w_folded.numel() + M * N) * x.element_size()),
-                    lib.st_ln_linear, x2.data_ptr(), stats.buf.data_ptr(), stats.chunks, w_folded.data_ptr(),
+    _C.check(lib.st_ln_linear(x2.data_ptr(), stats.buf.data_ptr(), stats.chunks, w_folded.data_ptr(),
                     c.data_ptr(), d.data_ptr(), out.data_ptr(), M, N, K,
                     lda, N, float(eps), _C.EPI_GEGLU if geglu else 0, _C.dtype_code(x.dtype), nxt_p, nxt_b, _C.stream_ptr()), "ln_linear")
     return out
 
 
 def xattn_fusable(x: torch.Tensor, k: torch.Tensor, heads: int) -> bool:
-    """Shapes `ln_linear_xattn` takes: bf16, a short context (the 16-row attention kernel's range) and query blocks of
+    """Shapes `ln_linear_xattn` takes: bf16 / fp16, a short context (the 16-row attention kernel's range) and query blocks of
     128 rows that do not straddle batch entries."""
     rows = x.shape[-2] if x.dim() >= 3 else x.shape[0]
-    return (x.dtype == torch.bfloat16 and k.dim() == 3 and k.shape[1] < 256 and rows % 128 == 0 and k.shape[-1] == heads * 64
+    return (x.dtype in (torch.bfloat16, torch.float16) and k.dim() == 3 and k.shape[1] < 256 and rows % 128 == 0 and k.shape[-1] == heads * 64
             and k.stride(-1) == 1)
 
 
@@ -495,16 +456,14 @@ def ln_linear_xattn(x: torch.Tensor, stats: "RowStats", w_folded: torch.Tensor, 
     if x.dim() != 3 or k.dim() != 3 or v.shape != k.shape or k.shape[0] != x.shape[0] or N != heads * 64 or k.shape[-1] != N:
         raise BackendError(f"ln_linear_xattn: shapes x={tuple(x.shape)} k={tuple(k.shape)} v={tuple(v.shape)} heads={heads}")
     if not xattn_fusable(x, k, heads) or v.stride(-1) != 1 or k.stride(0) != k.shape[1] * k.stride(1) or v.stride(0) != v.shape[1] * v.stride(1):
-        raise BackendError("ln_linear_xattn: layout not supported (bf16, context < 256 tokens, 128 | rows per batch, dense batches)")
+        raise BackendError("ln_linear_xattn: layout not supported (bf16 / fp16, context < 256 tokens, 128 | rows per batch, dense batches)")
     x2, M, lda = _rows2d(x)
     out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
     nxt_p, nxt_b = _next_weights(w_folded)
     S = k.shape[1]
-    _label(f"M={M} N={N} K={K} ln xattn S={S}")
-    _C.check(_timed("linear_xattn", 2.0 * M * N * K + 4.0 * M * S * N, float((M * K + w_folded.numel() + M * N + 2 * k.shape[0] * S * N) * x.element_size()),
-                    lib.st_ln_linear_xattn, x2.data_ptr(), stats.buf.data_ptr(), stats.chunks, w_folded.data_ptr(),
+    _C.check(lib.st_ln_linear_xattn(x2.data_ptr(), stats.buf.data_ptr(), stats.chunks, w_folded.data_ptr(),
                     c.data_ptr(), d.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), M, N, K, lda, N, float(eps),
-                    x.shape[1], S, heads, k.stride(1), v.stride(1), float(scale), nxt_p, nxt_b, _C.stream_ptr()), "ln_linear_xattn")
+                    x.shape[1], S, heads, k.stride(1), v.stride(1), float(scale), _C.dtype_code(x.dtype), nxt_p, nxt_b, _C.stream_ptr()), "ln_linear_xattn")
     return out
 
 
@@ -549,7 +508,7 @@ def quantize_fp8(x: torch.Tensor, layernorm=None) -> Fp8Rows:
     q = torch.empty((M, K), dtype=torch.uint8, device=x.device)
     scale = torch.empty((M,), dtype=torch.float32, device=x.device)
     if layernorm is None:
-        _C.check(_timed("quantize_fp8", 0.0, float(x2.numel() * (x.element_size() + 1)), lib.st_quantize_fp8, x2.data_ptr(), ldx,
+        _C.check(lib.st_quantize_fp8(x2.data_ptr(), ldx,
                         q.data_ptr(), scale.data_ptr(), M, K, _C.dtype_code(x.dtype), _C.stream_ptr()), "quantize_fp8")
     else:
         gamma, beta, eps = layernorm
@@ -557,7 +516,7 @@ def quantize_fp8(x: torch.Tensor, layernorm=None) -> Fp8Rows:
             x2 = x2.contiguous()
         g = gamma if gamma.dtype == x.dtype else gamma.to(x.dtype)
         b = beta if beta.dtype == x.dtype else beta.to(x.dtype)
-        _C.check(_timed("quantize_fp8", 0.0, float(x2.numel() * (x.element_size() + 1)), lib.st_layer_norm_quantize_fp8, x2.data_ptr(),
+        _C.check(lib.st_layer_norm_quantize_fp8(x2.data_ptr(),
                         g.data_ptr(), b.data_ptr(), q.data_ptr(), scale.data_ptr(), M, K, float(eps), _C.dtype_code(x.dtype),
                         _C.stream_ptr()), "layer_norm_quantize_fp8")
     return Fp8Rows(q, scale, x.shape)
@@ -591,9 +550,7 @@ def linear_fp8(x: "Fp8Rows", wq: torch.Tensor, w_scale: torch.Tensor, bias: Opti
         epi |= _C.EPI_RESIDUAL
     gws = _gemm_workspace(wq.device)
     nxt_p, nxt_b = _next_weights(wq)
-    _label(f"M={M} N={N} K={K} fp8 epi={epi}")
-    _C.check(_timed("linear_fp8", 2.0 * M * wq.shape[0] * K, float(M * K + wq.numel() + 2 * M * N), lib.st_linear_fp8,
-                    x.q.data_ptr(), x.scale.data_ptr(), wq.data_ptr(), w_scale.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
+    _C.check(lib.st_linear_fp8(x.q.data_ptr(), x.scale.data_ptr(), wq.data_ptr(), w_scale.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
                     M, N, K, K, N, ldr, epi, gws.data_ptr(), gws.numel(), nxt_p, nxt_b, _C.stream_ptr()), "linear_fp8")
     return out
 
@@ -619,9 +576,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int,
     k_, ldk = tok(k)
     v_, ldv = tok(v)
     out = torch.empty((B, T, Cc), dtype=q.dtype, device=q.device)
-    _label(f"B={B} T={T} S={S} H={num_heads}")
-    _C.check(_timed("attention_self" if S == T else "attention_cross", 4.0 * B * num_heads * T * S * D,
-                    float((2 * q.numel() + k.numel() + v.numel()) * q.element_size()), lib.st_attention, q_.data_ptr(), k_.data_ptr(), v_.data_ptr(), out.data_ptr(), B, T, S, num_heads, D,
+    _C.check(lib.st_attention(q_.data_ptr(), k_.data_ptr(), v_.data_ptr(), out.data_ptr(), B, T, S, num_heads, D,
                               ldq, ldk, ldv, Cc, float(scale), _C.dtype_code(q.dtype), _C.stream_ptr()), "attention")
     return out
 
@@ -672,9 +627,7 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
     if emit_colstats:
         import ctypes
         cbuf, ctiles, crows = _colstats_buffer(N * Ho * Wo, Cout, x.device)
-    _label(f"Cin={Cin} H={H} Cout={Cout} k={R} s={stride} ups={int(upsample2x)} epi={epi}{' colstats' if emit_colstats else ''}")
-    _C.check(_timed("conv2d", 2.0 * N * Ho * Wo * Cout * R * S * Cin,
-                    float((x.numel() + w.numel() + out.numel()) * x.element_size()), lib.st_conv2d, x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(rowbias), out.data_ptr(),
+    _C.check(lib.st_conv2d(x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(rowbias), out.data_ptr(),
                            N, H, W, Cin, Cout, R, S, stride, padding, int(upsample2x), epi,
                            _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(), _ptr(cbuf), ctiles or 0,
                            None if crows is None else ctypes.byref(crows), nxt_p, nxt_b, _C.stream_ptr()), "conv2d")

@@ -10,7 +10,6 @@ callable with the original forward signature; the caller re-attaches `.config`
 """
 from __future__ import annotations
 
-import os
 from typing import Dict
 
 import torch
@@ -24,10 +23,12 @@ from .optimizers import (dedupe_pure_calls, fuse_token_residual, fuse_attention,
                          replace_linear, replace_linear_activ)
 
 
-def replace_backend(gm: fx.GraphModule, fuse: bool = True, fp8: bool = False) -> fx.GraphModule:
+def replace_backend(gm: fx.GraphModule, fuse: bool = True, fp8: bool = False, xattn_fusion: bool = True,
+                    gn_stats: bool = True) -> fx.GraphModule:
     """Pass pipeline.  The first eight passes and their order are the reference's
     (optimization.py:10-22); replace_linear is enabled (the MFMA GEMM is the
-    product here), replace_conv / epilogue fusions / layout are additions."""
+    product here), replace_conv / epilogue fusions / layout are additions.
+    `xattn_fusion` / `gn_stats` switch two of the added fusions off (A/B measurements)."""
     stats: Dict[str, int] = {}
     stats["dropout"] = remove_dropout(gm)
     if fuse:
@@ -50,8 +51,8 @@ def replace_backend(gm: fx.GraphModule, fuse: bool = True, fp8: bool = False) ->
         if fp8:      # transformer-block projections on the fp8 matrix pipe (claims its LayerNorms before the bf16 folding does)
             stats["fp8_projections"] = quantize_projections_fp8(gm)
         stats["layer_norm_in_gemm"] = fuse_layernorm_into_linear(gm)
-        stats["query_projection_in_attention"] = 0 if os.environ.get("ST_NO_XATTN_FUSION") else fuse_query_projection_into_attention(gm)   # (env: developer A/B)
-        stats["group_norm_stats"] = 0 if os.environ.get("ST_NO_GN_STATS") else fuse_groupnorm_stats(gm)      # (env: developer A/B)
+        stats["query_projection_in_attention"] = fuse_query_projection_into_attention(gm) if xattn_fusion else 0
+        stats["group_norm_stats"] = fuse_groupnorm_stats(gm) if gn_stats else 0
     stats["channels_last_views"] = keep_channels_last(gm)
     gm.graph.eliminate_dead_code()
     gm.graph.lint()
@@ -74,8 +75,10 @@ def optimize_model(model: nn.Module, cuda_graph: bool = True, fuse: bool = True,
         raise RuntimeError("a CDNA GPU (gfx9xx; built and tuned for gfx950 / MI355X) is required")
     p0 = next(model.parameters())
     assert p0.device.type == "cuda", "Model must be on GPU"
-    if p0.dtype not in (torch.bfloat16, torch.float32):
-        raise RuntimeError(f"model dtype {p0.dtype} not supported: use bfloat16 (fast) or float32 (strict parity)")
+    # fp16 is what the reference's call site passes (load_sdxl_pipeline.py:17-28: `.half().cuda()`); bf16 has the same
+    # matrix-pipe rate and fp32's exponent range; fp32 is the strict parity mode
+    if p0.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+        raise RuntimeError(f"model dtype {p0.dtype} not supported: use float16 / bfloat16 (fast) or float32 (strict parity)")
     _C.load()                                  # fail now, loudly, if the HIP library is missing
     model = model.eval().to(memory_format=torch.channels_last)      # conv weights -> (Cout,R,S,Cin) strides
     if fp8 and p0.dtype != torch.bfloat16:

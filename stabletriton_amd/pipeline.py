@@ -98,8 +98,12 @@ class DenoiseLoop:
         """img2img start (the refiner's use, BASELINE config #5; restated diffusers img2img: `get_timesteps` +
         `scheduler.add_noise`): skip the first n - int(n * strength) schedule entries, start from
         init_latent + noise * sigma[t_start].  Returns the number of steps left to run (`run_steps(k)`, mode step / eager)."""
+        if self.mode == "loop":
+            raise ValueError("set_image needs mode='step' or 'eager': the captured full-trajectory loop cannot start mid-schedule")
         n = self.n_steps
         t_start = max(n - min(int(n * strength), n), 0)
+        if t_start >= n:
+            raise ValueError(f"strength {strength} leaves no denoise step of the {n}-step schedule (int(n * strength) == 0)")
         sigma = float(self.tables.sigmas[t_start])
         lat = init_latent.to(self.device, torch.float32) + noise_unit.to(self.device, torch.float32) * sigma
         self.latent.copy_(lat)

@@ -58,6 +58,21 @@ def sdxl_bf16_pair(gpu):
 
 
 @pytest.fixture(scope="session")
+def sdxl_fp16_pair(gpu):
+    """What the reference call site builds: the module in half precision (load_sdxl_pipeline.py:17-28)."""
+    import torch
+    pair = _build_sdxl(torch.float16, gpu)
+    yield pair
+    del pair
+    torch.cuda.empty_cache()
+
+
+@pytest.fixture(scope="session")
+def sdxl_fp16(sdxl_fp16_pair):
+    return sdxl_fp16_pair[1]
+
+
+@pytest.fixture(scope="session")
 def sdxl_fp32(sdxl_fp32_pair):
     return sdxl_fp32_pair[1]
 

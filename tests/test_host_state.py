@@ -106,3 +106,10 @@ def test_rccl_report_digest(tmp_path):
     rep = bench.rccl_report(str(log))
     assert rep["nranks_logged"] == 8 and rep["transports"] == ["P2P/IPC"] and rep["channels"] == 2
     assert bench.rccl_report(str(tmp_path / "missing.log")) is None
+
+
+def test_rccl_self_check_fails_a_partial_communicator(tmp_path):
+    """backend=nccl: the first real multi-GPU run checks itself - a communicator that does not span the job is an error."""
+    assert bench.rccl_self_check({"nranks_logged": 8, "transports": ["P2P/IPC"], "channels": 2}, 8) is None
+    assert "8" in bench.rccl_self_check({"nranks_logged": 4, "transports": [], "channels": 0}, 8)
+    assert bench.rccl_self_check(None, 2) is not None

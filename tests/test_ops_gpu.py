@@ -1,15 +1,15 @@
 """Per-operator parity: HIP kernels (through the C ABI) vs the CPU oracle on the
-same seeded inputs.  fp32 = strict mode, bf16 = fast mode (tolerances in util.py)."""
+same seeded inputs.  fp32 = strict mode, bf16 / fp16 = fast modes (tolerances in util.py)."""
 import pytest
 import torch
 import torch.nn.functional as F
 
 from oracle import unet_oracle as orc
 from stabletriton_amd import ops, synth
-from tests.util import assert_close, rounded
+from tests.util import HALF_DTYPES, assert_close, rounded
 
 pytestmark = pytest.mark.gpu
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 
 
 def rnd(name, shape, scale=1.0):
@@ -90,10 +90,10 @@ def test_linear(gpu, dtype, M, K, N):
                  "linear+bias+residual")
 
 
-def test_split_k_is_bit_reproducible(gpu):
+@pytest.mark.parametrize("dtype", HALF_DTYPES)
+def test_split_k_is_bit_reproducible(gpu, dtype):
     """The in-launch K split sums its slabs in slice order whichever block finishes last: repeated
     launches (and launches interleaved with other split GEMMs that share the workspace) agree bitwise."""
-    dtype = torch.bfloat16
     x, w, b = rnd("sk.x", (1024, 5120)).to(gpu, dtype), (rnd("sk.w", (1280, 5120)) * 5120 ** -0.5).to(gpu, dtype), rnd("sk.b", (1280,)).to(gpu, dtype)
     x2, w2 = rnd("sk.x2", (77, 2048)).to(gpu, dtype), (rnd("sk.w2", (640, 2048)) * 2048 ** -0.5).to(gpu, dtype)
     first = ops.linear(x, w, b)
@@ -168,8 +168,9 @@ def test_attention_peaked_softmax(gpu):
         assert_close(out, ref, dtype, "attention peaked")
 
 
+@pytest.mark.parametrize("dtype", HALF_DTYPES)
 @pytest.mark.parametrize("T,S", [(64, 320), (48, 4096), (16, 77)])
-def test_attention_lazy_reference_maximum(gpu, T, S):
+def test_attention_lazy_reference_maximum(gpu, T, S, dtype):
     """The bf16 16-row kernel keeps a row's reference maximum until a tile outruns it by 2^6 (attention.hip ATT_LAG):
     exercise rows whose maximum grows by less than the lag, by more (the exact path), late, and in the masked last
     tile; rows whose first tile holds only very negative scores; rows with very large scores."""
@@ -181,13 +182,13 @@ def test_attention_lazy_reference_maximum(gpu, T, S):
     k[:, S // 2] = q[:, 3] * 3.0
     k[:, :64] = k[:, :64] - q[:, 4:5] * 4.0 * (torch.arange(64)[None, :, None] >= 0)      # row 4: first tile strongly negative
     q[:, 5] = q[:, 5] * 12.0                # row 5: scores of magnitude ~100
-    dtype = torch.bfloat16
     ref = orc.attention_core(rounded(q, dtype), rounded(k, dtype), rounded(v, dtype), H)
     out = ops.attention(q.to(gpu, dtype), k.to(gpu, dtype), v.to(gpu, dtype), H, 0.125)
     assert_close(out, ref, dtype, "attention lazy maximum")
 
 
-def test_attention_seven_wave_blocks_lazy_maximum(gpu):
+@pytest.mark.parametrize("dtype", HALF_DTYPES)
+def test_attention_seven_wave_blocks_lazy_maximum(gpu, dtype):
     """attn32i_kernel<7, loader> (more than 128 blocks of 256 rows would be needed: 224-row blocks, T = 512 leaves a ragged
     last block): rows whose maximum outruns the lag in a late tile, in the masked last tile, and rows that start from a
     very negative first tile."""
@@ -197,18 +198,17 @@ def test_attention_seven_wave_blocks_lazy_maximum(gpu):
     k[:, 200] = q[:, 300] * 5.0
     k[:, 70] = q[:, 511] * 1.5
     k[:, :64] = k[:, :64] - q[:, 4:5] * 4.0
-    dtype = torch.bfloat16
     ref = orc.attention_core(rounded(q, dtype), rounded(k, dtype), rounded(v, dtype), H)
     out = ops.attention(q.to(gpu, dtype), k.to(gpu, dtype), v.to(gpu, dtype), H, 0.125)
     assert_close(out, ref, dtype, "attention, seven-wave blocks")
 
 
+@pytest.mark.parametrize("dtype", HALF_DTYPES)
 @pytest.mark.parametrize("B,T,S,H", [(1, 1024, 1024, 10), (1, 4096, 4096, 10), (2, 1024, 1024, 20), (1, 1024, 77, 20)])
-def test_attention_is_bit_stable_when_another_stream_shares_the_cus(gpu, B, T, S, H):
+def test_attention_is_bit_stable_when_another_stream_shares_the_cus(gpu, B, T, S, H, dtype):
     """The hardware does not interlock MFMA results against VALU reads and the compiler only protects instructions it
     can see; an inline-asm maximum over fresh accumulators once changed results by 1 ulp whenever the matrix pipe was
     shared with another kernel.  Solo and crowded runs must agree bit for bit."""
-    dtype = torch.bfloat16
     q, k, v = (rnd(f"attc.{n}", (B, L, H * 64)).to(gpu, dtype) for n, L in (("q", T), ("k", S), ("v", S)))
     solo = ops.attention(q, k, v, H, 0.125).clone()
     torch.cuda.synchronize()
@@ -225,10 +225,10 @@ def test_attention_is_bit_stable_when_another_stream_shares_the_cus(gpu, B, T, S
 
 
 @pytest.mark.parametrize("B,T,C,H,S", [(1, 1024, 1280, 20, 77), (2, 256, 640, 10, 77), (1, 4096, 640, 10, 77), (1, 128, 128, 2, 5), (3, 384, 192, 3, 200)])
-def test_query_projection_with_text_context_attention_in_its_epilogue(gpu, B, T, C, H, S):
+@pytest.mark.parametrize("dtype", HALF_DTYPES)
+def test_query_projection_with_text_context_attention_in_its_epilogue(gpu, B, T, C, H, S, dtype):
     """st_ln_linear_xattn == st_ln_linear followed by st_attention, bit for bit (the query tile is rounded to bf16 in LDS
     exactly as the unfused path rounds it in HBM), and both match the oracle."""
-    dtype = torch.bfloat16
     x = rnd("xa.x", (B, T, C)) * 1.3 + 0.2
     g, be = rnd("xa.g", (C,)) * 0.2 + 1.0, rnd("xa.b", (C,)) * 0.2
     w, b = rnd("xa.w", (C, C)) * C ** -0.5, rnd("xa.bias", (C,))
@@ -312,10 +312,15 @@ def test_ops_fail_loudly(gpu):
     with pytest.raises(ops.BackendError):
         ops.linear(x, w)                                   # CPU tensors: no fallback
     with pytest.raises(ops.BackendError):
-        ops.linear(x.to(gpu).half(), w.to(gpu).half())     # fp16 is not a supported dtype
+        ops.linear(x.to(gpu).double(), w.to(gpu).double())   # fp64 is not a supported dtype
     with pytest.raises(ops.BackendError):
         ops.attention(torch.zeros(1, 8, 96, device=gpu), torch.zeros(1, 8, 96, device=gpu),
                       torch.zeros(1, 8, 96, device=gpu), 3, 1.0)   # head_dim 32 unsupported
+    with pytest.raises(ops.BackendError):                  # the fused query-projection + attention launch takes short contexts only
+        C = 128
+        xg, st = ops.linear(torch.zeros(1, 128, C, device=gpu, dtype=torch.float16), torch.eye(C, device=gpu, dtype=torch.float16), None, emit_stats=True)
+        kv = torch.zeros(1, 300, C, device=gpu, dtype=torch.float16)
+        ops.ln_linear_xattn(xg, st, torch.eye(C, device=gpu, dtype=torch.float16), torch.zeros(C, device=gpu), torch.zeros(C, device=gpu), 1e-5, kv, kv, 2, 0.125)
 
 
 # ---------------------------------------------------------------------------------- GroupNorm statistics from the producer

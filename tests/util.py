@@ -10,7 +10,9 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 #  fp32 ("strict") path: same arithmetic as the eager reference up to summation
 #  order -> 2e-4 of the output scale per op, 1e-3 abs on final latents (north_star).
 #  bf16 path: inputs/outputs carry 8 mantissa bits (rel 2^-9 = 2e-3 per rounding).
-TOL = {torch.float32: 2e-4, torch.bfloat16: 2e-2}
+#  fp16 path (the reference's own compute type): 11 mantissa bits (rel 2^-12 per rounding): a quarter of the bf16 bound.
+TOL = {torch.float32: 2e-4, torch.bfloat16: 2e-2, torch.float16: 5e-3}
+HALF_DTYPES = [torch.bfloat16, torch.float16]
 
 
 def golden(name):
@@ -30,5 +32,5 @@ def assert_close(out, ref, dtype, what="", factor=1.0):
 
 
 def rounded(x: torch.Tensor, dtype) -> torch.Tensor:
-    """Value the kernel actually sees (bf16-rounded), as fp32 for the oracle."""
+    """Value the kernel actually sees (bf16- / fp16-rounded), as fp32 for the oracle."""
     return x.to(dtype).float()

@@ -1,10 +1,11 @@
 """Developer probe of attn32i_kernel (needs a -DST_PROBE build, e.g. tools/build_one_variant.sh attprobe attention.hip -DST_PROBE;
-run with ST_LIB_VARIANT=attprobe): per-wave cycles per trip of the QK phase, the PV phase, the lazy-maximum check and the DMA wait + barrier.
+run with ST_VARIANT=attprobe): per-wave cycles per trip of the QK phase, the PV phase, the lazy-maximum check and the DMA wait + barrier.
 The stamps themselves drain the LDS queue (s_memtime + lgkmcnt(0)), so the phases read a little long."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stabletriton_amd import _C, ops
-lib = _C.load()
+from tools.devlib import use_variant
+lib = use_variant(os.environ.get("ST_VARIANT", "attprobe"))
 dev = torch.device("cuda:0")
 probe = torch.zeros(64, dtype=torch.int64, device=dev)
 lib.st_debug_set_att_probe.argtypes = [ctypes.c_void_p]

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Developer helper: rebuild ONE source with extra -D flags and link it with the product objects of the other sources.
-# usage: tools/build_one_variant.sh <name> <source.hip> [-DFLAG ...]   -> stabletriton_amd/lib/<name>/libstabletriton_amd.so
+# usage: tools/build_one_variant.sh <name> <source.hip> [-DFLAG ...]   -> tools/_variants/<name>/libstabletriton_amd.so
 set -e
 name=$1; src=$2; shift 2
 root=$(cd "$(dirname "$0")/.." && pwd)
-out=$root/stabletriton_amd/lib/$name
+out=$root/tools/_variants/$name
 mkdir -p "$out"
 base=$(basename "${src%.hip}")
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form "$@" -c "$root/stabletriton_amd/csrc/$base.hip" -o "$out/$base.o"

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Developer helper: build an alternative library under stabletriton_amd/lib/<name>/ with extra -D flags.
-# usage: tools/build_variant.sh <name> [-DFLAG ...]    (ST_LIB_VARIANT=<name> selects it at run time)
+# Developer helper: build an alternative library under tools/_variants/<name>/ with extra -D flags.
+# usage: tools/build_variant.sh <name> [-DFLAG ...]    (tools/devlib.use_variant(<name>) / ST_VARIANT=<name> in the tools selects it)
 set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
-out=$root/stabletriton_amd/lib/$name
+out=$root/tools/_variants/$name
 mkdir -p "$out"
 objs=()
 for f in "$root"/stabletriton_amd/csrc/*.hip; do

@@ -1,5 +1,5 @@
 """Developer sweep: pipeline depth / tile variants of the LDS-DMA GEMM (dev variant: -DST_DEV_CONFIGS, optionally
--DST_FILL_ONLY to time the DMA stream alone).  ST_LIB_VARIANT selects the build."""
+-DST_FILL_ONLY to time the DMA stream alone).  ST_VARIANT selects the build."""
 import ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 """Developer sweep: tile config x in-launch split-K for the mid-size Linear shapes (needs the dev variant:
-tools/build_variant.sh dev -DST_DEV_CONFIGS; run with ST_LIB_VARIANT=dev)."""
+tools/build_variant.sh dev -DST_DEV_CONFIGS; run with ST_VARIANT=dev)."""
 import ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

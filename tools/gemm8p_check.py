@@ -1,6 +1,6 @@
 """Developer check of the 256x256 eight-phase GEMM against torch (fp32 reference on the bf16-rounded operands) and A/B
 timing against the cost model's choice.  Needs the dev library:  tools/build_variant.sh dev -DST_DEV_CONFIGS  and
-ST_LIB_VARIANT=dev."""
+ST_VARIANT=dev."""
 import ctypes
 import os
 import sys

@@ -1,5 +1,5 @@
 """Developer timing of one Linear shape: product dispatch, forced configurations, hipBLASLt (torch) - warm and cold weights.
-usage: gemm_one.py M K N [g]   (needs ST_LIB_VARIANT=dev for the forced rows)"""
+usage: gemm_one.py M K N [g]   (needs ST_VARIANT=dev for the forced rows)"""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stabletriton_amd import _C, ops

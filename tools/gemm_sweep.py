@@ -1,5 +1,5 @@
 """Developer sweep: every tile configuration x K split of the LDS-DMA GEMM for the Linear shapes of a batch size,
-against the cost model's own choice (needs the -DST_DEV_CONFIGS library: ST_LIB_VARIANT=dev).
+against the cost model's own choice (needs the -DST_DEV_CONFIGS library: ST_VARIANT=dev).
 usage: gemm_sweep.py <batch> [geglu|plain|all]"""
 import ctypes
 import os

@@ -7,6 +7,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stabletriton_amd import ops  # noqa: E402
+from tools.devlib import use_variant  # noqa: E402
+
+use_variant(os.environ.get("ST_VARIANT"))      # ST_VARIANT=<name>: a tools/_variants/<name> build (developer A/B runs)
 
 dev = torch.device("cuda:0")
 dt = torch.bfloat16

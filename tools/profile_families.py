@@ -16,12 +16,15 @@ import sys
 def family(name: str):
     if "conv_halo_kernel" in name or "conv_thin_kernel" in name:
         return "conv2d"
-    m = re.search(r"gemm_dma_kernelI\w*?Li\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELb([01])E", name)
+    # gemm_dma_kernel<T, BM, BN, WGM, WGN, STAGES, U, CONV, GEGLU, LNF, XA>: mangled (what rocprofv3 prints for it) or demangled
+    m = re.search(r"gemm_dma_kernelI\w*?Li\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELb([01])ELb[01]ELb[01]ELb([01])E", name)
     if m:
-        return "conv2d" if m.group(1) == "1" else "linear"
-    m = re.search(r"gemm_dma_kernel<[^>]*?,\s*(true|false),\s*(true|false),\s*(true|false)>", name)
+        conv, xa = m.group(1) == "1", m.group(2) == "1"
+        return "conv2d" if conv else ("linear_xattn" if xa else "linear")
+    m = re.search(r"gemm_dma_kernel<[^>]*?,\s*(true|false),\s*(?:true|false),\s*(?:true|false),\s*(true|false)>", name)
     if m:
-        return "conv2d" if m.group(1) == "true" else "linear"
+        conv, xa = m.group(1) == "true", m.group(2) == "true"
+        return "conv2d" if conv else ("linear_xattn" if xa else "linear")
     if "gemm8p_kernel" in name:
         return "linear"
     if "gemm_kernel" in name:                      # register-staged fallback (ragged K)
@@ -29,7 +32,7 @@ def family(name: str):
     if "attn16v2_kernel" in name:                  # the 77-token text context (S < 256) is the only user of the 16-row kernel
         return "attention_cross"
     if "attn" in name:
-        return "attention"
+        return "attention_self"
     if name.startswith("gn_") or "gn_stats" in name or "gn_apply" in name or "gn_finalize" in name:
         return "group_norm"
     if "ln_kernel" in name:
