@@ -1,7 +1,9 @@
+// (gemm_core.h: every kernel and launcher template of the GEMM-shaped operators; instantiated per element type in
+//  gemm_dense_*.hip / gemm_conv_*.hip / gemm_f32.hip / gemm_fp8.hip, entry points in gemm_api.hip)
 // MFMA GEMM for gfx950: y[M,N] = epilogue(A[M,K] * W[N,K]^T), used for
 //   * nn.Linear (rows L of SURVEY.md 8a)              - dense A loader
 //   * conv2d on NHWC as implicit GEMM (row R)         - gather A loader
-// bf16 runs on v_mfma_f32_16x16x32_bf16, fp32 ("strict" parity mode) on
+// bf16 / f16 run on v_mfma_f32_16x16x32_{bf16,f16}, fp32 ("strict" parity mode) on
 // v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain); both accumulate in fp32.
 //
 // Structure: block tile BM x BN, K step = one 128-byte row segment (64 bf16 /
@@ -200,6 +202,14 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Folded LayerNorm, y = rstd * (acc - mean * c) + d, as two explicit FMAs: every site that applies it (the three epilogue
+// forms, the fused query-projection epilogue) must round identically - left to the compiler, one site contracted the
+// multiply-adds and another did not, and st_ln_linear_xattn differed from st_ln_linear + st_attention in the last bit of a
+// few fp16 outputs (bf16's 8 bits hid it).
+__device__ __forceinline__ float ln_fold(float acc, float mean, float rstd, float c, float d) {
+    return __builtin_fmaf(rstd, __builtin_fmaf(-mean, c, acc), d);
+}
+
 // ---- shared epilogue ---------------------------------------------------------------------------
 // One output row m, 4 consecutive columns n..n+3: v = accumulators (value half), g = gate half (GEGLU).
 // epilogue_compute4 does every load and all the arithmetic and leaves the final values in v;
@@ -225,16 +235,16 @@ __device__ __forceinline__ void epilogue_compute4(const GemmArgs& p, int m, int 
             float c4[4], d4[4];
             Out4<float>::load(p.ln_c + n, c4); Out4<float>::load(p.ln_d + n, d4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ln_rstd * (v[e] - ln_mean * c4[e]) + d4[e];
+            for (int e = 0; e < 4; ++e) v[e] = ln_fold(v[e], ln_mean, ln_rstd, c4[e], d4[e]);
             if (GEGLU) {
                 Out4<float>::load(p.ln_c + p.N + n, c4); Out4<float>::load(p.ln_d + p.N + n, d4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = ln_rstd * (g[e] - ln_mean * c4[e]) + d4[e];
+                for (int e = 0; e < 4; ++e) g[e] = ln_fold(g[e], ln_mean, ln_rstd, c4[e], d4[e]);
             }
         } else {
             for (int e = 0; e < 4 && n + e < p.N; ++e) {
-                v[e] = ln_rstd * (v[e] - ln_mean * p.ln_c[n + e]) + p.ln_d[n + e];
-                if (GEGLU) g[e] = ln_rstd * (g[e] - ln_mean * p.ln_c[p.N + n + e]) + p.ln_d[p.N + n + e];
+                v[e] = ln_fold(v[e], ln_mean, ln_rstd, p.ln_c[n + e], p.ln_d[n + e]);
+                if (GEGLU) g[e] = ln_fold(g[e], ln_mean, ln_rstd, p.ln_c[p.N + n + e], p.ln_d[p.N + n + e]);
             }
         }
     }
@@ -405,8 +415,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                     if (has_ln) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            v[e] = rstd * (v[e] - mean * cv[j][e]) + dv[j][e];
-                            if (GEGLU) g[e] = rstd * (g[e] - mean * cg[j][e]) + dg[j][e];
+                            v[e] = ln_fold(v[e], mean, rstd, cv[j][e], dv[j][e]);
+                            if (GEGLU) g[e] = ln_fold(g[e], mean, rstd, cg[j][e], dg[j][e]);
                         }
                     }
                     if (has_bias) {
@@ -1188,7 +1198,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
                 const int row = wm * WTM + i * 16 + r16;
                 typename V16<T>::x4 o4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o4[e] = (T)(rstd[i] * (acc[i][j][e] - mean[i] * cv[e]) + dv[e]);
+                for (int e = 0; e < 4; ++e) o4[e] = (T)ln_fold(acc[i][j][e], mean[i], rstd[i], cv[e], dv[e]);
                 *reinterpret_cast<typename V16<T>::x4*>(qt + row * 64 + col) = o4;
             }
         }
