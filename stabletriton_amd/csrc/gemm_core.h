@@ -521,6 +521,249 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
     }
 }
 
+
+// =============================================================================
+// Staged epilogue (the LDS-DMA kernels, the 256 x 256 kernel, the halo conv).  After the K loop the LDS ring is free:
+// the block parks its fp32 accumulators there as a row-major tile, and every thread then owns ONE 16-byte output vector
+// (8 bf16 / f16 or 4 fp32 columns of one row) per pass:
+//   * stores, residual and row-bias loads are full 16-byte accesses, 128..512 contiguous bytes per row (the fragment
+//     layout gave 8 bytes per lane in 32-byte row segments);
+//   * per-column operands (bias, LayerNorm c / d, fp8 column scales) are loaded once per thread (its columns never change);
+//   * the loads of a chunk go out BEFORE the accumulators are parked, so their latency runs under the LDS staging;
+//   * a thread holds ~40 live registers instead of every epilogue operand of a whole wave tile (the 256-wide tiles and the
+//     halo conv spilled 38..116 VGPRs there);
+//   * GEGLU needs no value / gate pairing inside a wave any more: W rows are staged [values | gates] and the two halves of an
+//     accumulator row meet in LDS, so every tile shape can carry it.
+// Tiles that do not fit the ring at once go through it in row chunks (also bounding the loads in flight per thread).
+// Statistics for the consumers (LayerNorm row partials, GroupNorm column partials) are reduced through LDS in a fixed order:
+// bit-reproducible.  Arithmetic order per element is the one of epilogue_compute4.
+// =============================================================================
+template <typename TO> struct EpiVec;           // 16 bytes of outputs / residual / bias
+template <> struct EpiVec<bf16> { typedef bf16x8 type; static constexpr int N = 8; };
+template <> struct EpiVec<f16> { typedef f16x8 type; static constexpr int N = 8; };
+template <> struct EpiVec<float> { typedef f32x4 type; static constexpr int N = 4; };
+
+struct ColsPlain {              // accumulator n-tile j of wave column wn -> first tile column
+    int wn, wtn;
+    __device__ __forceinline__ int operator()(int j) const { return wn * wtn + j * 16; }
+};
+
+template <int BM, int BN, int NT, int VEC, bool GEGLU, int LDS_BYTES>
+struct EpiGeom {
+    static constexpr int BNO = GEGLU ? BN / 2 : BN;              // output columns of the tile
+    static_assert(BNO % VEC == 0, "tile width must be a whole number of 16-byte vectors");
+    static constexpr int VPR = BNO / VEC;                        // vectors (threads) per row
+    static constexpr int RPI = NT / VPR;                         // rows per pass of the block
+    static constexpr int LDW = BN + 4;                           // floats per staged row (+16 B: the 16 row lanes of a fragment hit different banks)
+    static constexpr int ROW_BYTES = LDW * 4 + VPR * 8;          // + one (sum, sum of squares) partial per vector (row statistics)
+    static constexpr int MAX_IT = 4;                             // passes per chunk (bounds the residual / row-bias vectors in flight)
+    static constexpr int ch0 = (LDS_BYTES / ROW_BYTES) / 16 * 16;
+    static constexpr int ch1 = ch0 < MAX_IT * RPI ? ch0 : (MAX_IT * RPI) / 16 * 16;
+    static constexpr int ch2 = ch1 < BM ? ch1 : BM;
+    static constexpr int NCH = (BM + ch2 - 1) / ch2;
+    static constexpr int CH = ((BM + NCH - 1) / NCH + 15) / 16 * 16;      // rows per chunk (balanced, multiple of 16)
+    static constexpr int IT = (CH + RPI - 1) / RPI;
+    static_assert(ch2 >= 16 && CH * ROW_BYTES <= LDS_BYTES, "staged epilogue: the ring cannot hold sixteen rows of the tile");
+    static_assert(RPI * BNO * 8 <= LDS_BYTES, "staged epilogue: column-statistics scratch");
+};
+
+template <typename TO, int BM, int BN, int WGM, int WGN, int TM, int TN, bool GEGLU, int LDS_BYTES, bool STATS, typename ColMap>
+__device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int tile_n, int wm, int r16, int q,
+                                                ColMap colmap, char* lds, const float2* lnrows) {
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int VEC = EpiVec<TO>::N;
+    typedef typename EpiVec<TO>::type OV;
+    typedef EpiGeom<BM, BN, NT, VEC, GEGLU, LDS_BYTES> G;
+    constexpr int BNO = G::BNO, VPR = G::VPR, RPI = G::RPI, LDW = G::LDW, CH = G::CH, NCH = G::NCH, IT = G::IT;
+    constexpr int WTM = BM / WGM;
+    const int t = threadIdx.x;
+    const bool worker = t < RPI * VPR;
+    const int rloc = t / VPR, v = t - rloc * VPR;
+    const int n = n0 + v * VEC;                                   // first output column of this thread
+    const bool has_bias = p.epi & ST_EPI_BIAS, has_res = p.epi & ST_EPI_RESIDUAL, has_rb = p.epi & ST_EPI_ROWBIAS;
+    const bool has_ln = p.ln_c != nullptr, do_silu = p.epi & ST_EPI_SILU, has_scale = p.col_scale != nullptr;
+    const bool col_full = n + VEC <= p.N;                         // all VEC columns exist
+    const bool col_any = worker && n < p.N;
+    const bool wide = col_full && (p.ldc % VEC == 0) && ((uintptr_t)p.C & 15) == 0;             // 16-byte stores
+    const bool wide_res = col_full && (p.ldr % VEC == 0) && ((uintptr_t)p.residual & 15) == 0;
+    const bool wide_rb = col_full && (p.N % VEC == 0) && ((uintptr_t)p.rowbias & 15) == 0;
+    float* tile = reinterpret_cast<float*>(lds);
+    float2* rstat = reinterpret_cast<float2*>(lds + (size_t)CH * LDW * 4);
+    const bool emit_rows = STATS && p.row_stats != nullptr, emit_cols = STATS && p.col_stats != nullptr && (p.N & 3) == 0;
+
+    // ---- per-column operands: once per thread ------------------------------------------------------
+    float bia[VEC], big[VEC], lc[VEC], ld[VEC], lcg[VEC], ldg[VEC], cs[VEC], csg[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { bia[e] = big[e] = 0.f; lc[e] = ld[e] = lcg[e] = ldg[e] = 0.f; cs[e] = csg[e] = 1.f; }
+    if (col_any) {
+        const TO* __restrict__ bias = (const TO*)p.bias;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int ne = (n + e < p.N) ? n + e : p.N - 1;       // clamped: every load unconditional
+            if (has_bias) { bia[e] = Elem<TO>::to_f(bias[ne]); if (GEGLU) big[e] = Elem<TO>::to_f(bias[p.N + ne]); }
+            if (has_ln) { lc[e] = p.ln_c[ne]; ld[e] = p.ln_d[ne]; if (GEGLU) { lcg[e] = p.ln_c[p.N + ne]; ldg[e] = p.ln_d[p.N + ne]; } }
+            if (has_scale) { cs[e] = p.col_scale[ne]; if (GEGLU) csg[e] = p.col_scale[p.N + ne]; }
+        }
+    }
+    float c1[VEC], c2[VEC];                                       // GroupNorm partials of this thread's columns over its rows
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { c1[e] = 0.f; c2[e] = 0.f; }
+    unsigned int touch_next = 0;
+
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the last fragment reads of the K loop have returned ...
+    __builtin_amdgcn_s_barrier();                                 // ... in every wave: the ring may be overwritten
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int row_lo = c * CH;                                // first tile row of this chunk
+        // -- loads of the chunk (16 bytes per row each), in flight while the accumulators are parked
+        OV res[IT], rbv[IT];
+        bool rok[IT];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int row = row_lo + rloc + k * RPI;
+            const int m = m0 + row;
+            rok[k] = col_any && (rloc + k * RPI < CH) && row < BM && m < p.M;
+            const int mc = rok[k] ? m : m0;                       // clamped
+            res[k] = OV{}; rbv[k] = OV{};
+            if (has_res) {
+                const TO* rr = (const TO*)p.residual + (size_t)mc * p.ldr + (col_any ? n : n0);
+                if (wide_res) res[k] = *reinterpret_cast<const OV*>(rr);
+                else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) res[k][e] = rr[(n + e < p.N) ? e : 0];
+                }
+            }
+            if (has_rb) {
+                const TO* rb = (const TO*)p.rowbias + (size_t)(mc / p.rows_per_batch) * p.N + (col_any ? n : n0);
+                if (wide_rb) rbv[k] = *reinterpret_cast<const OV*>(rb);
+                else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) rbv[k][e] = rb[(n + e < p.N) ? e : 0];
+                }
+            }
+        }
+        if (c == 0) touch_next_weights(p, touch_next);            // the next launch's weights: fire and forget until the exit
+        // -- park this chunk's accumulators (wave-uniform test: a 16-row accumulator tile lies in exactly one chunk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm * WTM + i * 16;
+            if (row >= row_lo && row < row_lo + CH) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    *reinterpret_cast<f32x4*>(tile + (size_t)(row - row_lo + r16) * LDW + colmap(j) + 4 * q) = acc[i][j];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // -- one 16-byte output vector per thread and pass
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int rl = rloc + k * RPI;                        // row inside the chunk
+            float val[VEC];
+            if (rok[k]) {
+                const int row = row_lo + rl, m = m0 + row;
+                const float* src = tile + (size_t)rl * LDW + v * VEC;
+                float g[VEC];
+#pragma unroll
+                for (int e4 = 0; e4 < VEC; e4 += 4) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(src + e4);
+                    val[e4] = a[0]; val[e4 + 1] = a[1]; val[e4 + 2] = a[2]; val[e4 + 3] = a[3];
+                    if (GEGLU) {
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(src + BNO + e4);
+                        g[e4] = b[0]; g[e4 + 1] = b[1]; g[e4 + 2] = b[2]; g[e4 + 3] = b[3];
+                    }
+                }
+                if (has_scale) {
+                    const float rs = p.row_scale[m];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { val[e] *= rs * cs[e]; if (GEGLU) g[e] *= rs * csg[e]; }
+                }
+                if (has_ln) {
+                    const float2 st = lnrows[row];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        val[e] = ln_fold(val[e], st.x, st.y, lc[e], ld[e]);
+                        if (GEGLU) g[e] = ln_fold(g[e], st.x, st.y, lcg[e], ldg[e]);
+                    }
+                }
+                if (has_bias) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { val[e] += bia[e]; if (GEGLU) g[e] += big[e]; }
+                }
+                if (GEGLU) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) val[e] *= gelu_for<TO>(g[e]);
+                }
+                if (do_silu) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) val[e] = silu_f(val[e]);
+                }
+                if (has_rb) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) val[e] += Elem<TO>::to_f(rbv[k][e]);
+                }
+                if (has_res) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) val[e] += Elem<TO>::to_f(res[k][e]);
+                }
+                OV out;
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    out[e] = Elem<TO>::from_f(val[e]);
+                    const float w = (n + e < p.N) ? Elem<TO>::to_f(out[e]) : 0.f;      // what is stored
+                    s1 += w; s2 = fmaf(w, w, s2);
+                    c1[e] += w; c2[e] = fmaf(w, w, c2[e]);
+                }
+                TO* dst = (TO*)p.C + (size_t)m * p.ldc + n;
+                if (wide) *reinterpret_cast<OV*>(dst) = out;
+                else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) if (n + e < p.N) dst[e] = out[e];
+                }
+                if (emit_rows) rstat[rl * VPR + v] = make_float2(s1, s2);
+            } else if (emit_rows && worker && rl < CH) {
+                rstat[rl * VPR + v] = make_float2(0.f, 0.f);
+            }
+        }
+        if (emit_rows) {
+            // LayerNorm partials of the rows just stored: one float2 per (row, N tile), the row's vectors added in order
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (int rl = t; rl < CH; rl += NT) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < VPR; ++w) { const float2 x = rstat[rl * VPR + w]; a1 += x.x; a2 += x.y; }
+                const int row = row_lo + rl;
+                if (row < BM && m0 + row < p.M)
+                    reinterpret_cast<float2*>(p.row_stats)[(size_t)(m0 + row) * p.stats_chunks + tile_n] = make_float2(a1, a2);
+            }
+        }
+        if (c + 1 < NCH || emit_cols) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this chunk's LDS reads are done before the next one is parked
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (emit_cols) {
+        // GroupNorm partials: per output column (sum, sum of squares) over the tile's rows - the RPI row slots through LDS,
+        // added in slot order
+        float2* cstat = reinterpret_cast<float2*>(lds);
+        if (worker) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) cstat[rloc * BNO + v * VEC + e] = make_float2(c1[e], c2[e]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int tile_m = m0 / BM;
+        for (int col = t; col < BNO; col += NT) {
+            float a1 = 0.f, a2 = 0.f;
+            for (int w = 0; w < RPI; ++w) { const float2 x = cstat[w * BNO + col]; a1 += x.x; a2 += x.y; }
+            if (n0 + col < p.N) reinterpret_cast<float2*>(p.col_stats)[(size_t)tile_m * p.N + n0 + col] = make_float2(a1, a2);
+        }
+    }
+    retire_touches(touch_next);
+}
+
 template <typename T, int BM, int BN, int WGM, int WGN, bool CONV, bool GEGLU>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     constexpr int NT = WGM * WGN * 64;
@@ -730,6 +973,50 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 
+// Row statistics of a LayerNorm-folded GEMM: the producer left per row one (sum, sum of squares) partial per N tile.
+// TPR adjacent threads share a row.  The order of the additions is CANONICAL - independent of TPR, i.e. of the tile
+// configuration the dispatch picked: eight strided partial sums (chunk c goes to class c mod 8, added in ascending c)
+// combined by the fixed tree ((0+1)+(2+3))+((4+5)+(6+7)).  A thread owns 8 / TPR classes; the tree's lower levels are a
+// butterfly over the TPR threads, its upper levels run inside the thread.  Without this the same x gave statistics that
+// differed in the last bit between a 64-row and a 128-row tile, and with them a few fp16 outputs.
+// load(): every load unconditional with clamped indices (one round trip, issued ahead of the prologue DMA).
+template <int TPR>
+struct LnRowSum {
+    static_assert(TPR == 1 || TPR == 2 || TPR == 4 || TPR == 8, "threads per row");
+    static constexpr int RES = 8 / TPR;          // classes per thread
+    static constexpr int PRE = 8 / RES;          // preloaded chunks per class (8 loads per thread in all)
+    float2 pre[RES][PRE];
+    __device__ __forceinline__ void load(const float2* row, int chunks, int part) {
+#pragma unroll
+        for (int j = 0; j < RES; ++j)
+#pragma unroll
+            for (int i = 0; i < PRE; ++i) {
+                const int c = part + TPR * j + 8 * i;
+                pre[j][i] = row[c < chunks ? c : 0];
+            }
+    }
+    __device__ __forceinline__ void finish(const float2* row, int chunks, int part, float& s1, float& s2) {
+        float a1[RES], a2[RES];
+#pragma unroll
+        for (int j = 0; j < RES; ++j) {
+            a1[j] = 0.f; a2[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < PRE; ++i) {
+                const bool ok = part + TPR * j + 8 * i < chunks;
+                a1[j] += ok ? pre[j][i].x : 0.f; a2[j] += ok ? pre[j][i].y : 0.f;
+            }
+            for (int c = part + TPR * j + 8 * PRE; c < chunks; c += 8) { const float2 v = row[c]; a1[j] += v.x; a2[j] += v.y; }
+#pragma unroll
+            for (int o = 1; o < TPR; o <<= 1) { a1[j] += __shfl_xor(a1[j], o, 64); a2[j] += __shfl_xor(a2[j], o, 64); }
+        }
+#pragma unroll
+        for (int w = 1; w < RES; w <<= 1)
+#pragma unroll
+            for (int j = 0; j + w < RES; j += 2 * w) { a1[j] += a1[j + w]; a2[j] += a2[j + w]; }
+        s1 = a1[0]; s2 = a2[0];
+    }
+};
+
 // In-launch split-K combine (cdna guide, projection GEMM item 2).  Every slice stores its fp32
 // accumulators as a slab in FRAGMENT order (a wave-instruction writes 1 KiB contiguous) with
 // write-through stores and draws a ticket; the block that draws the last ticket re-reads ALL slabs in
@@ -795,7 +1082,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     constexpr bool UNEVEN = (A_PIECES % NW != 0) || (B_PIECES % NW != 0);
     constexpr int G = (A_IT + B_IT) * U;                         // DMA instructions per wave per stage
     constexpr int A_BYTES = BM * 128, TILE = (BM + BN) * 128, STAGE = TILE * U;   // a stage = U consecutive K tiles
-    static_assert(!GEGLU || (TN % 2 == 0), "GEGLU pairs value/gate n-tiles inside one wave");
+    static_assert(!GEGLU || (BN % 32 == 0), "GEGLU: value and gate halves of the tile are whole 16-column accumulator tiles");
     static_assert((STAGES - 2) * G <= 63, "vmcnt immediate");
     typedef typename Mma<T>::Frag Frag;
     typedef typename OutT<T>::type TO;                          // element type of C, bias, residual (fp8 operands: bf16)
@@ -803,6 +1090,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const dump = lds + STAGES * STAGE + BM * 8;          // after the ring and the LayerNorm (mean, rstd) rows
 
+#ifdef ST_PROBE
+    unsigned long long pr_k0 = probe_now(), pr_rt0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pr_rt0)::"memory");
+#endif
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WGN, wn = wave - wm * WGN;
@@ -874,11 +1165,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         const int row = (wave + i * NW) * 8 + lr;
         int wrow;
         bool ok;
-        if (GEGLU) {
-            const int w_ = row / WTN, local = row - w_ * WTN;
-            const int half = local >= WTN / 2 ? 1 : 0;
-            const int ncol = n0 + w_ * (WTN / 2) + (local - half * (WTN / 2));
-            ok = ncol < p.N;
+        if (GEGLU) {                  // LDS rows [0, BN/2) = value rows of W, [BN/2, BN) = gate rows (N rows further down)
+            const int half = row >= BN / 2 ? 1 : 0;
+            const int ncol = n0 + row - half * (BN / 2);
+            ok = ncol < p.N && (!UNEVEN || wave + i * NW < B_PIECES);
             wrow = ncol + half * p.N;
         } else {
             wrow = n0 + row;
@@ -1025,39 +1315,28 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     // (row, producer N tile).  TPR adjacent threads share a row: each loads every TPR-th partial (all
     // loads unconditional with clamped indices, so they cost one round trip, issued ahead of the
     // prologue DMA), a fixed-order butterfly adds them, and (mean, rstd) wait in LDS for the epilogue.
-    constexpr int TPR = NW * 64 / BM;
-    constexpr int LN_UNROLL = 8;
-    float2 ln_part[LN_UNROLL];
+    constexpr int TPR = (NW * 64 / BM) >= 8 ? 8 : (NW * 64 / BM >= 1 ? NW * 64 / BM : 1);      // (threads beyond 8 per row idle here)
+    constexpr int TPR_SPAN = NW * 64 / BM >= 1 ? NW * 64 / BM : 1;                                 // threads that map to one row
+    LnRowSum<TPR> ln_sum;
     if constexpr (LNF) {
-        static_assert(TPR >= 1 && TPR <= 64 && (TPR & (TPR - 1)) == 0, "threads per row must be a power of two");
+        static_assert(NW * 64 % BM == 0 && (TPR_SPAN & (TPR_SPAN - 1)) == 0, "threads per row must be a power of two");
         const float2* st2 = reinterpret_cast<const float2*>(p.ln_stats);
-        const int row = t / TPR, part = t - row * TPR;
+        const int row = t / TPR_SPAN, part = (t - row * TPR_SPAN) & (TPR - 1);
         const int m = min(m0 + row, p.M - 1);
-#pragma unroll
-        for (int k_ = 0; k_ < LN_UNROLL; ++k_) {
-            const int c = part + k_ * TPR;
-            ln_part[k_] = st2[(size_t)m * p.ln_chunks + (c < p.ln_chunks ? c : 0)];
-        }
+        ln_sum.load(st2 + (size_t)m * p.ln_chunks, p.ln_chunks, part);
     }
 #pragma unroll
     for (int s_ = 0; s_ < STAGES - 1; ++s_)
         if (s_ < nk) { issue(s_, s_); if (CONV) conv_advance(s_ < nk - 1); }
     if constexpr (LNF) {
         const float2* st2 = reinterpret_cast<const float2*>(p.ln_stats);
-        const int row = t / TPR, part = t - row * TPR;
+        const int row = t / TPR_SPAN, sub = t - row * TPR_SPAN, part = sub & (TPR - 1);
         const int m = min(m0 + row, p.M - 1);
-        float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int k_ = 0; k_ < LN_UNROLL; ++k_) {
-            const bool ok = part + k_ * TPR < p.ln_chunks;
-            a1 += ok ? ln_part[k_].x : 0.f; a2 += ok ? ln_part[k_].y : 0.f;
-        }
-        for (int c = part + LN_UNROLL * TPR; c < p.ln_chunks; c += TPR) { const float2 v = st2[(size_t)m * p.ln_chunks + c]; a1 += v.x; a2 += v.y; }
-#pragma unroll
-        for (int o = 1; o < TPR; o <<= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+        float a1, a2;
+        ln_sum.finish(st2 + (size_t)m * p.ln_chunks, p.ln_chunks, part, a1, a2);
         const float mean = a1 / (float)p.K;
         const float rstd = rsqrtf(fmaxf(a2 / (float)p.K - mean * mean, 0.f) + p.ln_eps);
-        if (part == 0) reinterpret_cast<float2*>(lds + STAGES * STAGE)[row] = make_float2(mean, rstd);
+        if (sub == 0) reinterpret_cast<float2*>(lds + STAGES * STAGE)[row] = make_float2(mean, rstd);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // written before the raw barrier below
     }
     if (nk >= STAGES - 1) wait_vmcnt<(STAGES - 2) * G>(); else wait_vmcnt<0>();
@@ -1211,30 +1490,20 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         unsigned int sink = 0;
         touch_next_weights(p, sink);
         retire_touches(sink);
-    } else if constexpr (LNF) {
-        float mean[TM], rstd[TM];
-        const float2* lnst = reinterpret_cast<const float2*>(lds + STAGES * STAGE);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const float2 v = lnst[wm * WTM + i * 16 + r16];
-            mean[i] = v.x; rstd[i] = v.y;
-        }
-        gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wm, wn, r16, q, split, mean, rstd);
     } else {
-#ifdef ST_PROBE
-        unsigned long long ept[2] = {0, 0};
-        gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n, ept);
-        pr_x = ept[0] - pr_end; pr_d = ept[1] - ept[0];
-#else
-        gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n);
-#endif
+        // (the LayerNorm (mean, rstd) rows sit behind the ring, which the staged tile takes over)
+        staged_epilogue<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, STAGES * STAGE, !LNF>(
+            p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds, reinterpret_cast<const float2*>(lds + STAGES * STAGE));
     }
 #ifdef ST_PROBE
     {
         PROBE_STAMP(pr_fin)
         if (p.probe && lane == 0) {
-            unsigned long long* o = p.probe + ((size_t)blockIdx.x * NW + wave) * 8;
+            unsigned long long pr_rt1;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pr_rt1)::"memory");
+            unsigned long long* o = p.probe + ((size_t)blockIdx.x * NW + wave) * 12;
             o[0] = pr_a; o[1] = pr_b; o[2] = pr_c; o[3] = pr_end - pr_start; o[4] = pr_fin - pr_end; o[5] = pr_x; o[6] = pr_d; o[7] = nk;
+            o[8] = pr_start - pr_k0; o[9] = pr_rt0; o[10] = pr_rt1; o[11] = 0;      // prologue cycles; 100 MHz wall clock at entry / exit
         }
     }
 #endif
@@ -1353,30 +1622,19 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
         }
     }
     // LayerNorm-folded GEMM: row statistics from the producer's partials (two threads per row)
-    constexpr int LN_UNROLL = 8;
-    float2 ln_part[LN_UNROLL];
+    LnRowSum<2> ln_sum;
     if constexpr (LNF) {
         const float2* st2 = reinterpret_cast<const float2*>(p.ln_stats);
         const int row = t >> 1, part = t & 1;
-#pragma unroll
-        for (int k_ = 0; k_ < LN_UNROLL; ++k_) {
-            const int c = part + k_ * 2;
-            ln_part[k_] = st2[(size_t)(m0 + row) * p.ln_chunks + (c < p.ln_chunks ? c : 0)];
-        }
+        ln_sum.load(st2 + (size_t)(m0 + row) * p.ln_chunks, p.ln_chunks, part);
     }
     // prologue: K tile 0 whole and A0, B0 of K tile 1 (the loop issues B1(1), A1(1), A0(2), B0(2), B1(2), ...)
     issue_half(0, 0); issue_half(0, 2); issue_half(0, 3); issue_half(0, 1); issue_half(1, 0); issue_half(1, 2);
     if constexpr (LNF) {
         const float2* st2 = reinterpret_cast<const float2*>(p.ln_stats);
         const int row = t >> 1, part = t & 1;
-        float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int k_ = 0; k_ < LN_UNROLL; ++k_) {
-            const bool ok = part + k_ * 2 < p.ln_chunks;
-            a1 += ok ? ln_part[k_].x : 0.f; a2 += ok ? ln_part[k_].y : 0.f;
-        }
-        for (int c = part + LN_UNROLL * 2; c < p.ln_chunks; c += 2) { const float2 v = st2[(size_t)(m0 + row) * p.ln_chunks + c]; a1 += v.x; a2 += v.y; }
-        a1 += __shfl_xor(a1, 1, 64); a2 += __shfl_xor(a2, 1, 64);
+        float a1, a2;
+        ln_sum.finish(st2 + (size_t)(m0 + row) * p.ln_chunks, p.ln_chunks, part, a1, a2);
         const float mean = a1 / (float)p.K;
         const float rstd = rsqrtf(fmaxf(a2 / (float)p.K - mean * mean, 0.f) + p.ln_eps);
         if (part == 0) reinterpret_cast<float2*>(lnrows)[row] = make_float2(mean, rstd);
@@ -1471,18 +1729,17 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     if (wm == 0) __builtin_amdgcn_s_barrier();       // barrier counts of the two wave rows are equal again
     wait_vmcnt<0>();                                  // no LDS-DMA may outlive the workgroup's LDS allocation
     __builtin_amdgcn_s_barrier();
-    if constexpr (LNF) {
-        float mean[TM], rstd[TM];
-        const float2* lnst = reinterpret_cast<const float2*>(lnrows);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const float2 v = lnst[wm * WTM + i * 16 + r16];
-            mean[i] = v.x; rstd[i] = v.y;
+    // accumulator n-tile j = 2 * nh + j' of wave column wn: B half nh holds the value / gate rows (GEGLU) or columns
+    // 32 nh .. 32 nh + 31 of the wave's 64 (plain)
+    struct Cols8p {
+        int wn;
+        __device__ __forceinline__ int operator()(int j) const {
+            const int nh = j >> 1, jj = j & 1;
+            return GEGLU ? nh * 128 + wn * 32 + jj * 16 : wn * 64 + nh * 32 + jj * 16;
         }
-        gemm_epilogue<T, TM, TN, WTM, WTN, GEGLU, 0, 0, true>(p, acc, m0, n0, wm, wn, r16, q, 0, mean, rstd);
-    } else {
-        gemm_epilogue<T, TM, TN, WTM, WTN, GEGLU, WGM, WGN, true>(p, acc, m0, n0, wm, wn, r16, q, 0, nullptr, nullptr, lds, tile_n);
-    }
+    };
+    staged_epilogue<T, BM, BN, WGM, WGN, TM, TN, GEGLU, 2 * TILE_B, !LNF>(p, acc, m0, n0, tile_n, wm, r16, q, Cols8p{wn}, lds,
+                                                                        reinterpret_cast<const float2*>(lnrows));
 }
 
 static inline bool gemm8p_applies(const GemmArgs& a) {
@@ -1719,7 +1976,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
             return;
         }
     }
-    gemm_epilogue<T, TM, TN, WTM, WTN, false, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n);
+    staged_epilogue<T, BM, BN, WGM, WGN, TM, TN, false, 2 * PB + STAGES * WT_B, true>(p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds,
+                                                                                      nullptr);
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, bool CONV>
@@ -1783,7 +2041,7 @@ template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int U, bool 
 static void launch_dma(const GemmArgs& a, hipStream_t st) {
     if constexpr (!CONV) {
         const bool geglu = a.epi & ST_EPI_GEGLU;
-        constexpr bool PAIRS = ((BN / WGN / 16) % 2 == 0);      // GEGLU pairs value/gate n-tiles inside a wave
+        constexpr bool PAIRS = (BN % 32 == 0);                  // GEGLU: value and gate halves of the tile are whole accumulator tiles
         if constexpr (sizeof(T) != 1)
         if (a.ln_c) {          // LayerNorm-folded variants (never split over K: the row statistics need all of K)
             if constexpr (PAIRS) {
@@ -1803,13 +2061,13 @@ static void launch_dma(const GemmArgs& a, hipStream_t st) {
 // overrides the heuristic for A/B runs.
 enum { CFG_64x64_S4 = 0, CFG_64x64_S8 = 1, CFG_64x64_S4_U2 = 2, CFG_128x64_S4 = 3, CFG_128x64_S3_U2 = 4,
        CFG_128x128_S3 = 5, CFG_64x64_S3 = 6, CFG_64x64_W8 = 7, CFG_128x64_W8 = 8, CFG_128x128_W8 = 9,
-       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_128x320_W8 = 23, CFG_128x256_W8 = 24, CFG_64x320_W8 = 25, CFG_64x80_W4 = 26, CFG_128x80_W8 = 27, CFG_128x160_W8 = 28, CFG_COUNT, CFG_256x256_8P = 100 };
+       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_128x320_W8 = 23, CFG_128x256_W8 = 24, CFG_64x320_W8 = 25, CFG_64x80_W4 = 26, CFG_128x80_W8 = 27, CFG_128x160_W8 = 28, CFG_128x128_N4_S2 = 29, CFG_128x64_N4_S3 = 30, CFG_64x128_N4_S3 = 31, CFG_COUNT, CFG_256x256_8P = 100 };
 
 static inline int cfg_bn(int cfg) {
     switch (cfg) {
         case CFG_64x64_S4: case CFG_64x64_S8: case CFG_64x64_S4_U2: case CFG_128x64_S4: case CFG_128x64_S3_U2: case CFG_64x64_S3:
         case CFG_64x64_W8: case CFG_128x64_W8: case CFG_128x64_W8_S6: case CFG_64x64_W8_S8: case CFG_128x64_W8_U2:
-        case CFG_64x64_W8_U2: case CFG_128x64_W8_S3: return 64;
+        case CFG_64x64_W8_U2: case CFG_128x64_W8_S3: case CFG_128x64_N4_S3: return 64;
         case CFG_256x256_W8: case CFG_128x256_W8: return 256;
         case CFG_128x320_W8: case CFG_64x320_W8: return 320;
         case CFG_64x80_W4: case CFG_128x80_W8: return 80;
@@ -1873,7 +2131,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
         int cfg = CFG_64x64_W8, sk = 1;
         double best = 1e30;
         for (const Cand& c : cands) {
-            if ((a.epi & ST_EPI_GEGLU) && (c.cfg == CFG_64x320_W8 || c.bn == 80 || c.bn == 160)) continue;      // odd n-tiles per wave: no value/gate pairing
+            if ((a.epi & ST_EPI_GEGLU) && c.bn % 32 != 0) continue;      // GEGLU: the value / gate halves of a tile are whole accumulator tiles (BN = 80 is not)
             const long nt = tiles(c.bm, c.bn);
             const double trip = c.trip_us * (CONV ? 1.6 : 1.0);
             for (int k_ : sks) {
@@ -1950,6 +2208,10 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             case CFG_128x64_S3_U2: launch_dma<T, 128, 64, 2, 2, 3, 2, CONV>(b, st); break;
             case CFG_128x128_S3: launch_dma<T, 128, 128, 2, 2, 3, 1, CONV>(b, st); break;
             case CFG_64x64_S3: launch_dma<T, 64, 64, 2, 2, 3, 1, CONV>(b, st); break;
+            // four-wave blocks whose LDS ring lets TWO blocks share a CU (one block's prologue / epilogue beside the other's K loop)
+            case CFG_128x128_N4_S2: launch_dma<T, 128, 128, 2, 2, 2, 1, CONV>(b, st); break;
+            case CFG_128x64_N4_S3: launch_dma<T, 128, 64, 2, 2, 3, 1, CONV>(b, st); break;
+            case CFG_64x128_N4_S3: launch_dma<T, 64, 128, 2, 2, 3, 1, CONV>(b, st); break;
             case CFG_64x128_W8_S6: launch_dma<T, 64, 128, 2, 4, 6, 1, CONV>(b, st); break;
             case CFG_128x64_W8_S6: launch_dma<T, 128, 64, 4, 2, 6, 1, CONV>(b, st); break;
             case CFG_128x128_W8_S4: launch_dma<T, 128, 128, 2, 4, 3, 1, CONV>(b, st); break;       // (now the three-stage variant)

@@ -1,18 +1,23 @@
 #!/bin/bash
-# Developer helper: rebuild ONE source with extra -D flags and link it with the product objects of the other sources.
-# usage: tools/build_one_variant.sh <name> <source.hip> [-DFLAG ...]   -> tools/_variants/<name>/libstabletriton_amd.so
+# Developer helper: rebuild SOME sources with extra -D flags and link them with the variant's own earlier objects (or,
+# where it has none, the product objects of the other sources).
+# usage: tools/build_one_variant.sh <name> <source.hip>... [-DFLAG ...]   -> tools/_variants/<name>/libstabletriton_amd.so
 set -e
-name=$1; src=$2; shift 2
+name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/tools/_variants/$name
-mkdir -p "$out"
-base=$(basename "${src%.hip}")
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form "$@" -c "$root/stabletriton_amd/csrc/$base.hip" -o "$out/$base.o"
-objs=("$out/$base.o")
+mkdir -p "$out/obj"
+srcs=(); flags=()
+for a in "$@"; do case "$a" in *.hip) srcs+=("$a");; *) flags+=("$a");; esac; done
+for src in "${srcs[@]}"; do
+  base=$(basename "${src%.hip}")
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form "${flags[@]}" -c "$root/stabletriton_amd/csrc/$base.hip" -o "$out/obj/$base.o" &
+done
+wait
+objs=()
 for f in "$root"/stabletriton_amd/csrc/*.hip; do
   b=$(basename "${f%.hip}")
-  [ "$b" = "$base" ] || objs+=("$root/stabletriton_amd/lib/obj/$b.o")
+  if [ -f "$out/obj/$b.o" ]; then objs+=("$out/obj/$b.o"); else objs+=("$root/stabletriton_amd/lib/obj/$b.o"); fi
 done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -fno-gpu-rdc "${objs[@]}" -o "$out/libstabletriton_amd.so"
-rm -f "$out/$base.o"
 echo "$out/libstabletriton_amd.so"

@@ -5,14 +5,13 @@ set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/tools/_variants/$name
-mkdir -p "$out"
+mkdir -p "$out/obj"
 objs=()
 for f in "$root"/stabletriton_amd/csrc/*.hip; do
-  o=$out/$(basename "${f%.hip}").o
+  o=$out/obj/$(basename "${f%.hip}").o
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form "$@" -c "$f" -o "$o" &
   objs+=("$o")
 done
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -fno-gpu-rdc "${objs[@]}" -o "$out/libstabletriton_amd.so"
-rm -f "${objs[@]}"
 echo "$out/libstabletriton_amd.so"
