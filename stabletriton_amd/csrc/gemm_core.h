@@ -569,7 +569,8 @@ struct EpiGeom {
 
 template <typename TO, int BM, int BN, int WGM, int WGN, int TM, int TN, bool GEGLU, int LDS_BYTES, bool STATS, typename ColMap>
 __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int tile_n, int wm, int r16, int q,
-                                                ColMap colmap, char* lds, const float2* lnrows) {
+                                                ColMap colmap, char* lds, const float2* lnrows, unsigned long long* ptimes = nullptr) {
+    (void)ptimes;
     constexpr int NT = WGM * WGN * 64;
     constexpr int VEC = EpiVec<TO>::N;
     typedef typename EpiVec<TO>::type OV;
@@ -592,17 +593,39 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
     const bool emit_rows = STATS && p.row_stats != nullptr, emit_cols = STATS && p.col_stats != nullptr && (p.N & 3) == 0;
 
     // ---- per-column operands: once per thread ------------------------------------------------------
-    float bia[VEC], big[VEC], lc[VEC], ld[VEC], lcg[VEC], ldg[VEC], cs[VEC], csg[VEC];
+    // (kept as loaded - raw vectors - and converted where they are used: a conversion placed here would make the compiler
+    //  wait for the loads in front of the first barrier instead of letting them fly under the staging)
+    OV bia = OV{}, big = OV{};
+    float lc[VEC], ld[VEC], lcg[VEC], ldg[VEC], cs[VEC], csg[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { bia[e] = big[e] = 0.f; lc[e] = ld[e] = lcg[e] = ldg[e] = 0.f; cs[e] = csg[e] = 1.f; }
+    for (int e = 0; e < VEC; ++e) { lc[e] = ld[e] = lcg[e] = ldg[e] = 0.f; cs[e] = csg[e] = 1.f; }
     if (col_any) {
         const TO* __restrict__ bias = (const TO*)p.bias;
+        // whole vectors whenever the columns exist and the arrays keep 16-byte alignment (N % VEC == 0 covers the gate half too)
+        const bool vec_cols = col_full && (p.N % VEC == 0) && (!has_bias || ((uintptr_t)bias & 15) == 0) &&
+                              (!has_ln || (((uintptr_t)p.ln_c | (uintptr_t)p.ln_d) & 15) == 0) && (!has_scale || ((uintptr_t)p.col_scale & 15) == 0);
+        auto ldf = [&](const float* a, float (&dst)[VEC]) {       // VEC floats
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const int ne = (n + e < p.N) ? n + e : p.N - 1;       // clamped: every load unconditional
-            if (has_bias) { bia[e] = Elem<TO>::to_f(bias[ne]); if (GEGLU) big[e] = Elem<TO>::to_f(bias[p.N + ne]); }
-            if (has_ln) { lc[e] = p.ln_c[ne]; ld[e] = p.ln_d[ne]; if (GEGLU) { lcg[e] = p.ln_c[p.N + ne]; ldg[e] = p.ln_d[p.N + ne]; } }
-            if (has_scale) { cs[e] = p.col_scale[ne]; if (GEGLU) csg[e] = p.col_scale[p.N + ne]; }
+            for (int e4 = 0; e4 < VEC; e4 += 4) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(a + e4);
+                dst[e4] = x[0]; dst[e4 + 1] = x[1]; dst[e4 + 2] = x[2]; dst[e4 + 3] = x[3];
+            }
+        };
+        if (vec_cols) {
+            if (has_bias) {
+                bia = *reinterpret_cast<const OV*>(bias + n);
+                if (GEGLU) big = *reinterpret_cast<const OV*>(bias + p.N + n);
+            }
+            if (has_ln) { ldf(p.ln_c + n, lc); ldf(p.ln_d + n, ld); if (GEGLU) { ldf(p.ln_c + p.N + n, lcg); ldf(p.ln_d + p.N + n, ldg); } }
+            if (has_scale) { ldf(p.col_scale + n, cs); if (GEGLU) ldf(p.col_scale + p.N + n, csg); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int ne = (n + e < p.N) ? n + e : p.N - 1;       // clamped: every load unconditional
+                if (has_bias) { bia[e] = bias[ne]; if (GEGLU) big[e] = bias[p.N + ne]; }
+                if (has_ln) { lc[e] = p.ln_c[ne]; ld[e] = p.ln_d[ne]; if (GEGLU) { lcg[e] = p.ln_c[p.N + ne]; ldg[e] = p.ln_d[p.N + ne]; } }
+                if (has_scale) { cs[e] = p.col_scale[ne]; if (GEGLU) csg[e] = p.col_scale[p.N + ne]; }
+            }
         }
     }
     float c1[VEC], c2[VEC];                                       // GroupNorm partials of this thread's columns over its rows
@@ -655,6 +678,9 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#ifdef ST_PROBE
+        if (ptimes && c == 0) ptimes[0] = probe_now();
+#endif
         // -- one 16-byte output vector per thread and pass
 #pragma unroll
         for (int k = 0; k < IT; ++k) {
@@ -688,7 +714,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
                 }
                 if (has_bias) {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) { val[e] += bia[e]; if (GEGLU) g[e] += big[e]; }
+                    for (int e = 0; e < VEC; ++e) { val[e] += Elem<TO>::to_f(bia[e]); if (GEGLU) g[e] += Elem<TO>::to_f(big[e]); }
                 }
                 if (GEGLU) {
 #pragma unroll
@@ -762,6 +788,9 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
         }
     }
     retire_touches(touch_next);
+#ifdef ST_PROBE
+    if (ptimes) ptimes[1] = probe_now();
+#endif
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, bool CONV, bool GEGLU>
@@ -1492,8 +1521,16 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         retire_touches(sink);
     } else {
         // (the LayerNorm (mean, rstd) rows sit behind the ring, which the staged tile takes over)
+#ifdef ST_PROBE
+        unsigned long long ept[2] = {0, 0};
+#else
+        unsigned long long* const ept = nullptr;
+#endif
         staged_epilogue<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, STAGES * STAGE, !LNF>(
-            p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds, reinterpret_cast<const float2*>(lds + STAGES * STAGE));
+            p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds, reinterpret_cast<const float2*>(lds + STAGES * STAGE), ept);
+#ifdef ST_PROBE
+        pr_x = ept[0] - pr_end; pr_d = ept[1] - ept[0];
+#endif
     }
 #ifdef ST_PROBE
     {
@@ -2061,7 +2098,7 @@ static void launch_dma(const GemmArgs& a, hipStream_t st) {
 // overrides the heuristic for A/B runs.
 enum { CFG_64x64_S4 = 0, CFG_64x64_S8 = 1, CFG_64x64_S4_U2 = 2, CFG_128x64_S4 = 3, CFG_128x64_S3_U2 = 4,
        CFG_128x128_S3 = 5, CFG_64x64_S3 = 6, CFG_64x64_W8 = 7, CFG_128x64_W8 = 8, CFG_128x128_W8 = 9,
-       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_128x320_W8 = 23, CFG_128x256_W8 = 24, CFG_64x320_W8 = 25, CFG_64x80_W4 = 26, CFG_128x80_W8 = 27, CFG_128x160_W8 = 28, CFG_128x128_N4_S2 = 29, CFG_128x64_N4_S3 = 30, CFG_64x128_N4_S3 = 31, CFG_COUNT, CFG_256x256_8P = 100 };
+       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_128x320_W8 = 23, CFG_128x256_W8 = 24, CFG_64x320_W8 = 25, CFG_64x80_W4 = 26, CFG_128x80_W8 = 27, CFG_128x160_W8 = 28, CFG_128x128_N4_S2 = 29, CFG_128x64_N4_S3 = 30, CFG_64x128_N4_S3 = 31, CFG_256x160_W8_S2 = 32, CFG_COUNT, CFG_256x256_8P = 100 };
 
 static inline int cfg_bn(int cfg) {
     switch (cfg) {
@@ -2071,7 +2108,7 @@ static inline int cfg_bn(int cfg) {
         case CFG_256x256_W8: case CFG_128x256_W8: return 256;
         case CFG_128x320_W8: case CFG_64x320_W8: return 320;
         case CFG_64x80_W4: case CFG_128x80_W8: return 80;
-        case CFG_128x160_W8: return 160;
+        case CFG_128x160_W8: case CFG_256x160_W8_S2: return 160;
         default: return 128;
     }
 }
@@ -2179,7 +2216,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
         if (sk > 1) {
             int bm = 128;
             if (cfg == CFG_64x64_W8 || cfg == CFG_64x128_W8 || cfg == CFG_64x320_W8 || cfg == CFG_64x80_W4) bm = 64;
-            if (cfg == CFG_256x128_W8) bm = 256;
+            if (cfg == CFG_256x128_W8 || cfg == CFG_256x160_W8_S2) bm = 256;
             const long nt = tiles(bm, cfg_bn(cfg));
             if (nt <= 16384 && (size_t)sk * nt * bm * cfg_bn(cfg) * 4 + 65536 <= a.partial_bytes) {
                 // workspace layout: 16384 arrival counters (zero between launches), then the fp32 slabs
@@ -2212,6 +2249,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             case CFG_128x128_N4_S2: launch_dma<T, 128, 128, 2, 2, 2, 1, CONV>(b, st); break;
             case CFG_128x64_N4_S3: launch_dma<T, 128, 64, 2, 2, 3, 1, CONV>(b, st); break;
             case CFG_64x128_N4_S3: launch_dma<T, 64, 128, 2, 2, 3, 1, CONV>(b, st); break;
+            case CFG_256x160_W8_S2: launch_dma<T, 256, 160, 4, 2, 2, 1, CONV>(b, st); break;
             case CFG_64x128_W8_S6: launch_dma<T, 64, 128, 2, 4, 6, 1, CONV>(b, st); break;
             case CFG_128x64_W8_S6: launch_dma<T, 128, 64, 4, 2, 6, 1, CONV>(b, st); break;
             case CFG_128x128_W8_S4: launch_dma<T, 128, 128, 2, 4, 3, 1, CONV>(b, st); break;       // (now the three-stage variant)

@@ -31,5 +31,5 @@ for cfg in [int(c) for c in sys.argv[4:]] or [-1]:
     e1.record(); torch.cuda.synchronize()
     print(f"M={M} K={K} N={N} cfg={cfg}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us eager; waves={len(used)} trips={int(nk)} per-trip cycles: work={used[:,0].mean()/nk:.0f} vmwait={used[:,1].mean()/nk:.0f} "
           f"barrier={used[:,2].mean()/nk:.0f} | prologue={used[:,8].mean():.0f} loop={used[:,3].mean():.0f} (max {used[:,3].max():.0f}) epilogue={used[:,4].mean():.0f} "
-          f"(loads+math {used[:,5].mean():.0f}, stores {used[:,6].mean():.0f}) | wall (100 MHz ticks -> us): first entry -> last entry {(used[:,9].max()-used[:,9].min())/100:.2f}, "
+          f"(loads+park+barrier {used[:,5].mean():.0f}, vectors+stores {used[:,6].mean():.0f}) | wall (100 MHz ticks -> us): first entry -> last entry {(used[:,9].max()-used[:,9].min())/100:.2f}, "
           f"first entry -> last exit {(used[:,10].max()-used[:,9].min())/100:.2f}, mean block life {(used[:,10]-used[:,9]).mean()/100:.2f}")
