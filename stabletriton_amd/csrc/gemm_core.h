@@ -1547,40 +1547,46 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
 }
 
 // =============================================================================
-// gemm8p: 256 x 256 x 64 tiles for the large Linear problems (the projections at batch >= 2, the GEGLU
-// projection at any batch).  A 128 x 128 tile needs (128+128)*128 B of LDS fill per 0.21 us of MFMA work
-// - more than the ~130 GB/s one CU pulls from its L2 - a 256 x 256 tile half of that.
-//   * 8 waves = 2 (rows) x 4 (columns), wave tile 128 x 64 = four quadrants of 64 x 32; a K tile is four
-//     phases, one quadrant (16 MFMAs 16x16x32) each: (A0,B0) (A0,B1) (A1,B1) (A1,B0) with Ah / Bh the
-//     64-row / 32-column halves of the wave tile.  A phase reads only the fragments it is the first to
-//     use (A0+B0, B1, A1, nothing), so a K tile costs 24 ds_read_b128 per wave for 64 MFMAs.
-//   * The two wave rows run half a phase apart (waves 4-7 pass one extra barrier first): while one row's
-//     waves multiply, the other row's waves read fragments and issue DMAs, on the same SIMDs - a software
-//     ping-pong with two raw barriers per phase and no wave ever doing both at once.
-//   * LDS: two K tiles, each as four 16-KiB half tiles (A0, A1, B0, B1: the rows all eight waves read in
-//     the same phase), filled by LDS-DMA one half tile per phase (two 1-KiB pieces per wave), swizzled on
-//     the source side as in gemm_dma_kernel.  A half tile is refilled two phases after its last read and
-//     waited for (counted vmcnt, never 0) one phase before its first read, which leaves four half tiles
-//     (64 KiB per CU) in flight at all times.
-// Epilogue, LayerNorm folding, row statistics, next-weights touches and the XCD-aware tile order are the
-// ones of gemm_dma_kernel.  No K split (the shapes that come here have >= 160 tiles).
+// gemm8p: 256-row tiles for the large Linear problems (the projections at batch >= 2, the GEGLU projection at any
+// batch).  A 128 x 128 tile needs (128+128)*128 B of LDS fill per 0.21 us of MFMA work - more than the ~130 GB/s one
+// CU pulls from its L2 - a 256-row tile about half of that.  Two shapes of the same kernel:
+//     256 x 256: 8 waves = 2 (rows) x 4 (columns), wave tile 128 x 64;
+//     256 x 160: 8 waves = 4 x 2, wave tile 64 x 80 - SDXL's widths are 5 * 2^k: 1024 x 10240 (the GEGLU projection at
+//                batch 1) is 160 tiles of 256 x 256 but 256 of 256 x 160, one per CU.
+//   * A K tile is four phases, one quadrant of the wave tile each: (A0,B0) (A0,B1) (A1,B1) (A1,B0), Ah = the two halves of
+//     the wave's rows, B0 / B1 = its first ceil(TN/2) / last floor(TN/2) accumulator columns.  A phase reads only the
+//     fragments it is the first to use (A0+B0, B1, A1, nothing).
+//   * The two halves of the block's waves run half a phase apart (waves 4-7 pass one extra barrier first): while one
+//     half multiplies, the other reads fragments and issues DMAs, on the same SIMDs - a software ping-pong with two raw
+//     barriers per phase and no wave ever doing both at once.
+//   * LDS: two K tiles, each as four regions (A0, A1, B0, B1: the rows all eight waves read in the same phase), filled by
+//     LDS-DMA one region per phase (two 1-KiB pieces per wave; a region with fewer than sixteen pieces fills up with dummy
+//     pieces so that every wave counts the same vmcnt), swizzled on the source side as in gemm_dma_kernel.  A region is
+//     refilled two phases after its last read and waited for (counted vmcnt, never 0) one phase before its first read,
+//     which leaves four regions in flight at all times.
+// Staged epilogue (GEGLU: tile columns [values | gates]), LayerNorm folding, statistics, next-weights touches and the
+// XCD-aware tile order are the ones of gemm_dma_kernel.  No K split.
 // =============================================================================
-template <typename T, bool GEGLU, bool LNF>
+template <typename T, bool GEGLU, bool LNF, int BN = 256, int WGM = 2, int WGN = 4>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     static_assert(sizeof(T) == 2, "16-bit elements (bf16 / f16)");
-    constexpr int BM = 256, BN = 256, KB = 64, WGM = 2, WGN = 4, NW = 8;
-    constexpr int WTM = 128, WTN = 64, TM = 8, TN = 4;
-    constexpr int HALF_B = 128 * 128;                 // bytes of one half tile (128 rows x 128 B)
-    constexpr int TILE_B = 4 * HALF_B;                // A0 A1 B0 B1
+    constexpr int BM = 256, KB = 64, NW = 8;
+    static_assert(WGM * WGN == NW && BM % (32 * WGM) == 0 && BN % (16 * WGN) == 0 && (!GEGLU || BN % 32 == 0), "wave layout");
+    constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 16, TN = WTN / 16;
+    constexpr int TMH = TM / 2, TN0 = (TN + 1) / 2, TN1 = TN - TN0;          // accumulator tiles per A half / in B0 / in B1
+    constexpr int RA = WGM * TMH * 16, RB0 = WGN * TN0 * 16, RB1 = WGN * TN1 * 16;      // rows of the regions
+    static_assert(RA == 128 && RB0 <= 128 && RB1 <= 128 && RB0 % 8 == 0 && RB1 % 8 == 0, "a region is at most sixteen 8-row pieces");
+    constexpr int HA = RA * 128, HB0 = RB0 * 128, HB1 = RB1 * 128;            // bytes
+    constexpr int TILE_B = 2 * HA + HB0 + HB1;                                // A0 A1 B0 B1
     constexpr int BNO = GEGLU ? BN / 2 : BN;
     typedef typename Mma<T>::Frag Frag;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const lnrows = lds + 2 * TILE_B;            // LayerNorm (mean, rstd) per row
-    char* const dump = lnrows + BM * 8;               // target of the dummy DMAs past the last K tile
+    char* const dump = lnrows + BM * 8;               // target of the dummy DMAs
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WGN, wn = wave - wm * WGN;
     const int tiles_m = p.M / BM;
     const int nblk = gridDim.x - p.helper_blocks, bid = blockIdx.x;
     if (bid >= nblk) {                               // helper block on an otherwise idle CU: the next launch's weights
@@ -1605,28 +1611,36 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     const T* __restrict__ Wp = (const T*)p.W;
     const T* zeros = reinterpret_cast<const T*>(g_zero16);
 
-    // ---- per-lane DMA sources: piece e (0, 1) of this wave inside a half tile covers rows idx = (2*wave+e)*8 + lr
+    // ---- per-lane DMA sources: piece e (0, 1) of this wave inside a region covers region rows idx = (2*wave+e)*8 + lr.
+    //      A region row idx = wave row (idx / (TMH*16)), row inside that wave's half (idx % (TMH*16)); B likewise with the
+    //      wave column.  Tile column c -> row of W: c (plain), or value row c / gate row N + c - BN/2 (GEGLU).
     const int lr = lane >> 3;
     const int lc = (lane & 7) ^ lr;                  // logical 16-byte chunk this lane fetches (source-side swizzle)
     const T* a_src[2];
-    const T* b_src[2];
+    const T* b0_src[2];
+    const T* b1_src[2];
+    auto w_row = [&](int c) { return GEGLU ? (c < BN / 2 ? (size_t)(n0 + c) : (size_t)p.N + n0 + (c - BN / 2)) : (size_t)(n0 + c); };
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int idx = (2 * wave + e) * 8 + lr;
-        a_src[e] = Ap + (size_t)(m0 + (idx >> 6) * 128 + (idx & 63)) * p.lda + lc * 8;              // half h adds 64 rows
-        b_src[e] = GEGLU ? Wp + (size_t)(n0 + idx) * p.K + lc * 8                                    // half 0 = value rows, half 1 (+N rows) = gate rows
-                         : Wp + (size_t)(n0 + (idx >> 5) * 64 + (idx & 31)) * p.K + lc * 8;          // half h adds 32 rows
+        a_src[e] = Ap + (size_t)(m0 + (idx / (TMH * 16)) * WTM + (idx % (TMH * 16))) * p.lda + lc * 8;       // half h adds TMH*16 rows
+        const int i0 = idx < RB0 ? idx : 0, i1 = idx < RB1 ? idx : 0;
+        b0_src[e] = Wp + w_row((i0 / (TN0 * 16)) * WTN + (i0 % (TN0 * 16))) * p.K + lc * 8;
+        b1_src[e] = Wp + w_row((i1 / (TN1 * 16)) * WTN + TN0 * 16 + (i1 % (TN1 * 16))) * p.K + lc * 8;
     }
-    const size_t a_half = (size_t)64 * p.lda, b_half = GEGLU ? (size_t)p.N * p.K : (size_t)32 * p.K;
+    const size_t a_half = (size_t)(TMH * 16) * p.lda;
     const int nk = p.K / KB;
 
-    // region r of a K tile: 0 = A0, 1 = A1, 2 = B0, 3 = B1.  `kt >= nk` issues the two dummy pieces.
+    // region r of a K tile: 0 = A0, 1 = A1, 2 = B0, 3 = B1.  Always two DMAs per wave: pieces beyond the region's rows and
+    // `kt >= nk` are dummies (a zero line into the dump area).
     auto issue_half = [&](int kt, int region) {
-        char* dst = lds + (kt & 1) * TILE_B + region * HALF_B + (2 * wave) * 1024;
-        const bool live = kt < nk;
+        const int roff = region == 0 ? 0 : region == 1 ? HA : region == 2 ? 2 * HA : 2 * HA + HB0;
+        const int rrows = region < 2 ? RA : region == 2 ? RB0 : RB1;
+        char* dst = lds + (kt & 1) * TILE_B + roff + (2 * wave) * 1024;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const T* src = region < 2 ? a_src[e] + (region & 1) * a_half : b_src[e] + (region & 1) * b_half;
+            const bool live = kt < nk && (2 * wave + e) * 8 < rrows;
+            const T* src = region < 2 ? a_src[e] + (region & 1) * a_half : region == 2 ? b0_src[e] : b1_src[e];
             src = live ? src + (size_t)kt * KB : zeros;
             dma16<0>(src, live ? dst + e * 1024 : dump);
         }
@@ -1651,7 +1665,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
             if (GEGLU) { touch(p.ln_c, ((long)p.N + n0) * 4, BNO * 4); touch(p.ln_d, ((long)p.N + n0) * 4, BNO * 4); }
         }
         if (p.epi & ST_EPI_RESIDUAL) {
-            constexpr int lines = BNO * 2 / 128;
+            constexpr int lines = (BNO * 2 + 127) / 128;
             for (int o = t; o < BM * lines; o += 512) {
                 const int r = o / lines, l = o - r * lines;
                 touch_at((const char*)p.residual + ((size_t)(m0 + r) * p.ldr + n0) * 2 + l * 128);
@@ -1680,7 +1694,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     wait_vmcnt<8>();                                 // A0(0), B0(0) have landed (and every load older than the DMAs)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::"v"(touch_sink));
-    if (wm == 1) __builtin_amdgcn_s_barrier();       // the second wave row runs one barrier (half a phase) behind the first
+    if (wave >= 4) __builtin_amdgcn_s_barrier();     // the second half of the waves runs one barrier (half a phase) behind the first
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -1689,41 +1703,54 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int r16 = lane & 15, q = lane >> 4;
-    // fragment addresses: LDS row = half*128 + w*64 (A) / w*32 (B) + frag*16 + r16, chunk 4*kk + q, swizzled by row & 7 = r16 & 7
-    int a_off[2], b_off[2];
+    // fragment addresses: region row = w * (tiles * 16) + frag * 16 + r16, chunk 4*kk + q, swizzled by row & 7 = r16 & 7
+    int a_off[2], b0_off[2], b1_off[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const int sw = ((4 * kk + q) ^ (r16 & 7)) << 4;
-        a_off[kk] = (wm * 64 + r16) * 128 + sw;
-        b_off[kk] = 2 * HALF_B + (wn * 32 + r16) * 128 + sw;
+        a_off[kk] = (wm * TMH * 16 + r16) * 128 + sw;
+        b0_off[kk] = 2 * HA + (wn * TN0 * 16 + r16) * 128 + sw;
+        b1_off[kk] = 2 * HA + HB0 + (wn * TN1 * 16 + r16) * 128 + sw;
     }
-    Frag fa[4][2], fb0[2][2], fb1[2][2];              // A half in use, B0 (kept for the fourth phase), B1
+    Frag fa[TMH][2], fb0[TN0][2], fb1[TN1][2];        // A half in use, B0 (kept for the fourth phase), B1
     auto read_a = [&](const char* tile, int h) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TMH; ++i)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fa[i][kk] = *reinterpret_cast<const Frag*>(tile + h * HALF_B + i * 2048 + a_off[kk]);
+            for (int kk = 0; kk < 2; ++kk) fa[i][kk] = *reinterpret_cast<const Frag*>(tile + h * HA + i * 2048 + a_off[kk]);
     };
-    auto read_b = [&](const char* tile, int h, Frag (&fb)[2][2]) {
+    auto read_b0 = [&](const char* tile) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN0; ++j)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fb[j][kk] = *reinterpret_cast<const Frag*>(tile + h * HALF_B + j * 2048 + b_off[kk]);
+            for (int kk = 0; kk < 2; ++kk) fb0[j][kk] = *reinterpret_cast<const Frag*>(tile + j * 2048 + b0_off[kk]);
     };
-    auto quadrant = [&](auto mh_, auto nh_, Frag (&fb)[2][2]) {
+    auto read_b1 = [&](const char* tile) {
+#pragma unroll
+        for (int j = 0; j < TN1; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fb1[j][kk] = *reinterpret_cast<const Frag*>(tile + j * 2048 + b1_off[kk]);
+    };
+    auto quadrant = [&](auto mh_, auto nh_) {
         constexpr int mh = decltype(mh_)::value, nh = decltype(nh_)::value;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TMH; ++i) {
+                if constexpr (nh == 0) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) Mma<T>::run(acc[mh * 4 + i][nh * 2 + j], fb[j][kk], fa[i][kk]);
+                    for (int j = 0; j < TN0; ++j) Mma<T>::run(acc[mh * TMH + i][j], fb0[j][kk], fa[i][kk]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TN1; ++j) Mma<T>::run(acc[mh * TMH + i][TN0 + j], fb1[j][kk], fa[i][kk]);
+                }
+            }
         __builtin_amdgcn_s_setprio(0);
     };
-    // one phase: [fragment reads] [one half tile of DMA] [counted wait] barrier [16 MFMAs] barrier
-    // after the issue of phase ph the eight DMAs of phases ph-3 .. ph may stay in flight: the half tile issued in
-    // phase ph-4 has landed for this wave, and for everybody once both wave rows have passed their next barrier
+    // one phase: [fragment reads] [one region of DMA] [counted wait] barrier [MFMAs of one quadrant] barrier
+    // after the issue of phase ph the eight DMAs of phases ph-3 .. ph may stay in flight: the region issued in
+    // phase ph-4 has landed for this wave, and for everybody once both halves of the waves have passed their next barrier
 #define ST_PHASE_SYNC()                                   \
     __builtin_amdgcn_sched_barrier(0);                    \
     wait_vmcnt<8>();                                      \
@@ -1738,63 +1765,55 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     for (int kt = 0; kt < nk; ++kt) {
         const char* tile = lds + (kt & 1) * TILE_B;
         // phase 0: (A0, B0); refill B1 of tile kt+1 (last read in phase 1 of tile kt-1)
-        read_a(tile, 0); read_b(tile, 0, fb0);
+        read_a(tile, 0); read_b0(tile);
         issue_half(kt + 1, 3);
         ST_PHASE_SYNC();
-        quadrant(I0{}, I0{}, fb0);
+        quadrant(I0{}, I0{});
         ST_PHASE_END();
         // phase 1: (A0, B1); refill A1 of tile kt+1 (last read in phase 2 of tile kt-1)
-        read_b(tile, 1, fb1);
+        read_b1(tile);
         issue_half(kt + 1, 1);
         ST_PHASE_SYNC();
-        quadrant(I0{}, I1{}, fb1);
+        quadrant(I0{}, I1{});
         ST_PHASE_END();
         // phase 2: (A1, B1); refill A0 of tile kt+2 (last read in phase 0 of this tile)
         read_a(tile, 1);
         issue_half(kt + 2, 0);
         ST_PHASE_SYNC();
-        quadrant(I1{}, I1{}, fb1);
+        quadrant(I1{}, I1{});
         ST_PHASE_END();
         // phase 3: (A1, B0) from registers; refill B0 of tile kt+2 (last read in phase 0 of this tile)
         issue_half(kt + 2, 2);
         ST_PHASE_SYNC();
-        quadrant(I1{}, I0{}, fb0);
+        quadrant(I1{}, I0{});
         ST_PHASE_END();
     }
 #undef ST_PHASE_SYNC
 #undef ST_PHASE_END
-    if (wm == 0) __builtin_amdgcn_s_barrier();       // barrier counts of the two wave rows are equal again
+    if (wave < 4) __builtin_amdgcn_s_barrier();      // barrier counts of the two halves are equal again
     wait_vmcnt<0>();                                  // no LDS-DMA may outlive the workgroup's LDS allocation
     __builtin_amdgcn_s_barrier();
-    // accumulator n-tile j = 2 * nh + j' of wave column wn: B half nh holds the value / gate rows (GEGLU) or columns
-    // 32 nh .. 32 nh + 31 of the wave's 64 (plain)
-    struct Cols8p {
-        int wn;
-        __device__ __forceinline__ int operator()(int j) const {
-            const int nh = j >> 1, jj = j & 1;
-            return GEGLU ? nh * 128 + wn * 32 + jj * 16 : wn * 64 + nh * 32 + jj * 16;
-        }
-    };
-    staged_epilogue<T, BM, BN, WGM, WGN, TM, TN, GEGLU, 2 * TILE_B, !LNF>(p, acc, m0, n0, tile_n, wm, r16, q, Cols8p{wn}, lds,
+    staged_epilogue<T, BM, BN, WGM, WGN, TM, TN, GEGLU, 2 * TILE_B, !LNF>(p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds,
                                                                         reinterpret_cast<const float2*>(lnrows));
 }
 
-static inline bool gemm8p_applies(const GemmArgs& a) {
+// the two shapes of gemm8p: 256 (2 x 4 waves) and 160 columns (4 x 2 waves)
+static inline bool gemm8p_applies(const GemmArgs& a, int bn) {
     const long n_rows = (a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N;
-    return a.M % 256 == 0 && n_rows % 256 == 0 && a.K % 64 == 0 && a.K >= 256 && a.N % 4 == 0 &&
+    return a.M % 256 == 0 && n_rows % bn == 0 && a.K % 64 == 0 && a.K >= 256 && a.N % 8 == 0 &&
            !(a.epi & ST_EPI_ROWBIAS) && (!a.row_stats || !(a.epi & ST_EPI_GEGLU));
 }
 
-template <typename T, bool GEGLU, bool LNF>
+template <typename T, bool GEGLU, bool LNF, int BN, int WGM, int WGN>
 static void gemm8p_go(const GemmArgs& a, hipStream_t st) {
-    constexpr size_t lds = 2 * 4 * 128 * 128 + 256 * 8 + 1024;
-    auto kfn = gemm8p_kernel<T, GEGLU, LNF>;
+    constexpr size_t lds = 2 * (size_t)(2 * 128 * 128 + BN * 128) + 256 * 8 + 1024;
+    auto kfn = gemm8p_kernel<T, GEGLU, LNF, BN, WGM, WGN>;
     static unsigned long long lds_ok = 0;
     ensure_dynamic_lds(kfn, lds, &lds_ok);
     GemmArgs b = a;
-    const int tiles_m = a.M / 256, tiles_n = (int)(((a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N) / 256);
+    const int tiles_m = a.M / 256, tiles_n = (int)(((a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N) / BN);
     {   // XCD partition of the tile order: bytes from beyond L2 ~ A * (8 / panels) + W * panels
-        const double abytes = (double)a.M * a.K, wbytes = (double)tiles_n * 256 * a.K;
+        const double abytes = (double)a.M * a.K, wbytes = (double)tiles_n * BN * a.K;
         int best_p = 1;
         double best = 1e300;
         for (int pm = 1; pm <= 8 && pm <= tiles_m; pm *= 2) {
@@ -1812,11 +1831,11 @@ static void gemm8p_go(const GemmArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(kfn, dim3(main_blocks + b.helper_blocks), dim3(512), lds, st, b);
 }
 
-template <typename T>
+template <typename T, int BN, int WGM, int WGN>
 static void gemm8p_launch(const GemmArgs& a, hipStream_t st) {
     const bool geglu = a.epi & ST_EPI_GEGLU;
-    if (a.ln_c) { if (geglu) gemm8p_go<T, true, true>(a, st); else gemm8p_go<T, false, true>(a, st); }
-    else { if (geglu) gemm8p_go<T, true, false>(a, st); else gemm8p_go<T, false, false>(a, st); }
+    if (a.ln_c) { if (geglu) gemm8p_go<T, true, true, BN, WGM, WGN>(a, st); else gemm8p_go<T, false, true, BN, WGM, WGN>(a, st); }
+    else { if (geglu) gemm8p_go<T, true, false, BN, WGM, WGN>(a, st); else gemm8p_go<T, false, false, BN, WGM, WGN>(a, st); }
 }
 
 // =============================================================================
@@ -2098,7 +2117,7 @@ static void launch_dma(const GemmArgs& a, hipStream_t st) {
 // overrides the heuristic for A/B runs.
 enum { CFG_64x64_S4 = 0, CFG_64x64_S8 = 1, CFG_64x64_S4_U2 = 2, CFG_128x64_S4 = 3, CFG_128x64_S3_U2 = 4,
        CFG_128x128_S3 = 5, CFG_64x64_S3 = 6, CFG_64x64_W8 = 7, CFG_128x64_W8 = 8, CFG_128x128_W8 = 9,
-       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_128x320_W8 = 23, CFG_128x256_W8 = 24, CFG_64x320_W8 = 25, CFG_64x80_W4 = 26, CFG_128x80_W8 = 27, CFG_128x160_W8 = 28, CFG_128x128_N4_S2 = 29, CFG_128x64_N4_S3 = 30, CFG_64x128_N4_S3 = 31, CFG_256x160_W8_S2 = 32, CFG_COUNT, CFG_256x256_8P = 100 };
+       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_128x320_W8 = 23, CFG_128x256_W8 = 24, CFG_64x320_W8 = 25, CFG_64x80_W4 = 26, CFG_128x80_W8 = 27, CFG_128x160_W8 = 28, CFG_128x128_N4_S2 = 29, CFG_128x64_N4_S3 = 30, CFG_64x128_N4_S3 = 31, CFG_256x160_W8_S2 = 32, CFG_COUNT, CFG_256x256_8P = 100, CFG_256x160_8P = 101 };
 
 static inline int cfg_bn(int cfg) {
     switch (cfg) {
@@ -2181,17 +2200,19 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             }
         }
         if constexpr (!CONV && sizeof(T) == 2) {
-            // the 256 x 256 eight-phase kernel: no K split, whole rounds of 256 blocks
-            if (gemm8p_applies(a)) {
-                const long nt = tiles(256, 256);
-                const double rounds = (double)((nt + 255) / 256);
-                const double cost = rounds * (nk * 1.65 + 4.0);      // a 256 x 256 x 64 step is MFMA-paced: ~1.6 us at the clock the chip holds
-                const int f = forced_cfg();
-                // the per-trip constants above were fitted on one-round launches and run 25-45 % optimistic once a launch
-                // takes several rounds (tools/gemm_sweep.py: FF1 of the 1280-channel level 51 us predicted 35, this kernel 39
-                // predicted 37; QKV at batch 4 72 us against 55), so this kernel also takes the near ties
-                if ((cost < 1.3 * best && f < 0) || f == CFG_256x256_8P) { gemm8p_launch<T>(a, st); return st_check_launch(who); }
-            }
+            // the eight-phase kernel (256 x 256 or 256 x 160 tiles): no K split, whole rounds of 256 blocks.  A K step is
+            // MFMA-paced (~1.6 us for 256 x 256 x 64 at the clock the chip holds, ~1.05 us for 256 x 160 x 64).
+            // The per-trip constants above were fitted on one-round launches and run 25-45 % optimistic once a launch
+            // takes several rounds (tools/gemm_sweep.py: FF1 of the 1280-channel level 51 us predicted 35, this kernel 39
+            // predicted 37; QKV at batch 4 72 us against 55), so this kernel also takes the near ties.
+            const int f = forced_cfg();
+            double c256 = 1e30, c160 = 1e30;
+            if (gemm8p_applies(a, 256)) c256 = (double)((tiles(256, 256) + 255) / 256) * (nk * 1.65 + 4.0);
+            if (gemm8p_applies(a, 160)) c160 = (double)((tiles(256, 160) + 255) / 256) * (nk * 1.10 + 4.0);
+            const bool take256 = f == CFG_256x256_8P || (f < 0 && c256 <= c160 && c256 < 1.3 * best);
+            const bool take160 = f == CFG_256x160_8P || (f < 0 && c160 < c256 && c160 < 1.3 * best);
+            if (take256 && c256 < 1e29) { gemm8p_launch<T, 256, 2, 4>(a, st); return st_check_launch(who); }
+            if (take160 && c160 < 1e29) { gemm8p_launch<T, 160, 4, 2>(a, st); return st_check_launch(who); }
         }
         GemmArgs b = a;
 #ifdef ST_DEV_CONFIGS

@@ -26,7 +26,7 @@ for ncopy, tag in ((1, "warm"), (max(1, min(32, int(600e6 // (rows * K * 2)))), 
     if force is not None: force(-1, -1)
     us = timeit(ours, iters=max(20, ncopy)); line += f"product {us:.1f} us ({fl/us/1e6:.0f} TF/s)"
     if force is not None:
-        for cfg, name in ((100, "8p"), (19, "256x128"), (9, "128x128"), (28, "128x160"), (10, "64x128"), (8, "128x64"), (27, "128x80"), (26, "64x80 W4"), (15, "64x128 U2"), (16, "128x64 U2"), (11, "64x128 S6"), (12, "128x64 S6"),
+        for cfg, name in ((100, "8p"), (101, "8p160"), (19, "256x128"), (9, "128x128"), (28, "128x160"), (10, "64x128"), (8, "128x64"), (27, "128x80"), (26, "64x80 W4"), (15, "64x128 U2"), (16, "128x64 U2"), (11, "64x128 S6"), (12, "128x64 S6"),
                           (5, "128x128 N4S3"), (29, "128x128 N4S2"), (30, "128x64 N4S3"), (31, "64x128 N4S3"), (3, "128x64 N4S4"), (6, "64x64 N4S3"), (32, "256x160 S2")):
             if geglu and cfg in (27, 26, 30, 6, 3):          # (odd n-tiles per wave: no value/gate pairing; the dispatch never picks it)
                 continue
