@@ -2200,15 +2200,17 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             }
         }
         if constexpr (!CONV && sizeof(T) == 2) {
-            // the eight-phase kernel (256 x 256 or 256 x 160 tiles): no K split, whole rounds of 256 blocks.  A K step is
-            // MFMA-paced (~1.6 us for 256 x 256 x 64 at the clock the chip holds, ~1.05 us for 256 x 160 x 64).
+            // the eight-phase kernel (256 x 256 or 256 x 160 tiles): no K split, whole rounds of 256 blocks.  A K step costs
+            // ~1.65 us for 256 x 256 x 64 and ~1.5 us for 256 x 160 x 64 (measured, tools/gemm8p_check.py: a phase is paced by
+            // its load segment - two LDS-DMA issues per wave, the fragment reads, two barriers - more than by its 12-16 MFMAs,
+            // so the narrower tile buys only 8 % per step; what it buys is whole rounds: 1024 x 10240 is 256 tiles, not 160).
             // The per-trip constants above were fitted on one-round launches and run 25-45 % optimistic once a launch
             // takes several rounds (tools/gemm_sweep.py: FF1 of the 1280-channel level 51 us predicted 35, this kernel 39
             // predicted 37; QKV at batch 4 72 us against 55), so this kernel also takes the near ties.
             const int f = forced_cfg();
             double c256 = 1e30, c160 = 1e30;
             if (gemm8p_applies(a, 256)) c256 = (double)((tiles(256, 256) + 255) / 256) * (nk * 1.65 + 4.0);
-            if (gemm8p_applies(a, 160)) c160 = (double)((tiles(256, 160) + 255) / 256) * (nk * 1.10 + 4.0);
+            if (gemm8p_applies(a, 160)) c160 = (double)((tiles(256, 160) + 255) / 256) * (nk * 1.52 + 4.0);
             const bool take256 = f == CFG_256x256_8P || (f < 0 && c256 <= c160 && c256 < 1.3 * best);
             const bool take160 = f == CFG_256x160_8P || (f < 0 && c160 < c256 && c160 < 1.3 * best);
             if (take256 && c256 < 1e29) { gemm8p_launch<T, 256, 2, 4>(a, st); return st_check_launch(who); }
