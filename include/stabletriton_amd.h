@@ -188,7 +188,9 @@ int st_timestep_features(const float* t, long t_stride, const int* step, void* o
 
 /* ---- fp8 projection path (BASELINE config #5).  Seed in the reference: fp8-stored projection
  * weights, up-converted before the product (kernels/attention_proj.py:36-39, 105-155); here both operands stay OCP
- * e4m3 ("e4m3fn") down to the matrix pipe (v_mfma_f32_16x16x32_fp8_fp8), accumulation fp32, output bf16.
+ * e4m3 ("e4m3fn") down to the matrix pipe - the block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 at twice the bf16 rate, its
+ * E8M0 block scales all 2^0 (the scales of this path are per row / per output channel, applied in the epilogue) -
+ * accumulation fp32, output bf16.
  *
  * st_quantize_fp8: x (rows, C) of `dtype` (any of the three), row stride ldx elements -> xq (rows, C) e4m3 bytes, contiguous, and
  *   row_scale[m] = max_k |x[m][k]| / 448 (fp32), xq[m][k] = e4m3(x[m][k] / row_scale[m]), round to nearest even.

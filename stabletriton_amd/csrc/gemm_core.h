@@ -90,22 +90,24 @@ template <> struct Mma<float> {
     }
 };
 
-// fp8 (OCP e4m3) operands: A and W are bytes in memory, accumulation is fp32, everything the epilogue touches is bf16
+// fp8 (OCP e4m3) operands: A and W are bytes in memory, accumulation is fp32, everything the epilogue touches is bf16.
+// The matrix instruction is the block-scaled one, v_mfma_scale_f32_16x16x128_f8f6f4 with e4m3 operands: 128 k per
+// instruction in twice the cycles of a bf16 16x16x32, i.e. TWICE the bf16 rate (the plain v_mfma_f32_16x16x32_fp8_fp8 runs
+// at the bf16 rate).  Its per-32-element E8M0 block scales are all 2^0 here (0x7F): the scales of this path are per row /
+// per output channel and applied in the epilogue.  A lane (row r, lane group q) hands over 32 bytes of its row - here the
+// 16-byte chunks q and q + 4 of the 128-byte K tile; which 32 of the 128 k a lane group takes is free as long as both
+// operands take the same ones (the instruction sums over all of them).
 struct f8 { unsigned char v; };
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 template <> struct Mma<f8> {
-    typedef u32x4 Frag;              // 16 consecutive k of one row
-    // the low and the high 8 bytes feed one v_mfma_f32_16x16x32_fp8_fp8 each: lane (r, q) then contributes
-    // k = 16q .. 16q+7 and 16q+8 .. 16q+15 of this 64-wide k group - the same permutation on both operands
+    typedef i32x8 Frag;              // 32 bytes of one row: two 16-byte chunks of the K tile
     static __device__ __forceinline__ void run(f32x4& acc, const Frag& a, const Frag& b) {
-        const long a0 = (long)(((unsigned long)a[1] << 32) | a[0]), a1 = (long)(((unsigned long)a[3] << 32) | a[2]);
-        const long b0 = (long)(((unsigned long)b[1] << 32) | b[0]), b1 = (long)(((unsigned long)b[3] << 32) | b[2]);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc, 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
     }
 };
 template <typename T> struct OutT { typedef T type; };
 template <> struct OutT<f8> { typedef bf16 type; };
-template <typename T> constexpr int mfma_per_frag() { return sizeof(T) == 4 ? 4 : (sizeof(T) == 1 ? 2 : 1); }
+template <typename T> constexpr int mfma_per_frag() { return sizeof(T) == 4 ? 4 : 1; }
 
 template <typename T> struct Out4;
 template <> struct Out4<bf16> {
@@ -1375,27 +1377,32 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     // Software pipeline (one wave per SIMD has nobody else to hide LDS latency behind):
     // the fragments of MFMA group g+1 are read while group g multiplies, and the LAST group
     // of a stage multiplies after the stage barrier, under the first reads of the next stage.
-    constexpr int NG = 2 * U;                     // MFMA groups per stage (two 64-byte halves per K tile)
+    constexpr int GPT = sizeof(T) == 1 ? 1 : 2;    // MFMA groups per K tile: two 64-byte halves; fp8: the whole 128-byte row per instruction
+    constexpr int NG = GPT * U;                   // MFMA groups per stage
+    constexpr int RPF = sizeof(T) == 1 ? 2 : 1;   // 16-byte LDS reads per fragment
     // with only two buffers the whole prefetch must be issued before the stage barrier (group 0)
     constexpr bool EARLY = (STAGES == 2);
     Frag fa[2][TM], fb[2][TN];
+    auto read_frag = [&](const char* base, int row, int g) -> Frag {
+        if constexpr (sizeof(T) == 1) {
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(base + row * 128 + ((q ^ (row & 7)) << 4));
+            const u32x4 hi = *reinterpret_cast<const u32x4*>(base + row * 128 + (((q + 4) ^ (row & 7)) << 4));
+            return Frag{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        } else {
+            const int c = 4 * (g & 1) + q;
+            return *reinterpret_cast<const Frag*>(base + row * 128 + ((c ^ (row & 7)) << 4));
+        }
+    };
     auto read_group = [&](int buf, int g, int set) {
 #ifdef ST_FILL_ONLY
         (void)buf; (void)g; (void)set; return;        // timing experiment: DMA stream only
 #endif
-        const char* sa = lds + buf * STAGE + (g >> 1) * TILE;
+        const char* sa = lds + buf * STAGE + (g / GPT) * TILE;
         const char* sb = sa + A_BYTES;
-        const int c = 4 * (g & 1) + q;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = wm * WTM + i * 16 + r16;
-            fa[set][i] = *reinterpret_cast<const Frag*>(sa + row * 128 + ((c ^ (row & 7)) << 4));
-        }
+        for (int i = 0; i < TM; ++i) fa[set][i] = read_frag(sa, wm * WTM + i * 16 + r16, g);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int row = wn * WTN + j * 16 + r16;
-            fb[set][j] = *reinterpret_cast<const Frag*>(sb + row * 128 + ((c ^ (row & 7)) << 4));
-        }
+        for (int j = 0; j < TN; ++j) fb[set][j] = read_frag(sb, wn * WTN + j * 16 + r16, g);
     };
     auto mma_group = [&](int set) {
 #if defined(ST_FILL_ONLY)
@@ -1417,15 +1424,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     PROBE_DECL
     PROBE_STAMP(pr_start)
     read_group(0, 0, 0);
-    // The loop body is branch-free: trips past the last prefetch re-fetch the final stage into a
+    // The trip body is branch-free: trips past the last prefetch re-fetch the final stage into a
     // buffer nobody reads again, so the vmcnt bookkeeping is the same every trip.
-    for (int kt = 0; kt < nk; ++kt) {
+    // PAR: which of the two fragment register sets group 0 of this trip multiplies from - with an odd number of groups
+    // per stage (fp8: one) the sets trade places every trip, so the loop runs two trips per iteration.
+    auto trip = [&](int kt, auto par_) {
+        constexpr int PAR = decltype(par_)::value;
         PROBE_STAMP(pr_i0)
         const int pf = min(kt + STAGES - 1, nk - 1);      // stage to prefetch (clamped)
         auto group = [&](auto gc) {
             constexpr int g = decltype(gc)::value;
             if constexpr (g + 1 < NG) {
-                read_group(cur, g + 1, (g + 1) & 1);
+                read_group(cur, g + 1, (g + 1 + PAR) & 1);
             } else {
                 // stage kt+1 must have landed (own DMAs), then everyone's; the barrier also retires
                 // every wave's reads of `cur` (all of them are in registers by now) before its refill
@@ -1438,18 +1448,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
                 PROBE_STAMP(pr_i3)
                 PROBE_ADD(pr_a, pr_i1, pr_i0) PROBE_ADD(pr_b, pr_i2, pr_i1) PROBE_ADD(pr_c, pr_i3, pr_i2)
                 __builtin_amdgcn_sched_barrier(0);
-                read_group(cur + 1 == STAGES ? 0 : cur + 1, 0, (g + 1) & 1);
+                read_group(cur + 1 == STAGES ? 0 : cur + 1, 0, (g + 1 + PAR) & 1);
             }
             constexpr int n_dma = EARLY ? (g == 0 ? G : 0) : dma_in_group(G, NG, g);
 #pragma unroll
             for (int e = 0; e < G; ++e)
                 if ((EARLY ? 0 : e * NG / G) == g) issue_one(pf, nxt, e);
-            mma_group(g & 1);
+            mma_group((g + PAR) & 1);
             // pin the emitted order of this group: fragment reads of the NEXT group first, then this
             // group's DMA share, then this group's MFMAs (hipcc otherwise sinks the reads to just
             // before their use and exposes the LDS latency in front of every MFMA cluster)
 #ifndef ST_NO_PIN
-            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, (TM + TN) * RPF, 0);
             if constexpr (n_dma > 0) __builtin_amdgcn_sched_group_barrier(0x020, n_dma, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * mfma_per_frag<T>(), 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -1458,7 +1468,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
 #endif
         };
         group(std::integral_constant<int, 0>{});
-        group(std::integral_constant<int, 1>{});
+        if constexpr (NG > 1) group(std::integral_constant<int, 1>{});
         if constexpr (NG > 2) {
             group(std::integral_constant<int, 2>{});
             group(std::integral_constant<int, 3>{});
@@ -1471,6 +1481,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         cur = cur + 1 == STAGES ? 0 : cur + 1;
         nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
         if (CONV) conv_advance(kt + STAGES - 1 < nk - 1);
+    };
+    if constexpr (NG % 2 == 0) {
+        for (int kt = 0; kt < nk; ++kt) trip(kt, std::integral_constant<int, 0>{});
+    } else {
+        for (int kt = 0; kt < nk; kt += 2) {
+            trip(kt, std::integral_constant<int, 0>{});
+            if (kt + 1 < nk) trip(kt + 1, std::integral_constant<int, 1>{});
+        }
     }
     wait_vmcnt<0>();                              // no LDS-DMA may outlive the workgroup's LDS allocation
     PROBE_STAMP(pr_end)
@@ -2187,6 +2205,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
         int cfg = CFG_64x64_W8, sk = 1;
         double best = 1e30;
         for (const Cand& c : cands) {
+            if (sizeof(T) == 1 && c.bn == 320) continue;                 // fp8 fragments are 32 bytes: the 320-wide wave tiles spill
             if ((a.epi & ST_EPI_GEGLU) && c.bn % 32 != 0) continue;      // GEGLU: the value / gate halves of a tile are whole accumulator tiles (BN = 80 is not)
             const long nt = tiles(c.bm, c.bn);
             const double trip = c.trip_us * (CONV ? 1.6 : 1.0);
