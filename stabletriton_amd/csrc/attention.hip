@@ -469,13 +469,21 @@ static int attention16_launch(const void* q, const void* k, const void* v, void*
     // the CUs idle: SDXL's 32x32 level at batch 1 is then 160 blocks of four waves, one per SIMD (15.4 us against 20.2).
     // Against eight self-loading waves: 4096 tokens 73 -> 70 us (batch 1), 215 -> 206 us (batch 4); 1024 tokens at
     // batch 4 43.8 -> 39.2 us.
+    // Three compute waves (96 rows) when four would still leave a third of the CUs without a block: the 32x32 level at batch 1
+    // is 220 blocks instead of 160 (15.3 -> 13.9 us).
     int nw = (long)cdiv(T, 256) * H * B <= 128 ? 4 : 7;
-    if (force_nw == 4 || force_nw == 8 || force_nw == 7) nw = force_nw;
-    auto kfn = nw == 8 ? attn32i_kernel<E, 8, false> : nw == 7 ? attn32i_kernel<E, 7, true> : attn32i_kernel<E, 4, true>;
-    static unsigned long long lds_ok[3] = {0, 0, 0};          // per kernel: bit mask over device ordinals
-    ensure_dynamic_lds(kfn, RING, &lds_ok[nw == 8 ? 0 : nw == 7 ? 1 : 2]);
+    if (nw == 4 && (long)cdiv(T, 128) * H * B <= 176 && (long)cdiv(T, 96) * H * B <= 256) nw = 3;
+    if (force_nw == 3 || force_nw == 4 || force_nw == 8 || force_nw == 7) nw = force_nw;
+    auto kfn = nw == 8 ? attn32i_kernel<E, 8, false> : nw == 7 ? attn32i_kernel<E, 7, true> : nw == 3 ? attn32i_kernel<E, 3, true> : attn32i_kernel<E, 4, true>;
+    int threads = nw == 4 ? 320 : nw == 3 ? 256 : 512;
+#ifdef ST_DEV_CONFIGS
+    if (force_nw == 5) { nw = 5; kfn = attn32i_kernel<E, 5, true>; threads = 384; }
+    if (force_nw == 6) { nw = 6; kfn = attn32i_kernel<E, 6, true>; threads = 448; }
+#endif
+    static unsigned long long lds_ok[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // per kernel: bit mask over device ordinals
+    ensure_dynamic_lds(kfn, RING, &lds_ok[nw - 1]);
     ST_REQUIRE((long)cdiv(T, 32 * nw) * H * B < (1L << 31), "attention: too many blocks");
-    hipLaunchKernelGGL(kfn, dim3(cdiv(T, 32 * nw) * H * B), dim3(nw == 4 ? 320 : 512), RING, st, (const E*)q, (const E*)k, (const E*)v,
+    hipLaunchKernelGGL(kfn, dim3(cdiv(T, 32 * nw) * H * B), dim3(threads), RING, st, (const E*)q, (const E*)k, (const E*)v,
                        (E*)out, T, S, ldq, ldk, ldv, ldo, c, H, ATT_PROBE_ARG);
     return st_check_launch("attention");
 }
