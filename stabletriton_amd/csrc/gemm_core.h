@@ -635,6 +635,8 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
     for (int e = 0; e < VEC; ++e) { c1[e] = 0.f; c2[e] = 0.f; }
     unsigned int touch_next = 0;
 
+    // (this barrier costs 0.6 % of a batch-1 step - measured by leaving it out - and stays: nothing else orders the other
+    //  waves' last fragment reads and tail DMAs against the tile that is about to overwrite the ring)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the last fragment reads of the K loop have returned ...
     __builtin_amdgcn_s_barrier();                                 // ... in every wave: the ring may be overwritten
 #pragma unroll
