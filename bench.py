@@ -388,13 +388,13 @@ def main():
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     rccl_log = rccl_problem = None
+    if args.same_device:                 # rehearsal on one card: RCCL cannot put two ranks on one device
+        args.backend = "gloo"
     if world_env > 1 and args.backend == "nccl":
         rccl_log = os.path.join(tempfile.gettempdir(), f"st_rccl_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('RANK', '0')}.log")
         os.environ.setdefault("NCCL_DEBUG", "INFO")
         os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,P2P,NET")
         os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
-    if args.same_device:                 # rehearsal on one card: RCCL cannot put two ranks on one device
-        args.backend = "gloo"
     rank, world, local = parallel.init_from_env(args.backend)
     if args.same_device:
         local = 0
