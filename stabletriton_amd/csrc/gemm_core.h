@@ -1539,7 +1539,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         unsigned int sink = 0;
         touch_next_weights(p, sink);
         retire_touches(sink);
-    } else {
+    } else if constexpr (BM * BN >= 128 * 128 || GEGLU || CONV) {
+        // staged epilogue (through LDS): the wide tiles, every GEGLU tile, the implicit-GEMM convs
         // (the LayerNorm (mean, rstd) rows sit behind the ring, which the staged tile takes over)
 #ifdef ST_PROBE
         unsigned long long ept[2] = {0, 0};
@@ -1550,6 +1551,26 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
             p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds, reinterpret_cast<const float2*>(lds + STAGES * STAGE), ept);
 #ifdef ST_PROBE
         pr_x = ept[0] - pr_end; pr_d = ept[1] - ept[0];
+#endif
+    } else if constexpr (LNF) {
+        // the small dense tiles (64 x 64 ... 128 x 80) keep the fragment-layout epilogue: with 2-4 accumulator tiles per wave
+        // the two block barriers and the LDS round trip of the staged form cost more than its coalescing returns
+        // (128 x 64: 4400 against 3700 cycles; from 128 x 128 on the staged form is level or ahead: tools/gemm_probe.py)
+        float mean[TM], rstd[TM];
+        const float2* lnst = reinterpret_cast<const float2*>(lds + STAGES * STAGE);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float2 v = lnst[wm * WTM + i * 16 + r16];
+            mean[i] = v.x; rstd[i] = v.y;
+        }
+        gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wm, wn, r16, q, split, mean, rstd);
+    } else {
+#ifdef ST_PROBE
+        unsigned long long ept[2] = {0, 0};
+        gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n, ept);
+        pr_x = ept[0] - pr_end; pr_d = ept[1] - ept[0];
+#else
+        gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n);
 #endif
     }
 #ifdef ST_PROBE
