@@ -118,7 +118,7 @@ def test_fp8_mode_claims_the_transformer_projections():
 def test_fp8_unet_step_vs_oracle(gpu, sdxl_bf16_pair):
     """One SDXL-base step (F1 input) with fp8 projections against the reference's own output.  Tolerance: the
     projections carry ~4 % rms error each (above); through 70 transformer layers with residual connections the output
-    deviates by a few tens of percent of its rms in this random-weight network - reported, and gated at 0.5 to catch
+    deviates by a few tens of percent of its rms in this random-weight network - reported, and gated at 1.5 x the measured value to catch
     a broken kernel (bf16 mode: 0.04)."""
     from stabletriton_amd import synth
     from stabletriton_amd.optimization import optimize_model
@@ -133,4 +133,4 @@ def test_fp8_unet_step_vs_oracle(gpu, sdxl_bf16_pair):
     ref = torch.from_numpy(golden("f1_unet_step_latent64")["out"])
     rms = float((out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
     print(f"F1 with fp8 projections: relative rms error {rms:.3f}, max abs {float((out - ref).abs().max()):.3f} (|ref| max {float(ref.abs().max()):.2f})")
-    assert torch.isfinite(out).all() and rms <= 0.5
+    assert torch.isfinite(out).all() and rms <= 0.39          # 1.5 x the measured 0.262

@@ -256,3 +256,12 @@ def test_comfy_callsite_sdxl_b4_per_row_timesteps(gpu, sdxl_fp32_pair):
     err = float((out.cpu() - ref).abs().max())
     print(f"F1-b4 per-row timesteps via the ComfyUI entry, fp32: max abs err {err:.2e} (|ref| max {float(ref.abs().max()):.2f})")
     assert err <= ABS_TOL_STRICT
+    # the arguments the compiled path does not implement are refused at SDXL size too, never silently dropped (the reference's
+    # forward swallows **kwargs, unet_pt.py:469-471): ControlNet residuals of the real shapes, attention patches
+    control = {"input": [torch.zeros(4, 320, 64, 64, device=gpu)], "middle": [torch.zeros(4, 1280, 16, 16, device=gpu)],
+               "output": [torch.zeros(4, 1280, 16, 16, device=gpu), torch.zeros(4, 640, 32, 32, device=gpu)]}
+    args = dict(timesteps=torch.from_numpy(g["timesteps_vec"]).to(gpu), context=x["encoder_hidden_states"].to(gpu), y=y.to(gpu))
+    with pytest.raises(NotImplementedError):
+        adapter(x["latent"].to(gpu), control=control, **args)
+    with pytest.raises(NotImplementedError):
+        adapter(x["latent"].to(gpu), transformer_options={"patches_replace": {"attn1": {("input", 4, 0): object()}}}, **args)

@@ -112,4 +112,4 @@ def test_sdxl_refiner_img2img_1024_fp8(gpu):
     assert torch.isfinite(finals[True]).all()
     rms = float((finals[True] - finals[False]).pow(2).mean().sqrt() / finals[False].pow(2).mean().sqrt())
     print(f"SDXL-refiner img2img 1024 px, 15 steps: fp8-projection trajectory vs bf16 trajectory, relative rms difference {rms:.3f}")
-    assert rms <= 0.5
+    assert rms <= 0.06           # 1.5 x the measured 0.039 (15 img2img steps at strength 0.3)

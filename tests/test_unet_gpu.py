@@ -21,7 +21,7 @@ from tests.util import golden, rel_err
 
 pytestmark = pytest.mark.gpu
 ABS_TOL_STRICT = 1e-3          # north_star: 1e-3 abs on the final latent
-BF16_F3_MAX_ABS = {64: 0.6, 128: 0.6}      # bf16 50-step final latent, worst element (set from the measured values)
+BF16_F3_MAX_ABS = {64: 0.51, 128: 0.49}    # bf16 50-step final latent, worst element of |latent| <= 56: 1.5 x the measured 0.341 / 0.324
 F2_STRIDE = 31                 # oracle/make_golden.py subsample rule
 
 

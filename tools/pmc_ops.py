@@ -70,7 +70,18 @@ per, fam_acc = {}, {}
 for name in shapes:
     fam, flops, nbytes, cnt = meta(name)
     # (one_op.py runs the producer GEMM once before the LayerNorm-folded launches: keep only the kernel under study)
-    only = (lambda ds: [d for d in ds if "ELb1ELb1EEv" in d["kernel"]]) if fam == "linear_xattn" else (lambda ds: ds)
+    # r02 kept that producer launch in the LayerNorm-folded linear shapes (1 of 6 dispatches, a short 1280^2 GEMM): it pulled the
+    # average duration down and with it mfma_busy below flops_over_peak by 12-15 %.  Keep the kernel that was launched most.
+    def only(ds):
+        if fam == "linear_xattn":
+            return [d for d in ds if "ELb1ELb1EEv" in d["kernel"]]
+        if fam in ("linear", "conv2d") and ds:
+            names = {}
+            for d in ds:
+                names[d["kernel"]] = names.get(d["kernel"], 0) + 1
+            top = max(names, key=names.get)
+            return [d for d in ds if d["kernel"] == top]
+        return ds
     sq = only(read(os.path.join(src, name + "__sq", "*", "*counter_collection.csv")))
     if not sq:
         continue
