@@ -40,10 +40,11 @@ enum {
     ST_EPI_ROWBIAS   = 16   /* + rowbias[batch(m)][n]     (time-embedding add)    */
 };
 
-int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 10
+int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 11
                                               (6: next-weights hint passed per call, st_timestep_sincos; 7: fp8 entry points; 8: GroupNorm partials from the
                                               producer; 9: st_ln_linear_xattn; 10: ST_F16 accepted by every entry point
-                                              that takes a dtype, st_ln_linear_xattn takes a dtype) */
+                                              that takes a dtype, st_ln_linear_xattn takes a dtype; 11: fp8 plan with
+                                              delayed per-tensor scaling - st_linear_emit8, st_linear_fp8x, st_fp8_update_scales) */
 const char* st_last_error(void);           /* host string, thread-local     */
 
 /* GroupNorm (+SiLU).  Replaces reference group_norm_wrapper
@@ -205,6 +206,37 @@ int st_linear_fp8(const void* xq, const float* row_scale, const void* Wq, const 
                   const void* residual, void* y, int M, int N, int K, long lda, long ldc, long ldr, int epilogue,
                   void* workspace, size_t workspace_bytes, const void* next_weights, size_t next_weights_bytes,
                   void* stream);
+
+/* ---- fp8 plan of the compiled graph (optimizers/plan_fp8.py): the three big projections of a transformer block (q|k|v, the
+ * GEGLU projection, the feed-forward output) run with e4m3 operands and NO quantisation launches.  The launch that produces a
+ * projection's input also writes an e4m3 copy of it, scaled by a PER-TENSOR factor derived from the previous denoise step's
+ * max |value| ("delayed scaling"); this step's maximum goes to the tensor's `amax` partial slots (256 unsigned ints holding
+ * non-negative float bit patterns, combined by atomic max).  st_fp8_update_scales runs once per step before the first launch:
+ * for tensor i, scale[i] = margin * max(amax_parts[i][0..255]) / 448, inv_scale[i] = 1 / scale[i], partials cleared; a tensor
+ * whose partials are all zero keeps its scale.
+ *
+ * st_linear_emit8: st_linear whose epilogue also writes q8[m][n] = e4m3(clamp(y[m][n] * *q8_inv_scale, +-448)) (row stride ldq8
+ *   bytes, N and ldq8 multiples of 8) and this launch's max |y| to q8_amax.  16-bit dtypes.
+ * st_linear_fp8x: y[M,N] = epilogue((xq Wq^T) * a_scale[m * a_scale_stride] * w_scale[n]) - a_scale_stride 0: one scale for the
+ *   whole activation tensor (the scale[i] above), 1: per row (st_quantize_fp8's row_scale).  With ln_c / ln_d / ln_stats the
+ *   LayerNorm in front of the projection is folded exactly as in st_ln_linear (xq is then the e4m3 copy of the UN-normalised
+ *   input, c[n] = sum_k of the dequantised folded weights).  `y` may be NULL when only the e4m3 copy q8 of the output is
+ *   wanted (the GEGLU projection feeding the feed-forward output projection).  row_stats as in st_linear. */
+int st_linear_emit8(const void* x, const void* W, const void* bias, const void* residual,
+                    const void* rowbias, void* y, int M, int N, int K,
+                    long lda, long ldc, long ldr, int rows_per_batch,
+                    int epilogue, int dtype, void* workspace, size_t workspace_bytes,
+                    float* row_stats, int row_stats_capacity, int* row_stats_chunks,
+                    float* col_stats, int col_stats_tiles, int* col_stats_rows,
+                    void* q8, long ldq8, const float* q8_inv_scale, unsigned int* q8_amax,
+                    const void* next_weights, size_t next_weights_bytes, void* stream);
+int st_linear_fp8x(const void* xq, const float* a_scale, int a_scale_stride, const void* Wq, const float* w_scale,
+                   const void* bias, const void* residual, void* y, int M, int N, int K, long lda, long ldc, long ldr, int epilogue,
+                   const float* ln_stats, int ln_chunks, const float* ln_c, const float* ln_d, float ln_eps,
+                   float* row_stats, int row_stats_capacity, int* row_stats_chunks,
+                   void* q8, long ldq8, const float* q8_inv_scale, unsigned int* q8_amax,
+                   void* workspace, size_t workspace_bytes, const void* next_weights, size_t next_weights_bytes, void* stream);
+int st_fp8_update_scales(float* scale, float* inv_scale, unsigned int* amax_parts, int n_tensors, float margin, void* stream);
 
 /* The reference's own timestep operator, elementwise (optimizers/replace_timesteps.py:33-40 ->
  * kernels/timestep.py:13-45): x is fp32 of shape (..., half), n elements in all;

@@ -113,6 +113,23 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- e4m3 copies of an operator's output for an fp8 consumer (delayed per-tensor scaling) -------------------------------
+static constexpr float ST_FP8_MAX = 448.0f;                 // largest finite OCP e4m3 value
+static constexpr int ST_FP8_AMAX_SLOTS = 256;               // max |value| partials per tensor (spread atomics, reduced once per step)
+__device__ __forceinline__ unsigned int pack4_fp8(float a, float b, float c, float d) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);      // bytes 0, 1
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);       // bytes 2, 3
+    return (unsigned int)w;
+}
+__device__ __forceinline__ float clamp_fp8(float v) { return fminf(fmaxf(v, -ST_FP8_MAX), ST_FP8_MAX); }
+// a wave's max |value| -> one of the tensor's partial slots (non-negative floats order like their bit patterns)
+__device__ __forceinline__ void publish_amax(unsigned int* slots, float a, int wave_id) {
+    a = wave_max(a);
+    if ((threadIdx.x & 63) == 0 && a > 0.f)
+        __hip_atomic_fetch_max(slots + (wave_id & (ST_FP8_AMAX_SLOTS - 1)), __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Kernels that need more than 64 KiB of dynamic LDS have that limit raised with hipFuncSetAttribute, which is PER DEVICE:

@@ -4,14 +4,7 @@
 // LayerNorm -> Linear pairs of the transformer blocks (unet_pt.py:192-208) cost one pass instead of two.
 #include "common.h"
 
-static constexpr float FP8_MAX = 448.0f;
-
-__device__ __forceinline__ unsigned int pack4_fp8(float a, float b, float c, float d) {
-    int w = 0;
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);      // bytes 0, 1
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);       // bytes 2, 3
-    return (unsigned int)w;
-}
+static constexpr float FP8_MAX = ST_FP8_MAX;
 
 template <typename T, int NV, bool LN>
 __global__ __launch_bounds__(256) void quant_fp8_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ gamma,
@@ -112,4 +105,38 @@ extern "C" int st_layer_norm_quantize_fp8(const void* x, const void* gamma, cons
     if (dtype == ST_F16) return quant_launch<f16, true>(x, C, gamma, beta, xq, row_scale, rows, C, eps, st);
     if (dtype == ST_F32) return quant_launch<float, true>(x, C, gamma, beta, xq, row_scale, rows, C, eps, st);
     return st_fail("layer_norm_quantize_fp8: unsupported dtype %d", dtype);
+}
+
+
+// ---- delayed per-tensor scaling (the fp8 plan of the compiled graph: optimizers/plan_fp8.py) ------------------------
+// A producer's epilogue quantises with the scale derived from the PREVIOUS step's max |value| (no pass over the tensor, no
+// extra launch, no host round trip) and leaves this step's maximum in the tensor's partial slots.  Once per step, before
+// the first launch, this kernel turns the partials of every tensor into the scale of the coming step and clears them:
+//   scale = margin * amax / 448 (what one e4m3 unit is worth), inv_scale = 1 / scale;  a tensor that saw nothing keeps its scale.
+__global__ __launch_bounds__(ST_FP8_AMAX_SLOTS) void fp8_update_scales_kernel(float* __restrict__ scale, float* __restrict__ inv_scale,
+                                                                               unsigned int* __restrict__ parts, float margin) {
+    const int i = blockIdx.x, t = threadIdx.x;
+    unsigned int* mine = parts + (size_t)i * ST_FP8_AMAX_SLOTS;
+    float a = __uint_as_float(mine[t]);
+    mine[t] = 0u;
+    a = wave_max(a);
+    __shared__ float red[ST_FP8_AMAX_SLOTS / 64];
+    if ((t & 63) == 0) red[t >> 6] = a;
+    __syncthreads();
+    if (t == 0) {
+        float m = 0.f;
+#pragma unroll
+        for (int w = 0; w < ST_FP8_AMAX_SLOTS / 64; ++w) m = fmaxf(m, red[w]);
+        if (m > 0.f) {
+            const float s = margin * m / ST_FP8_MAX;
+            scale[i] = s;
+            inv_scale[i] = 1.0f / s;
+        }
+    }
+}
+
+extern "C" int st_fp8_update_scales(float* scale, float* inv_scale, unsigned int* amax_parts, int n_tensors, float margin, void* stream) {
+    ST_REQUIRE(scale && inv_scale && amax_parts && n_tensors > 0 && margin >= 1.0f, "fp8_update_scales: bad arguments");
+    hipLaunchKernelGGL(fp8_update_scales_kernel, dim3(n_tensors), dim3(ST_FP8_AMAX_SLOTS), 0, (hipStream_t)stream, scale, inv_scale, amax_parts, margin);
+    return st_check_launch("fp8_update_scales");
 }

@@ -20,11 +20,20 @@ static int run_dense(const GemmArgs& a, int dtype, hipStream_t st) {
     }
 }
 
-extern "C" int st_linear(const void* x, const void* W, const void* bias, const void* residual, const void* rowbias, void* y,
-                         int M, int N, int K, long lda, long ldc, long ldr, int rows_per_batch, int epilogue, int dtype,
-                         void* workspace, size_t workspace_bytes, float* row_stats, int row_stats_capacity,
-                         int* row_stats_chunks, float* col_stats, int col_stats_tiles, int* col_stats_rows,
-                         const void* next_weights, size_t next_weights_bytes, void* stream) {
+static int check_q8(const char* who, GemmArgs& a, void* q8, long ldq8, const float* q8_inv_scale, unsigned int* q8_amax) {
+    if (!q8) return 0;
+    ST_REQUIRE(q8_inv_scale && q8_amax, "%s: the e4m3 copy needs its scale and its amax slots", who);
+    ST_REQUIRE(a.N % 8 == 0 && ldq8 % 8 == 0 && (uintptr_t)q8 % 8 == 0, "%s: e4m3 copy: N and its row stride must be multiples of 8", who);
+    a.q8_out = q8; a.q8_ld = ldq8; a.q8_inv_scale = q8_inv_scale; a.q8_amax = q8_amax;
+    return 0;
+}
+
+static int linear_impl(const void* x, const void* W, const void* bias, const void* residual, const void* rowbias, void* y,
+                       int M, int N, int K, long lda, long ldc, long ldr, int rows_per_batch, int epilogue, int dtype,
+                       void* workspace, size_t workspace_bytes, float* row_stats, int row_stats_capacity,
+                       int* row_stats_chunks, float* col_stats, int col_stats_tiles, int* col_stats_rows,
+                       void* q8, long ldq8, const float* q8_inv_scale, unsigned int* q8_amax,
+                       const void* next_weights, size_t next_weights_bytes, void* stream) {
     if (col_stats_rows) *col_stats_rows = 0;
     ST_REQUIRE(x && W && y, "linear: null pointer");
     ST_REQUIRE(M > 0 && N > 0 && K > 0, "linear: bad shape M=%d N=%d K=%d", M, N, K);
@@ -45,7 +54,34 @@ extern "C" int st_linear(const void* x, const void* W, const void* bias, const v
 #endif
     take_hint(a, next_weights, next_weights_bytes);
     if (int e = check_epilogue("linear", a)) return e;
+    if (q8) {
+        ST_REQUIRE(st_dtype_is16(dtype), "linear: the e4m3 copy is emitted by the 16-bit kernels");
+        if (int e = check_q8("linear", a, q8, ldq8, q8_inv_scale, q8_amax)) return e;
+    }
     return run_dense(a, dtype, (hipStream_t)stream);
+}
+
+extern "C" int st_linear(const void* x, const void* W, const void* bias, const void* residual, const void* rowbias, void* y,
+                         int M, int N, int K, long lda, long ldc, long ldr, int rows_per_batch, int epilogue, int dtype,
+                         void* workspace, size_t workspace_bytes, float* row_stats, int row_stats_capacity,
+                         int* row_stats_chunks, float* col_stats, int col_stats_tiles, int* col_stats_rows,
+                         const void* next_weights, size_t next_weights_bytes, void* stream) {
+    return linear_impl(x, W, bias, residual, rowbias, y, M, N, K, lda, ldc, ldr, rows_per_batch, epilogue, dtype, workspace, workspace_bytes,
+                       row_stats, row_stats_capacity, row_stats_chunks, col_stats, col_stats_tiles, col_stats_rows, nullptr, 0, nullptr, nullptr,
+                       next_weights, next_weights_bytes, stream);
+}
+
+// st_linear that also leaves an e4m3 copy of its output for an fp8 consumer (see the header).
+extern "C" int st_linear_emit8(const void* x, const void* W, const void* bias, const void* residual, const void* rowbias, void* y,
+                               int M, int N, int K, long lda, long ldc, long ldr, int rows_per_batch, int epilogue, int dtype,
+                               void* workspace, size_t workspace_bytes, float* row_stats, int row_stats_capacity,
+                               int* row_stats_chunks, float* col_stats, int col_stats_tiles, int* col_stats_rows,
+                               void* q8, long ldq8, const float* q8_inv_scale, unsigned int* q8_amax,
+                               const void* next_weights, size_t next_weights_bytes, void* stream) {
+    ST_REQUIRE(q8, "linear_emit8: null e4m3 output");
+    return linear_impl(x, W, bias, residual, rowbias, y, M, N, K, lda, ldc, ldr, rows_per_batch, epilogue, dtype, workspace, workspace_bytes,
+                       row_stats, row_stats_capacity, row_stats_chunks, col_stats, col_stats_tiles, col_stats_rows, q8, ldq8, q8_inv_scale, q8_amax,
+                       next_weights, next_weights_bytes, stream);
 }
 
 // LayerNorm folded into the following Linear (or GEGLU projection): see GemmArgs::ln_c.
@@ -110,10 +146,42 @@ extern "C" int st_linear_fp8(const void* xq, const float* row_scale, const void*
     GemmArgs a = {};
     a.A = xq; a.W = Wq; a.bias = bias; a.residual = residual; a.C = y;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.epi = epilogue;
-    a.row_scale = row_scale; a.col_scale = w_scale;
+    a.row_scale = row_scale; a.col_scale = w_scale; a.rs_stride = 1;
     a.splitk = 1; a.partial = (float*)workspace; a.partial_bytes = workspace ? workspace_bytes : 0;
     take_hint(a, next_weights, next_weights_bytes);
     if (int e = check_epilogue("linear_fp8", a)) return e;
+    return gemm_dense_fp8(a, (hipStream_t)stream);
+}
+
+// The general fp8 GEMM of the compiled graph's fp8 plan (see the header): activation scale per row or per tensor, optional
+// folded LayerNorm, optional e4m3 copy of the output (with or without the bf16 output itself), row statistics for a following
+// folded LayerNorm.
+extern "C" int st_linear_fp8x(const void* xq, const float* a_scale, int a_scale_stride, const void* Wq, const float* w_scale,
+                              const void* bias, const void* residual, void* y, int M, int N, int K, long lda, long ldc, long ldr, int epilogue,
+                              const float* ln_stats, int ln_chunks, const float* ln_c, const float* ln_d, float ln_eps,
+                              float* row_stats, int row_stats_capacity, int* row_stats_chunks,
+                              void* q8, long ldq8, const float* q8_inv_scale, unsigned int* q8_amax,
+                              void* workspace, size_t workspace_bytes, const void* next_weights, size_t next_weights_bytes, void* stream) {
+    ST_REQUIRE(xq && a_scale && Wq && w_scale && (y || q8), "linear_fp8x: null pointer");
+    ST_REQUIRE(a_scale_stride == 0 || a_scale_stride == 1, "linear_fp8x: activation scale stride %d (0 = per tensor, 1 = per row)", a_scale_stride);
+    ST_REQUIRE(M > 0 && N > 0 && K > 0, "linear_fp8x: bad shape M=%d N=%d K=%d", M, N, K);
+    ST_REQUIRE(K % 128 == 0 && lda % 16 == 0, "linear_fp8x: K=%d must be a multiple of 128 and lda=%ld of 16", K, lda);
+    ST_REQUIRE(N % 4 == 0 && (!y || ldc % 4 == 0) && (!(epilogue & ST_EPI_RESIDUAL) || ldr % 4 == 0), "linear_fp8x: N, ldc, ldr must be multiples of 4");
+    ST_REQUIRE(!(epilogue & ST_EPI_ROWBIAS), "linear_fp8x: the row-bias epilogue is not supported");
+    ST_REQUIRE(((uintptr_t)xq | (uintptr_t)Wq | (uintptr_t)y | (uintptr_t)w_scale) % 16 == 0, "linear_fp8x: pointers must be 16-byte aligned");
+    ST_REQUIRE(!ln_c || (ln_d && ln_stats && ln_chunks > 0 && !(epilogue & ~ST_EPI_GEGLU)), "linear_fp8x: folded LayerNorm takes c, d, the row statistics and only the GEGLU flag (bias lives in d)");
+    ST_REQUIRE(y || (epilogue & ST_EPI_GEGLU) || ln_c, "linear_fp8x: an output without y is the GEGLU / folded-LayerNorm form");
+    GemmArgs a = {};
+    a.A = xq; a.W = Wq; a.bias = bias; a.residual = residual; a.C = y;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.epi = epilogue;
+    a.row_scale = a_scale; a.col_scale = w_scale; a.rs_stride = a_scale_stride;
+    a.ln_c = ln_c; a.ln_d = ln_d; a.ln_eps = ln_eps; a.ln_stats = ln_stats; a.ln_chunks = ln_chunks;
+    a.splitk = 1; a.partial = (float*)workspace; a.partial_bytes = workspace ? workspace_bytes : 0;
+    ST_REQUIRE(!row_stats || !(epilogue & ST_EPI_GEGLU), "linear_fp8x: row_stats with GEGLU is not supported");
+    a.row_stats = row_stats; a.stats_capacity = row_stats_capacity; a.stats_chunks_out = row_stats_chunks;
+    take_hint(a, next_weights, next_weights_bytes);
+    if (int e = check_epilogue("linear_fp8x", a)) return e;
+    if (int e = check_q8("linear_fp8x", a, q8, ldq8, q8_inv_scale, q8_amax)) return e;
     return gemm_dense_fp8(a, (hipStream_t)stream);
 }
 

@@ -46,6 +46,10 @@ struct GemmArgs {
     int panel_h;                 // tile rows per panel of the block order (see gemm_dma_kernel); >= 1
     // fp8 operands (st_linear_fp8): acc * row_scale[m] * col_scale[n] before anything else (col_scale has 2N entries with GEGLU)
     const float* row_scale; const float* col_scale;
+    int rs_stride;               // stride of row_scale: 1 = a scale per row, 0 = one scale for the whole activation tensor
+    // e4m3 copy of the output for an fp8 consumer (delayed per-tensor scaling, fp8.hip): q8[m][n] = e4m3(value * *q8_inv_scale),
+    // the launch's max |value| goes to the q8_amax partial slots; C may then be NULL (only the copy is wanted)
+    void* q8_out; long q8_ld; const float* q8_inv_scale; unsigned int* q8_amax;
     const void* next_w; size_t next_bytes;   // weights of the NEXT launch (host hint): touched during this epilogue
     int helper_blocks;           // > 0: that many extra blocks at the end of the grid (idle CUs) do the touching instead
     // st_ln_linear_xattn: the tile is the query block of ONE head; its epilogue runs the text-context attention on it
@@ -229,7 +233,7 @@ __device__ __forceinline__ void epilogue_compute4(const GemmArgs& p, int m, int 
 #pragma unroll
     for (int e = 0; e < 4; ++e) g[e] = g_in[e];
     if (p.col_scale) {                                 // fp8 operands: dequantisation scales
-        const float rs = p.row_scale[m];
+        const float rs = p.row_scale[(size_t)m * p.rs_stride];
         for (int e = 0; e < 4 && n + e < p.N; ++e) { v[e] *= rs * p.col_scale[n + e]; if (GEGLU) g[e] *= rs * p.col_scale[p.N + n + e]; }
     }
     if (p.ln_c) {                                      // folded LayerNorm: rank-1 correction per row / column
@@ -371,7 +375,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                     if (GEGLU) gsc[j] = *reinterpret_cast<const f32x4*>(p.col_scale + p.N + ncol[J0 + j]);
                 }
 #pragma unroll
-                for (int i = 0; i < TM; ++i) rsc[i] = p.row_scale[mrow[i]];
+                for (int i = 0; i < TM; ++i) rsc[i] = p.row_scale[(size_t)mrow[i] * p.rs_stride];
             }
             if (has_bias) {
 #pragma unroll
@@ -458,6 +462,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 #ifdef ST_PROBE
         if (ptimes) ptimes[0] = probe_now();
 #endif
+        const float q8_inv = p.q8_out ? *p.q8_inv_scale : 0.f;
+        float q8_max = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -465,7 +471,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                 if (mok[i] && nok[j]) {
                     const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                     Out4<T>::store((T*)p.C + (size_t)mrow[i] * p.ldc + ncol[j], v);
+                    if (p.q8_out) {            // e4m3 copy of the stored values (4 bytes per lane)
+                        q8_max = fmaxf(fmaxf(q8_max, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                        *reinterpret_cast<unsigned int*>((unsigned char*)p.q8_out + (size_t)mrow[i] * p.q8_ld + ncol[j]) =
+                            pack4_fp8(clamp_fp8(v[0] * q8_inv), clamp_fp8(v[1] * q8_inv), clamp_fp8(v[2] * q8_inv), clamp_fp8(v[3] * q8_inv));
+                    }
                 }
+        if (p.q8_out) publish_amax(p.q8_amax, q8_max, blockIdx.x * 8 + (threadIdx.x >> 6));
         retire_touches(touch_next);
     }
 #ifdef ST_PROBE
@@ -630,6 +642,8 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
             }
         }
     }
+    const float q8_inv = p.q8_out ? *p.q8_inv_scale : 0.f;         // e4m3 copy for an fp8 consumer (see GemmArgs::q8_out)
+    float q8_max = 0.f;
     float c1[VEC], c2[VEC];                                       // GroupNorm partials of this thread's columns over its rows
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { c1[e] = 0.f; c2[e] = 0.f; }
@@ -704,7 +718,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
                     }
                 }
                 if (has_scale) {
-                    const float rs = p.row_scale[m];
+                    const float rs = p.row_scale[(size_t)m * p.rs_stride];
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) { val[e] *= rs * cs[e]; if (GEGLU) g[e] *= rs * csg[e]; }
                 }
@@ -745,11 +759,28 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
                     s1 += w; s2 = fmaf(w, w, s2);
                     c1[e] += w; c2[e] = fmaf(w, w, c2[e]);
                 }
-                TO* dst = (TO*)p.C + (size_t)m * p.ldc + n;
-                if (wide) *reinterpret_cast<OV*>(dst) = out;
-                else {
+                if (p.C) {
+                    TO* dst = (TO*)p.C + (size_t)m * p.ldc + n;
+                    if (wide) *reinterpret_cast<OV*>(dst) = out;
+                    else {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) if (n + e < p.N) dst[e] = out[e];
+                        for (int e = 0; e < VEC; ++e) if (n + e < p.N) dst[e] = out[e];
+                    }
+                }
+                if constexpr (VEC == 8) {
+                    if (p.q8_out && col_full) {        // eight e4m3 bytes per thread, 64..256 contiguous bytes per row
+                        float a = 0.f;
+                        unsigned int w2[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const float x0 = Elem<TO>::to_f(out[4 * h]), x1 = Elem<TO>::to_f(out[4 * h + 1]), x2 = Elem<TO>::to_f(out[4 * h + 2]),
+                                        x3 = Elem<TO>::to_f(out[4 * h + 3]);
+                            a = fmaxf(fmaxf(a, fmaxf(fabsf(x0), fabsf(x1))), fmaxf(fabsf(x2), fabsf(x3)));
+                            w2[h] = pack4_fp8(clamp_fp8(x0 * q8_inv), clamp_fp8(x1 * q8_inv), clamp_fp8(x2 * q8_inv), clamp_fp8(x3 * q8_inv));
+                        }
+                        q8_max = fmaxf(q8_max, a);
+                        *reinterpret_cast<u32x2*>((unsigned char*)p.q8_out + (size_t)m * p.q8_ld + n) = u32x2{w2[0], w2[1]};
+                    }
                 }
                 if (emit_rows) rstat[rl * VPR + v] = make_float2(s1, s2);
             } else if (emit_rows && worker && rl < CH) {
@@ -791,6 +822,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
             if (n0 + col < p.N) reinterpret_cast<float2*>(p.col_stats)[(size_t)tile_m * p.N + n0 + col] = make_float2(a1, a2);
         }
     }
+    if (p.q8_out) publish_amax(p.q8_amax, q8_max, blockIdx.x * (NT / 64) + (threadIdx.x >> 6));
     retire_touches(touch_next);
 #ifdef ST_PROBE
     if (ptimes) ptimes[1] = probe_now();
@@ -2139,7 +2171,6 @@ static void launch_dma(const GemmArgs& a, hipStream_t st) {
     if constexpr (!CONV) {
         const bool geglu = a.epi & ST_EPI_GEGLU;
         constexpr bool PAIRS = (BN % 32 == 0);                  // GEGLU: value and gate halves of the tile are whole accumulator tiles
-        if constexpr (sizeof(T) != 1)
         if (a.ln_c) {          // LayerNorm-folded variants (never split over K: the row statistics need all of K)
             if constexpr (PAIRS) {
                 if (geglu) { launch_dma_one<T, BM, BN, WGM, WGN, STAGES, U, false, true, true>(a, st, cdiv(a.N, BN / 2)); return; }

@@ -111,6 +111,7 @@ class ExecContext:
         self.hinting = False         # True only inside step(): one-off passes (context / time tables) stay out of the plan
         self._ws = {}
         self.derived = {}
+        self.fp8 = None              # Fp8Scales of the fp8 plan (delayed per-tensor scaling), created on first use
 
     def gemm_workspace(self, device: torch.device) -> torch.Tensor:
         key = (device.type, device.index)
@@ -149,6 +150,52 @@ class ExecContext:
     def __exit__(self, *exc):
         _tls.stack.pop()
         return False
+
+
+FP8_MAX_TENSORS = 512       # e4m3 activation tensors one compiled module may track (fixed: captured graphs hold the addresses)
+FP8_AMAX_SLOTS = 256         # partial maxima per tensor (csrc/common.h ST_FP8_AMAX_SLOTS)
+FP8_MARGIN = 2.0             # head room of a scale over the previous step's maximum (values beyond it saturate at +-448)
+
+
+class Fp8Scales:
+    """Delayed per-tensor scaling state of one compiled module: for every e4m3 activation tensor of the fp8 plan a scale
+    (what one e4m3 unit is worth), its inverse, and the partial maxima this step's producer leaves behind.  `update()` is the
+    ONE launch per step that turns the maxima into the next step's scales; `site(key)` hands out the tensor's index."""
+
+    def __init__(self, device):
+        self.scale = torch.full((FP8_MAX_TENSORS,), 1.0 / 16, dtype=torch.float32, device=device)       # until a first pass has measured
+        self.inv_scale = torch.full((FP8_MAX_TENSORS,), 16.0, dtype=torch.float32, device=device)
+        self.amax = torch.zeros((FP8_MAX_TENSORS, FP8_AMAX_SLOTS), dtype=torch.int32, device=device)
+        self.sites = {}
+        self.calibrated = False      # False until one whole forward has left its maxima (the first one runs twice)
+
+    def site(self, key) -> int:
+        i = self.sites.get(key)
+        if i is None:
+            if len(self.sites) >= FP8_MAX_TENSORS:
+                raise BackendError("fp8 plan: more e4m3 activation tensors than FP8_MAX_TENSORS")
+            i = self.sites[key] = len(self.sites)
+        return i
+
+    def update(self) -> None:
+        if self.sites:
+            _C.check(_C.load().st_fp8_update_scales(self.scale.data_ptr(), self.inv_scale.data_ptr(), self.amax.data_ptr(),
+                                                    len(self.sites), FP8_MARGIN, _C.stream_ptr()), "fp8_update_scales")
+
+
+class Fp8Act:
+    """An activation tensor as e4m3 bytes with ONE scale: q (M, K) uint8, the index of its scale in the context's Fp8Scales."""
+    __slots__ = ("q", "index", "shape")
+
+    def __init__(self, q: torch.Tensor, index: int, shape):
+        self.q, self.index, self.shape = q, index, tuple(shape)
+
+
+def fp8_scales(device) -> Fp8Scales:
+    ctx = current_context(device)
+    if ctx.fp8 is None:
+        ctx.fp8 = Fp8Scales(device)
+    return ctx.fp8
 
 
 class _StepScope:
@@ -342,11 +389,13 @@ class RowStats:
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, silu: bool = False,
-           geglu: bool = False, residual: Optional[torch.Tensor] = None, emit_stats: bool = False, emit_colstats: bool = False):
+           geglu: bool = False, residual: Optional[torch.Tensor] = None, emit_stats: bool = False, emit_colstats: bool = False,
+           emit_q8=None):
     """epilogue(x @ weight.T): +bias, then SiLU or GEGLU (weight has 2N rows), then +residual.
     With emit_stats the GEMM also writes the LayerNorm partials of its output rows and the call
     returns (out, RowStats).  With emit_colstats (x is (B, T, K): T tokens per image) it writes the GroupNorm partials
-    of its output columns and the call returns (out, ColStats or None)."""
+    of its output columns and the call returns (out, ColStats or None).  With emit_q8 (a site key of the fp8 plan) the
+    epilogue also leaves an e4m3 copy of the output under that tensor's delayed scale; the Fp8Act is appended to the result."""
     _C.require_device(x, weight, bias, residual)
     lib = _C.load()
     K = x.shape[-1]
@@ -391,11 +440,33 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
             cbuf, ctiles, crows = _colstats_buffer(M, N, x.device)
         # (any other rank: tokens were flattened, the image boundaries are unknown - no partials, the consumer
         # GroupNorm takes its own statistics pass, as for every other producer that cannot emit them)
-    _C.check(lib.st_linear(x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
-                    lda, N, ldr, rows_per_image, epi, _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(),
-                    _ptr(stats), 0 if stats is None else stats.shape[1],
-                    None if chunks is None else ctypes.byref(chunks), _ptr(cbuf), ctiles or 0,
-                    None if crows is None else ctypes.byref(crows), nxt_p, nxt_b, _C.stream_ptr()), "linear")
+    act8 = None
+    if emit_q8 is None:
+        _C.check(lib.st_linear(x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
+                        lda, N, ldr, rows_per_image, epi, _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(),
+                        _ptr(stats), 0 if stats is None else stats.shape[1],
+                        None if chunks is None else ctypes.byref(chunks), _ptr(cbuf), ctiles or 0,
+                        None if crows is None else ctypes.byref(crows), nxt_p, nxt_b, _C.stream_ptr()), "linear")
+    else:
+        sc = fp8_scales(x.device)
+        idx = sc.site(emit_q8)
+        q8 = torch.empty((M, N), dtype=torch.uint8, device=x.device)
+        act8 = Fp8Act(q8, idx, out.shape)
+        _C.check(lib.st_linear_emit8(x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
+                        lda, N, ldr, rows_per_image, epi, _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(),
+                        _ptr(stats), 0 if stats is None else stats.shape[1],
+                        None if chunks is None else ctypes.byref(chunks), _ptr(cbuf), ctiles or 0,
+                        None if crows is None else ctypes.byref(crows), q8.data_ptr(), N, sc.inv_scale[idx:].data_ptr(), sc.amax[idx:].data_ptr(),
+                        nxt_p, nxt_b, _C.stream_ptr()), "linear_emit8")
+    if act8 is not None:
+        if emit_colstats:
+            raise BackendError("linear: emit_q8 with emit_colstats is not supported")
+        if emit_stats:
+            if chunks.value <= 0:
+                raise BackendError("linear: this shape cannot emit LayerNorm row statistics (K must be a multiple of the K tile)")
+            dense = stats.view(-1)[:M * chunks.value * 2].view(M, chunks.value, 2)
+            return out, RowStats(dense, chunks.value), act8
+        return out, act8
     if emit_colstats:
         return out, (ColStats(cbuf, crows.value, N) if crows is not None and crows.value > 0 else None)
     if emit_stats:
@@ -553,6 +624,85 @@ def linear_fp8(x: "Fp8Rows", wq: torch.Tensor, w_scale: torch.Tensor, bias: Opti
     _C.check(lib.st_linear_fp8(x.q.data_ptr(), x.scale.data_ptr(), wq.data_ptr(), w_scale.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
                     M, N, K, K, N, ldr, epi, gws.data_ptr(), gws.numel(), nxt_p, nxt_b, _C.stream_ptr()), "linear_fp8")
     return out
+
+
+def linear_fp8x(x: "Fp8Act", wq: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor] = None, *, geglu: bool = False,
+                residual: Optional[torch.Tensor] = None, ln=None, emit_stats: bool = False, emit_q8=None, want_out: bool = True):
+    """The fp8 GEMM of the fp8 plan: epilogue((xq @ wq.T) * scale(x) * w_scale) with x an Fp8Act (ONE delayed scale for the whole
+    tensor).  `ln = (RowStats, c, d, eps)` folds the LayerNorm in front of the projection (x is then the e4m3 copy of the
+    un-normalised tensor).  Returns out [, RowStats] [, Fp8Act of the output]; with want_out=False only the Fp8Act."""
+    _C.require_device(x.q, wq, w_scale, bias, residual)
+    lib = _C.load()
+    import ctypes
+    M, K = x.q.shape
+    if wq.dtype != torch.uint8 or wq.dim() != 2 or wq.shape[1] != K or w_scale.numel() != wq.shape[0]:
+        raise BackendError("linear_fp8x: weight must be (N, K) e4m3 bytes (uint8) with one fp32 scale per row")
+    N = wq.shape[0] // 2 if geglu else wq.shape[0]
+    dev = wq.device
+    sc = fp8_scales(dev)
+    out = torch.empty(*x.shape[:-1], N, dtype=torch.bfloat16, device=dev) if want_out else None
+    if not want_out and emit_q8 is None:
+        raise BackendError("linear_fp8x: nothing to compute (no output, no e4m3 copy)")
+    epi = 0
+    if bias is not None:
+        epi |= _C.EPI_BIAS
+        bias = bias if bias.dtype == torch.bfloat16 else bias.to(torch.bfloat16)
+    if geglu:
+        epi |= _C.EPI_GEGLU
+    ldr = 0
+    if residual is not None:
+        if not want_out or residual.shape != out.shape or residual.dtype != torch.bfloat16:
+            raise BackendError("linear_fp8x: residual must match the bf16 output")
+        residual, _, ldr = _rows2d(residual)
+        epi |= _C.EPI_RESIDUAL
+    st_in = c = d = None
+    eps = 0.0
+    if ln is not None:
+        st_in, c, d, eps = ln
+        if bias is not None:
+            raise BackendError("linear_fp8x: with a folded LayerNorm the bias lives in d")
+    stats = chunks = None
+    if emit_stats:
+        cap = min(STATS_MAX_CHUNKS, (N + 63) // 64)
+        stats = torch.empty((M, cap, 2), dtype=torch.float32, device=dev)
+        chunks = ctypes.c_int(0)
+    q8 = act8 = None
+    idx_out = 0
+    if emit_q8 is not None:
+        idx_out = sc.site(emit_q8)
+        q8 = torch.empty((M, N), dtype=torch.uint8, device=dev)
+        act8 = Fp8Act(q8, idx_out, tuple(x.shape[:-1]) + (N,))
+    gws = _gemm_workspace(dev)
+    nxt_p, nxt_b = _next_weights(wq)
+    _C.check(lib.st_linear_fp8x(x.q.data_ptr(), sc.scale[x.index:].data_ptr(), 0, wq.data_ptr(), w_scale.data_ptr(), _ptr(bias), _ptr(residual),
+                                _ptr(out), M, N, K, K, N, ldr, epi,
+                                None if st_in is None else st_in.buf.data_ptr(), 0 if st_in is None else st_in.chunks, _ptr(c), _ptr(d), float(eps),
+                                _ptr(stats), 0 if stats is None else stats.shape[1], None if chunks is None else ctypes.byref(chunks),
+                                _ptr(q8), N, None if q8 is None else sc.inv_scale[idx_out:].data_ptr(), None if q8 is None else sc.amax[idx_out:].data_ptr(),
+                                gws.data_ptr(), gws.numel(), nxt_p, nxt_b, _C.stream_ptr()), "linear_fp8x")
+    res = []
+    if want_out:
+        res.append(out)
+    if emit_stats:
+        if chunks.value <= 0:
+            raise BackendError("linear_fp8x: this shape cannot emit LayerNorm row statistics")
+        res.append(RowStats(stats.view(-1)[:M * chunks.value * 2].view(M, chunks.value, 2), chunks.value))
+    if act8 is not None:
+        res.append(act8)
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+@torch.no_grad()
+def fold_layer_norm_fp8(gamma: torch.Tensor, beta: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+    """fold_layer_norm for the fp8 GEMM: (e4m3 bytes of W * diag(gamma), per-channel scales, c = row sums of the DEQUANTISED
+    folded weights, d = W beta + bias), c / d fp32."""
+    wf = weight.float() * gamma.float()[None, :]
+    wq, ws = quantize_weight_fp8(wf)
+    c = (wq.view(torch.float8_e4m3fn).float().sum(dim=1) * ws).contiguous()
+    d = weight.float() @ beta.float()
+    if bias is not None:
+        d = d + bias.float()
+    return wq, ws, c, d.contiguous()
 
 
 # ----------------------------------------------------------------------------- attention

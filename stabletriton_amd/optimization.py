@@ -18,7 +18,7 @@ from torch import fx, nn
 from . import _C, ops
 from .optimizers import (dedupe_pure_calls, fuse_token_residual, fuse_attention, fuse_geglu, fuse_geglu_into_linear, fuse_groupnorm_stats, fuse_layernorm_into_linear, fuse_query_projection_into_attention, fuse_residual_adds,
                          fuse_shared_input_linears,
-                         fuse_temb_add, fuse_timesteps, split_context, split_region, keep_channels_last, make_dynamic_graphed_callable, quantize_projections_fp8, remove_dropout,
+                         fuse_temb_add, fuse_timesteps, split_context, split_region, keep_channels_last, make_dynamic_graphed_callable, plan_fp8, remove_dropout,
                          replace_conv, replace_group_norm, replace_group_norm_activation, replace_layer_norm,
                          replace_linear, replace_linear_activ)
 
@@ -48,11 +48,11 @@ def replace_backend(gm: fx.GraphModule, fuse: bool = True, fp8: bool = False, xa
         stats["residual_adds"] = fuse_residual_adds(gm)
         stats["token_residuals"] = fuse_token_residual(gm)
         stats["shared_input_gemms"] = fuse_shared_input_linears(gm)
-        if fp8:      # transformer-block projections on the fp8 matrix pipe (claims its LayerNorms before the bf16 folding does)
-            stats["fp8_projections"] = quantize_projections_fp8(gm)
         stats["layer_norm_in_gemm"] = fuse_layernorm_into_linear(gm)
         stats["query_projection_in_attention"] = fuse_query_projection_into_attention(gm) if xattn_fusion else 0
         stats["group_norm_stats"] = fuse_groupnorm_stats(gm) if gn_stats else 0
+        if fp8:      # the three big projections of every transformer block on the fp8 matrix pipe, fed by e4m3 copies their
+            stats["fp8_plan"] = plan_fp8(gm)      # producers' epilogues leave (no quantisation launches): optimizers/plan_fp8.py
     stats["channels_last_views"] = keep_channels_last(gm)
     gm.graph.eliminate_dead_code()
     gm.graph.lint()
@@ -66,8 +66,9 @@ def run_compiler(gm: fx.GraphModule) -> fx.GraphModule:
 
 
 def optimize_model(model: nn.Module, cuda_graph: bool = True, fuse: bool = True, fp8: bool = False) -> fx.GraphModule:
-    """`fp8=True` (addition, BASELINE config #5): the transformer-block projections of a bf16 model run with OCP e4m3
-    operands on the fp8 matrix pipe (optimizers/quantize_fp8.py); everything else is unchanged."""
+    """`fp8=True` (addition, BASELINE config #5): the q|k|v, GEGLU and feed-forward output projections of a bf16 model's
+    transformer blocks run with OCP e4m3 operands on the fp8 matrix pipe, fed by e4m3 copies their producers' epilogues
+    leave under delayed per-tensor scales (optimizers/plan_fp8.py); everything else is unchanged."""
     # same preconditions as the reference (optimization.py:29-33), for ROCm
     assert torch.cuda.is_available(), "a ROCm GPU is required to use stabletriton_amd"
     major, _ = torch.cuda.get_device_capability()
@@ -87,17 +88,39 @@ def optimize_model(model: nn.Module, cuda_graph: bool = True, fuse: bool = True,
     # the compiled module owns its mutable host state (split-K workspace, next-weights plan, derived weight buffers):
     # two compiled modules, or two streams each driving their own, never share any (ops.ExecContext)
     gm.exec_context = ops.ExecContext()
+    gm.fp8_plan = bool(fp8 and fuse)
     if not (fuse and _install_context_split(gm)):
         plain = gm.forward
 
         def forward(*args, **kwargs):
-            with gm.exec_context.step():
-                return plain(*args, **kwargs)
+            return _run_step(gm, lambda: plain(*args, **kwargs))
 
         gm.forward = forward
     if cuda_graph:
         gm.forward = make_dynamic_graphed_callable(gm.forward, before_replay=gm.exec_context.refresh_derived)
     return gm
+
+
+def _run_step(gm: fx.GraphModule, core):
+    """One UNet evaluation inside the module's step scope.  With the fp8 plan: the launch that turns the previous step's
+    maxima into this step's scales goes first; the very first evaluation runs twice (its first pass only measures)."""
+    ectx = gm.exec_context
+    with ectx.step():
+        if not getattr(gm, "fp8_plan", False):
+            return core()
+        if ectx.fp8 is None or not ectx.fp8.calibrated:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("fp8 plan: run one eager step before capturing (DenoiseLoop.capture and the graph cache do)")
+            out = core()                             # measuring pass: e4m3 copies under the initial scales, true maxima recorded
+            if ectx.plan is not None:
+                ectx.plan.reset()
+            if ectx.fp8 is None:                     # nothing in this module qualified for the plan
+                gm.fp8_plan = False
+                return out
+            ectx.fp8.calibrated = True
+    with ectx.step():
+        ectx.fp8.update()
+        return core()
 
 
 def _install_context_split(gm: fx.GraphModule) -> bool:
@@ -135,8 +158,7 @@ def _install_context_split(gm: fx.GraphModule) -> bool:
 
     if time_module is None:
         def forward_with_context(sample, timesteps, context_cache, added_cond_kwargs, **kwargs):
-            with ectx.step():
-                return core(sample, timesteps, None, context_cache, added_cond_kwargs, **kwargs)
+            return _run_step(gm, lambda: core(sample, timesteps, None, context_cache, added_cond_kwargs, **kwargs))
     else:
         gm.time_module = time_module
         gm.rewrite_stats["time_outputs"] = len([n for n in time_module.graph.nodes if n.op == "output"][0].args[0])
@@ -149,8 +171,8 @@ def _install_context_split(gm: fx.GraphModule) -> bool:
         def forward_with_context(sample, timesteps, context_cache, added_cond_kwargs, time_cache=None, **kwargs):
             if time_cache is None:
                 time_cache = precompute_time(sample, timesteps, added_cond_kwargs)
-            with ectx.step():             # one pass over the same GEMMs in the same order: each launch warms the next one's weights
-                return core(sample, timesteps, None, context_cache, added_cond_kwargs, time_cache, **kwargs)
+            # one pass over the same GEMMs in the same order: each launch warms the next one's weights
+            return _run_step(gm, lambda: core(sample, timesteps, None, context_cache, added_cond_kwargs, time_cache, **kwargs))
 
         gm.precompute_time = precompute_time
 

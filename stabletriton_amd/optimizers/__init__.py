@@ -9,7 +9,7 @@ from .replace_timesteps import fuse_timesteps
 from .fuse_epilogues import fuse_geglu_into_linear, fuse_residual_adds, fuse_temb_add
 from .fuse_projections import (fuse_layernorm_into_linear, fuse_query_projection_into_attention, fuse_shared_input_linears, split_context,
                                split_region)
-from .quantize_fp8 import quantize_projections_fp8
+from .plan_fp8 import plan_fp8
 from .fuse_groupnorm_stats import fuse_groupnorm_stats
 from .cleanup import dedupe_pure_calls, fuse_token_residual
 from .layout import keep_channels_last

@@ -104,15 +104,21 @@ def test_linear_fp8_rejects_bad_shapes(gpu):
 
 # ---------------------------------------------------------------------------------- the compiled UNet in fp8 mode
 def test_fp8_mode_claims_the_transformer_projections():
-    """Host logic (no launch): 443 projections of SDXL-base go to the fp8 path, and with them every LayerNorm."""
+    """Host logic (no launch): the fp8 plan of SDXL-base - the q|k|v and GEGLU projections (140, LayerNorm folded) and the
+    feed-forward output projections (70) on the fp8 pipe, fed by 210 e4m3 copies their producers' epilogues leave;
+    no LayerNorm and no quantisation launch in the graph."""
     from torch import fx
     from stabletriton_amd.optimization import replace_backend
     from stabletriton_amd.unet import SDXL_BASE, UNet2DConditionModel
     with torch.device("meta"):
         m = UNet2DConditionModel(SDXL_BASE).to(torch.bfloat16)
     gm = replace_backend(fx.symbolic_trace(m), fp8=True)
-    assert gm.rewrite_stats["fp8_projections"] == 443 and gm.rewrite_stats["layer_norm_in_gemm"] == 0
-    assert not [n for n in gm.graph.nodes if n.op == "call_function" and getattr(n.target, "__name__", "") == "layer_norm_wrapper"]
+    plan = gm.rewrite_stats["fp8_plan"]
+    assert plan == {"ln_projections": 140, "ff_out_projections": 70, "emitting_producers": 140, "e4m3_tensors": 210}
+    assert gm.rewrite_stats["layer_norm_in_gemm"] == 210
+    names = [getattr(n.target, "__name__", "") for n in gm.graph.nodes if n.op == "call_function"]
+    assert "layer_norm_wrapper" not in names and "ln_linear_wrapper" not in names
+    assert names.count("ln_linear_fp8_wrapper") == 140 and names.count("linear_fp8_residual_wrapper") == 70
 
 
 def test_fp8_unet_step_vs_oracle(gpu, sdxl_bf16_pair):
@@ -134,3 +140,96 @@ def test_fp8_unet_step_vs_oracle(gpu, sdxl_bf16_pair):
     rms = float((out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
     print(f"F1 with fp8 projections: relative rms error {rms:.3f}, max abs {float((out - ref).abs().max()):.3f} (|ref| max {float(ref.abs().max()):.2f})")
     assert torch.isfinite(out).all() and rms <= 0.39          # 1.5 x the measured 0.262
+
+
+# ---------------------------------------------------------------------------------- the fp8 plan: e4m3 copies from epilogues, delayed scales
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,K,N,res", [(1024, 1280, 1280, True), (4096, 640, 640, True), (256, 256, 3840, False), (100, 128, 136, False)])
+def test_epilogue_leaves_e4m3_copy_and_maximum(gpu, dtype, M, K, N, res):
+    """st_linear_emit8: the copy is e4m3(clamp(stored value / scale)) bit for bit, the partial slots hold the launch's max |value|,
+    and st_fp8_update_scales turns them into margin * amax / 448 and clears them (both epilogue forms: 128 x 64 tiles keep the
+    fragment layout, 3840 columns take the staged one)."""
+    import torch.nn.functional as F
+    with ops.ExecContext(hints=False) as ctx:
+        x, w, b = rnd("e8.x", (M, K)).to(gpu, dtype), (rnd("e8.w", (N, K)) * K ** -0.5).to(gpu, dtype), rnd("e8.b", (N,)).to(gpu, dtype)
+        r = (rnd("e8.r", (M, N)) * 3).to(gpu, dtype) if res else None
+        out, stats, act = ops.linear(x, w, b, residual=r, emit_stats=True, emit_q8=("t", 0))
+        plain = ops.linear(x, w, b, residual=r)
+        assert torch.equal(out, plain)                                   # the copy does not disturb the output
+        sc = ctx.fp8
+        inv = float(sc.inv_scale[act.index])
+        want = (out.float() * inv).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+        assert torch.equal(act.q, want)
+        amax = sc.amax[act.index].view(torch.float32).max()
+        assert float(amax) == float(out.float().abs().max())
+        sc.update()
+        torch.cuda.synchronize()
+        assert abs(float(sc.scale[act.index]) - ops.FP8_MARGIN * float(amax) / 448) <= 1e-6 * float(amax)
+        assert int(sc.amax[act.index].abs().max()) == 0
+        assert abs(float(sc.inv_scale[act.index]) * float(sc.scale[act.index]) - 1) < 1e-6
+
+
+@pytest.mark.parametrize("M,K,N,geglu", [(1024, 1280, 3840, False), (1024, 1280, 5120, True), (4096, 640, 2560, True), (256, 128, 64, False)])
+def test_ln_linear_fp8x_against_same_operands(gpu, M, K, N, geglu):
+    """The fp8 GEMM with the LayerNorm folded (the q|k|v / GEGLU projections of the plan) is exact on what it is given: against
+    fp32 arithmetic on the dequantised e4m3 copy and weights; and within the fp8 tolerance of the unquantised bf16 path."""
+    import torch.nn.functional as F
+    from oracle import unet_oracle as orc
+    dtype = torch.bfloat16
+    with ops.ExecContext(hints=False) as ctx:
+        x0 = (rnd("l8x.x", (M, K)) * 1.7 + 0.4).to(gpu, dtype)
+        g, be = (rnd("l8x.g", (K,)) * 0.2 + 1.0).to(gpu, dtype), (rnd("l8x.b", (K,)) * 0.2).to(gpu, dtype)
+        rows = 2 * N if geglu else N
+        w, bias = (rnd("l8x.w", (rows, K)) * K ** -0.5).to(gpu, dtype), rnd("l8x.bias", (rows,)).to(gpu, dtype)
+        eye = torch.eye(K, device=gpu, dtype=dtype)
+        for _ in range(2):                                   # second pass: the scale comes from the first pass's maximum
+            xg, stats, act = ops.linear(x0, eye, None, emit_stats=True, emit_q8=("t", 1))
+            ctx.fp8.update()
+        xg, stats, act = ops.linear(x0, eye, None, emit_stats=True, emit_q8=("t", 1))
+        wq, ws, c, d = ops.fold_layer_norm_fp8(g, be, w, bias)
+        out = ops.linear_fp8x(act, wq, ws, None, geglu=geglu, ln=(stats, c, d, 1e-5))
+        scale = float(ctx.fp8.scale[act.index])
+        xdq = act.q.view(torch.float8_e4m3fn).float() * scale
+        assert float((xdq - xg.float()).abs().max()) <= 2.0 ** -4 * float(xg.float().abs().max())     # in range: nothing saturated
+        mean, var = xg.float().mean(1, keepdim=True), xg.float().var(1, unbiased=False, keepdim=True)
+        acc = xdq @ dq_weight(wq, ws).t()
+        same = torch.rsqrt(var + 1e-5) * (acc - mean * c[None, :]) + d[None, :]
+        ref = F.linear(F.layer_norm(xg.float(), (K,), g.float(), be.float(), 1e-5), w.float(), bias.float())
+        if geglu:
+            same, ref = orc.geglu(same.cpu()).to(gpu), orc.geglu(ref.cpu()).to(gpu)
+        e_same = rel_err(out, same)
+        rms = float((out.float() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        print(f"ln_linear_fp8x M={M} K={K} N={N} geglu={geglu}: vs same operands {e_same:.2e}, vs unquantised rms {rms:.3f}")
+        assert e_same <= 1.2e-2 and rms <= FP8_RMS_TOL * (1.5 if geglu else 1.0)
+
+
+def test_fp8_feed_forward_pair_keeps_e4m3_between_the_two_gemms(gpu):
+    """GEGLU projection -> feed-forward output projection of the plan: the first leaves ONLY an e4m3 copy, the second consumes it
+    and emits x', its row statistics and its own copy."""
+    import torch.nn.functional as F
+    from oracle import unet_oracle as orc
+    M, C = 1024, 1280
+    dtype = torch.bfloat16
+    with ops.ExecContext(hints=False) as ctx:
+        x0 = (rnd("ff8.x", (M, C)) * 1.3).to(gpu, dtype)
+        g, be = (rnd("ff8.g", (C,)) * 0.2 + 1.0).to(gpu, dtype), (rnd("ff8.b", (C,)) * 0.2).to(gpu, dtype)
+        w1, b1 = (rnd("ff8.w1", (8 * C, C)) * C ** -0.5).to(gpu, dtype), rnd("ff8.b1", (8 * C,)).to(gpu, dtype)
+        w2, b2 = (rnd("ff8.w2", (C, 4 * C)) * (4 * C) ** -0.5).to(gpu, dtype), rnd("ff8.b2", (C,)).to(gpu, dtype)
+        eye = torch.eye(C, device=gpu, dtype=dtype)
+        w1q, w1s, c, d = ops.fold_layer_norm_fp8(g, be, w1, b1)
+        w2q, w2s = ops.quantize_weight_fp8(w2)
+        for _ in range(3):
+            xg, stats, act = ops.linear(x0, eye, None, emit_stats=True, emit_q8=("t", 2))
+            h8 = ops.linear_fp8x(act, w1q, w1s, None, geglu=True, ln=(stats, c, d, 1e-5), emit_q8=("t", 3), want_out=False)
+            assert isinstance(h8, ops.Fp8Act) and h8.q.shape == (M, 4 * C)
+            y, st2, y8 = ops.linear_fp8x(h8, w2q, w2s, b2, residual=xg, emit_stats=True, emit_q8=("t", 4))
+            ctx.fp8.update()
+        h = orc.geglu(F.linear(F.layer_norm(xg.float(), (C,), g.float(), be.float(), 1e-5), w1.float(), b1.float()).cpu()).to(gpu)
+        ref = F.linear(h, w2.float(), b2.float()) + xg.float()
+        delta = (y.float() - xg.float()), (ref - xg.float())
+        rms = float((delta[0] - delta[1]).pow(2).mean().sqrt() / delta[1].pow(2).mean().sqrt())
+        print(f"fp8 feed-forward pair: relative rms error of the block's update {rms:.3f}")
+        assert rms <= 0.1
+        s = st2.buf.double().sum(1)
+        assert torch.allclose(s[:, 0], y.double().sum(1), rtol=1e-4, atol=1e-2)
+        assert torch.equal(y8.q, (y.float() * float(ctx.fp8.inv_scale[y8.index])).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8))

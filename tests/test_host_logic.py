@@ -214,6 +214,6 @@ def test_refiner_spec_and_fp8_pass_counts():
     st = gm.rewrite_stats
     # 4 + 4 layers x 2 resnets on the middle levels down, 3 on the way up, + 4 in the middle block = 8 + 8 + 12 + 12 + 4
     assert st["layer_norm"] == 3 * 44 and st["attention"] == 2 * 44 and st["geglu_in_gemm"] == 44
-    assert st["fp8_projections"] > 0 and st["layer_norm_in_gemm"] == 0
+    assert st["fp8_plan"]["ln_projections"] == 2 * 44 and st["fp8_plan"]["ff_out_projections"] == 44 and st["layer_norm_in_gemm"] == 3 * 44
     left = [n for n in gm.graph.nodes if n.op == "call_module"]
     assert not [n for n in left if isinstance(gm.get_submodule(n.target), (nn.Linear, nn.Conv2d, nn.GroupNorm, nn.LayerNorm, nn.Dropout))]

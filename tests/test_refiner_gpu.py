@@ -98,7 +98,7 @@ def test_sdxl_refiner_img2img_1024_fp8(gpu):
     for fp8 in (False, True):
         gm = optimize_model(m, cuda_graph=False, fp8=fp8)
         if fp8:
-            assert gm.rewrite_stats["fp8_projections"] > 200
+            assert gm.rewrite_stats["fp8_plan"]["ln_projections"] == 88
         loop = DenoiseLoop(gm, 1, 128, torch.bfloat16, gpu, euler_discrete_tables(50), cross_dim=SDXL_REFINER.cross_dim,
                            pooled_dim=SDXL_REFINER.pooled_dim, mode="step", n_time_ids=SDXL_REFINER.n_time_ids)
         loop.set_conditioning(x["encoder_hidden_states"].to(gpu, torch.bfloat16), x["text_embeds"].to(gpu, torch.bfloat16),
