@@ -570,7 +570,9 @@ struct EpiGeom {
     static constexpr int RPI = NT / VPR;                         // rows per pass of the block
     static constexpr int LDW = BN + 4;                           // floats per staged row (+16 B: the 16 row lanes of a fragment hit different banks)
     static constexpr int ROW_BYTES = LDW * 4 + VPR * 8;          // + one (sum, sum of squares) partial per vector (row statistics)
-    static constexpr int MAX_IT = 4;                             // passes per chunk (bounds the residual / row-bias vectors in flight)
+    // passes per chunk (bounds the residual / row-bias vectors in flight; the 256 x 256 tile still holds up to 96 accumulator
+    // registers of later chunks while it works on one: two passes keep it from spilling)
+    static constexpr int MAX_IT = (BM * BN >= 256 * 256) ? 2 : 4;
     static constexpr int ch0 = (LDS_BYTES / ROW_BYTES) / 16 * 16;
     static constexpr int ch1 = ch0 < MAX_IT * RPI ? ch0 : (MAX_IT * RPI) / 16 * 16;
     static constexpr int ch2 = ch1 < BM ? ch1 : BM;
@@ -1642,8 +1644,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
 // =============================================================================
 template <typename T, bool GEGLU, bool LNF, int BN = 256, int WGM = 2, int WGN = 4>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
-    static_assert(sizeof(T) == 2, "16-bit elements (bf16 / f16)");
-    constexpr int BM = 256, KB = 64, NW = 8;
+    static_assert(sizeof(T) <= 2, "16-bit elements (bf16 / f16) or e4m3 bytes");
+    constexpr int BM = 256, NW = 8;
+    constexpr int KB = 128 / (int)sizeof(T);           // elements per 128-byte row of a K tile: 64, or 128 e4m3
+    constexpr int EV = 16 / (int)sizeof(T);            // elements per 16-byte chunk
+    typedef typename OutT<T>::type TO;                // element type of C, bias, residual (e4m3 operands: bf16)
     static_assert(WGM * WGN == NW && BM % (32 * WGM) == 0 && BN % (16 * WGN) == 0 && (!GEGLU || BN % 32 == 0), "wave layout");
     constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 16, TN = WTN / 16;
     constexpr int TMH = TM / 2, TN0 = (TN + 1) / 2, TN1 = TN - TN0;          // accumulator tiles per A half / in B0 / in B1
@@ -1653,6 +1658,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     constexpr int TILE_B = 2 * HA + HB0 + HB1;                                // A0 A1 B0 B1
     constexpr int BNO = GEGLU ? BN / 2 : BN;
     typedef typename Mma<T>::Frag Frag;
+    // what one ds_read_b128 delivers: a whole MFMA operand of 32 k (16-bit), or half of the 128-k operand of the e4m3 instruction
+    typedef typename std::conditional<sizeof(T) == 1, u32x4, Frag>::type Half;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const lnrows = lds + 2 * TILE_B;            // LayerNorm (mean, rstd) per row
     char* const dump = lnrows + BM * 8;               // target of the dummy DMAs
@@ -1696,10 +1703,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int idx = (2 * wave + e) * 8 + lr;
-        a_src[e] = Ap + (size_t)(m0 + (idx / (TMH * 16)) * WTM + (idx % (TMH * 16))) * p.lda + lc * 8;       // half h adds TMH*16 rows
+        a_src[e] = Ap + (size_t)(m0 + (idx / (TMH * 16)) * WTM + (idx % (TMH * 16))) * p.lda + lc * EV;      // half h adds TMH*16 rows
         const int i0 = idx < RB0 ? idx : 0, i1 = idx < RB1 ? idx : 0;
-        b0_src[e] = Wp + w_row((i0 / (TN0 * 16)) * WTN + (i0 % (TN0 * 16))) * p.K + lc * 8;
-        b1_src[e] = Wp + w_row((i1 / (TN1 * 16)) * WTN + TN0 * 16 + (i1 % (TN1 * 16))) * p.K + lc * 8;
+        b0_src[e] = Wp + w_row((i0 / (TN0 * 16)) * WTN + (i0 % (TN0 * 16))) * p.K + lc * EV;
+        b1_src[e] = Wp + w_row((i1 / (TN1 * 16)) * WTN + TN0 * 16 + (i1 % (TN1 * 16))) * p.K + lc * EV;
     }
     const size_t a_half = (size_t)(TMH * 16) * p.lda;
     const int nk = p.K / KB;
@@ -1785,30 +1792,36 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
         b0_off[kk] = 2 * HA + (wn * TN0 * 16 + r16) * 128 + sw;
         b1_off[kk] = 2 * HA + HB0 + (wn * TN1 * 16 + r16) * 128 + sw;
     }
-    Frag fa[TMH][2], fb0[TN0][2], fb1[TN1][2];        // A half in use, B0 (kept for the fourth phase), B1
+    // A half in use, B0 (kept for the fourth phase), B1.  16-bit: [..][kk] = the operand of k step kk; e4m3: [..][0] is the whole
+    // 128-k operand, assembled from the two 16-byte reads (chunks q and q + 4) where they land
+    constexpr int NKK = sizeof(T) == 1 ? 1 : 2;
+    Frag fa[TMH][NKK], fb0[TN0][NKK], fb1[TN1][NKK];
+    auto read_op = [&](const char* base, const int (&off)[2], Frag (&dst)[NKK]) {
+        if constexpr (sizeof(T) == 1) {
+            const Half lo = *reinterpret_cast<const Half*>(base + off[0]), hi = *reinterpret_cast<const Half*>(base + off[1]);
+            dst[0] = Frag{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) dst[kk] = *reinterpret_cast<const Frag*>(base + off[kk]);
+        }
+    };
     auto read_a = [&](const char* tile, int h) {
 #pragma unroll
-        for (int i = 0; i < TMH; ++i)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fa[i][kk] = *reinterpret_cast<const Frag*>(tile + h * HA + i * 2048 + a_off[kk]);
+        for (int i = 0; i < TMH; ++i) read_op(tile + h * HA + i * 2048, a_off, fa[i]);
     };
     auto read_b0 = [&](const char* tile) {
 #pragma unroll
-        for (int j = 0; j < TN0; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fb0[j][kk] = *reinterpret_cast<const Frag*>(tile + j * 2048 + b0_off[kk]);
+        for (int j = 0; j < TN0; ++j) read_op(tile + j * 2048, b0_off, fb0[j]);
     };
     auto read_b1 = [&](const char* tile) {
 #pragma unroll
-        for (int j = 0; j < TN1; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fb1[j][kk] = *reinterpret_cast<const Frag*>(tile + j * 2048 + b1_off[kk]);
+        for (int j = 0; j < TN1; ++j) read_op(tile + j * 2048, b1_off, fb1[j]);
     };
     auto quadrant = [&](auto mh_, auto nh_) {
         constexpr int mh = decltype(mh_)::value, nh = decltype(nh_)::value;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
             for (int i = 0; i < TMH; ++i) {
                 if constexpr (nh == 0) {
@@ -1866,14 +1879,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     if (wave < 4) __builtin_amdgcn_s_barrier();      // barrier counts of the two halves are equal again
     wait_vmcnt<0>();                                  // no LDS-DMA may outlive the workgroup's LDS allocation
     __builtin_amdgcn_s_barrier();
-    staged_epilogue<T, BM, BN, WGM, WGN, TM, TN, GEGLU, 2 * TILE_B, !LNF>(p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds,
+    staged_epilogue<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, 2 * TILE_B, !LNF>(p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds,
                                                                         reinterpret_cast<const float2*>(lnrows));
 }
 
 // the two shapes of gemm8p: 256 (2 x 4 waves) and 160 columns (4 x 2 waves)
-static inline bool gemm8p_applies(const GemmArgs& a, int bn) {
+static inline bool gemm8p_applies(const GemmArgs& a, int bn, int kb = 64) {
     const long n_rows = (a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N;
-    return a.M % 256 == 0 && n_rows % bn == 0 && a.K % 64 == 0 && a.K >= 256 && a.N % 8 == 0 &&
+    return a.M % 256 == 0 && n_rows % bn == 0 && a.K % kb == 0 && a.K >= 2 * kb && a.N % 8 == 0 &&
            !(a.epi & ST_EPI_ROWBIAS) && (!a.row_stats || !(a.epi & ST_EPI_GEGLU));
 }
 
@@ -2272,7 +2285,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
                 if (cost < best) { best = cost; cfg = c.cfg; sk = k_; }
             }
         }
-        if constexpr (!CONV && sizeof(T) == 2) {
+        if constexpr (!CONV && sizeof(T) <= 2) {
             // the eight-phase kernel (256 x 256 or 256 x 160 tiles): no K split, whole rounds of 256 blocks.  A K step costs
             // ~1.65 us for 256 x 256 x 64 and ~1.5 us for 256 x 160 x 64 (measured, tools/gemm8p_check.py: a phase is paced by
             // its load segment - two LDS-DMA issues per wave, the fragment reads, two barriers - more than by its 12-16 MFMAs,
@@ -2282,8 +2295,9 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             // predicted 37; QKV at batch 4 72 us against 55), so this kernel also takes the near ties.
             const int f = forced_cfg();
             double c256 = 1e30, c160 = 1e30;
-            if (gemm8p_applies(a, 256)) c256 = (double)((tiles(256, 256) + 255) / 256) * (nk * 1.65 + 4.0);
-            if (gemm8p_applies(a, 160)) c160 = (double)((tiles(256, 160) + 255) / 256) * (nk * 1.52 + 4.0);
+            // (e4m3: a K step is 128 k - the same bytes, fragment reads and phases as a 64-k bf16 step, twice the product)
+            if (gemm8p_applies(a, 256, KB)) c256 = (double)((tiles(256, 256) + 255) / 256) * (nk * 1.65 + 4.0);
+            if (gemm8p_applies(a, 160, KB)) c160 = (double)((tiles(256, 160) + 255) / 256) * (nk * 1.52 + 4.0);
             const bool take256 = f == CFG_256x256_8P || (f < 0 && c256 <= c160 && c256 < 1.3 * best);
             const bool take160 = f == CFG_256x160_8P || (f < 0 && c160 < c256 && c160 < 1.3 * best);
             if (take256 && c256 < 1e29) { gemm8p_launch<T, 256, 2, 4>(a, st); return st_check_launch(who); }

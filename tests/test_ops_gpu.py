@@ -120,7 +120,9 @@ def test_linear_geglu(gpu, dtype, M, K, F_):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,K,N,geglu", [(1024, 1280, 3840, False), (100, 640, 640, False), (256, 640, 2560, True),
-                                         (1024, 1280, 5120, True), (77, 128, 64, False), (4096, 640, 1920, False)])
+                                         (1024, 1280, 5120, True), (77, 128, 64, False), (4096, 640, 1920, False),
+                                         # batch-4 shapes: the 256 x 256 eight-phase kernel (plain and GEGLU; the batch-1 GEGLU shape above takes 256 x 160)
+                                         (4096, 1280, 3840, False), (4096, 1280, 5120, True)])
 def test_ln_linear(gpu, dtype, M, K, N, geglu):
     """LayerNorm folded into the consuming GEMM == LayerNorm followed by Linear (/GEGLU)."""
     x = rnd("lnl.x", (M, K)) * 1.7 + 0.4                  # rows with a non-zero mean
