@@ -9,6 +9,7 @@ python bench.py > $o/bench_default.json 2> $o/bench_default.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/bench_driver_call.json 2>/dev/null
 python bench.py --steps 50 --warmup 50 --no-cpu-baseline --no-extras --dtype fp16 > $o/bench_fp16.json 2>/dev/null
 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extras --batch 2 > $o/bench_b2.json 2>/dev/null
+python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extras --batch 2 --fp8 > $o/bench_b2_fp8.json 2>/dev/null
 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extras --batch 4 > $o/bench_b4.json 2>/dev/null
 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extras --batch 4 --dtype fp16 > $o/bench_b4_fp16.json 2>/dev/null
 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extras --batch 4 --fp8 > $o/bench_b4_fp8.json 2>/dev/null
