@@ -80,7 +80,19 @@ def _linear_fp8(a):
     return "linear_fp8", 2.0 * M * rows * K, float(M * K + rows * K + 2 * M * N), f"M={M} N={N} K={K} fp8 epi={epi}"
 
 
-DECODERS = {"st_linear": _linear, "st_ln_linear": _ln_linear, "st_ln_linear_xattn": _ln_linear_xattn, "st_attention": _attention,
+def _linear_emit8(a):
+    fam, fl, by, tag = _linear(a)
+    return fam, fl, by + float(a[6] * a[7]), tag + " +e4m3 copy"
+
+
+def _linear_fp8x(a):
+    M, N, K, epi = a[8], a[9], a[10], a[14]
+    rows = 2 * N if epi & GEGLU else N
+    out_bytes = (2 * M * N if a[7] else 0) + (M * N if a[24] else 0)
+    return "linear_fp8", 2.0 * M * rows * K, float(M * K + rows * K + out_bytes), f"M={M} N={N} K={K} fp8x epi={epi}" + (" ln" if a[17] else "") + (" +e4m3 copy" if a[24] else "")
+
+
+DECODERS = {"st_linear": _linear, "st_linear_emit8": _linear_emit8, "st_linear_fp8x": _linear_fp8x, "st_ln_linear": _ln_linear, "st_ln_linear_xattn": _ln_linear_xattn, "st_attention": _attention,
             "st_conv2d": _conv2d, "st_group_norm": _group_norm, "st_group_norm_from_stats": _group_norm_from_stats,
             "st_layer_norm": _layer_norm, "st_geglu": _geglu, "st_quantize_fp8": _quantize_fp8,
             "st_layer_norm_quantize_fp8": _ln_quantize_fp8, "st_linear_fp8": _linear_fp8}
