@@ -572,7 +572,11 @@ struct EpiGeom {
     static constexpr int ROW_BYTES = LDW * 4 + VPR * 8;          // + one (sum, sum of squares) partial per vector (row statistics)
     // passes per chunk (bounds the residual / row-bias vectors in flight; the 256 x 256 tile still holds up to 96 accumulator
     // registers of later chunks while it works on one: two passes keep it from spilling)
+#ifdef ST_EPI_MAXIT_256T
+    static constexpr int MAX_IT = (BM * BN >= 256 * 256) ? (NT == 256 ? ST_EPI_MAXIT_256T : 2) : 4;
+#else
     static constexpr int MAX_IT = (BM * BN >= 256 * 256) ? 2 : 4;
+#endif
     static constexpr int ch0 = (LDS_BYTES / ROW_BYTES) / 16 * 16;
     static constexpr int ch1 = ch0 < MAX_IT * RPI ? ch0 : (MAX_IT * RPI) / 16 * 16;
     static constexpr int ch2 = ch1 < BM ? ch1 : BM;
@@ -583,10 +587,19 @@ struct EpiGeom {
     static_assert(RPI * BNO * 8 <= LDS_BYTES, "staged epilogue: column-statistics scratch");
 };
 
-template <typename TO, int BM, int BN, int WGM, int WGN, int TM, int TN, bool GEGLU, int LDS_BYTES, bool STATS, typename ColMap>
-__device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int tile_n, int wm, int r16, int q,
-                                                ColMap colmap, char* lds, const float2* lnrows, unsigned long long* ptimes = nullptr) {
+// What the epilogue of a launch has to do, as bits: MODE >= 0 instantiates staged_epilogue_impl for exactly that set with the
+// tile known to lie inside the matrix and every pointer / stride 16-byte aligned (no per-element tests, no wide / narrow
+// branches, no code for the absent features); MODE = -1 is the general instance that reads the set from the arguments.
+// Why: with run-time flags the bias-only epilogue of a 256 x 256 tile took 24,000 cycles, the bare accumulators -> LDS ->
+// 16-byte stores round trip 9,400 (tools/gemm_probe.py): twelve microseconds of a 48-us launch went into testing flags.
+enum { EPI_F_BIAS = 1, EPI_F_RES = 2, EPI_F_RB = 4, EPI_F_LN = 8, EPI_F_SILU = 16, EPI_F_SCALE = 32, EPI_F_ROWS = 64, EPI_F_COLS = 128,
+       EPI_F_Q8 = 256, EPI_F_NOC = 512 };
+
+template <typename TO, int BM, int BN, int WGM, int WGN, int TM, int TN, bool GEGLU, int LDS_BYTES, bool STATS, int MODE, typename ColMap>
+__device__ __forceinline__ void staged_epilogue_impl(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int tile_n, int wm, int r16, int q,
+                                                     ColMap colmap, char* lds, const float2* lnrows, unsigned long long* ptimes = nullptr) {
     (void)ptimes;
+    constexpr bool FAST = MODE >= 0;
     constexpr int NT = WGM * WGN * 64;
     constexpr int VEC = EpiVec<TO>::N;
     typedef typename EpiVec<TO>::type OV;
@@ -594,19 +607,33 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
     constexpr int BNO = G::BNO, VPR = G::VPR, RPI = G::RPI, LDW = G::LDW, CH = G::CH, NCH = G::NCH, IT = G::IT;
     constexpr int WTM = BM / WGM;
     const int t = threadIdx.x;
+#ifdef ST_PROBE
+    if (ptimes) ptimes[2] = probe_now();
+#endif
     const bool worker = t < RPI * VPR;
     const int rloc = t / VPR, v = t - rloc * VPR;
     const int n = n0 + v * VEC;                                   // first output column of this thread
-    const bool has_bias = p.epi & ST_EPI_BIAS, has_res = p.epi & ST_EPI_RESIDUAL, has_rb = p.epi & ST_EPI_ROWBIAS;
-    const bool has_ln = p.ln_c != nullptr, do_silu = p.epi & ST_EPI_SILU, has_scale = p.col_scale != nullptr;
-    const bool col_full = n + VEC <= p.N;                         // all VEC columns exist
-    const bool col_any = worker && n < p.N;
+#ifdef ST_EPI_MIN       // timing experiment: the bare round trip accumulators -> LDS -> 16-byte stores
+    constexpr bool has_bias = false, has_res = false, has_rb = false, has_ln = false, do_silu = false, has_scale = false;
+#else
+    const bool has_bias = FAST ? bool(MODE & EPI_F_BIAS) : bool(p.epi & ST_EPI_BIAS), has_res = FAST ? bool(MODE & EPI_F_RES) : bool(p.epi & ST_EPI_RESIDUAL);
+    const bool has_rb = FAST ? bool(MODE & EPI_F_RB) : bool(p.epi & ST_EPI_ROWBIAS), has_ln = FAST ? bool(MODE & EPI_F_LN) : (p.ln_c != nullptr);
+    const bool do_silu = FAST ? bool(MODE & EPI_F_SILU) : bool(p.epi & ST_EPI_SILU), has_scale = FAST ? bool(MODE & EPI_F_SCALE) : (p.col_scale != nullptr);
+#endif
+    const bool has_q8 = FAST ? bool(MODE & EPI_F_Q8) : (p.q8_out != nullptr), has_c = FAST ? !(MODE & EPI_F_NOC) : (p.C != nullptr);
+    const bool col_full = FAST || n + VEC <= p.N;                 // all VEC columns exist
+    const bool col_any = worker && (FAST || n < p.N);
     const bool wide = col_full && (p.ldc % VEC == 0) && ((uintptr_t)p.C & 15) == 0;             // 16-byte stores
     const bool wide_res = col_full && (p.ldr % VEC == 0) && ((uintptr_t)p.residual & 15) == 0;
     const bool wide_rb = col_full && (p.N % VEC == 0) && ((uintptr_t)p.rowbias & 15) == 0;
     float* tile = reinterpret_cast<float*>(lds);
     float2* rstat = reinterpret_cast<float2*>(lds + (size_t)CH * LDW * 4);
-    const bool emit_rows = STATS && p.row_stats != nullptr, emit_cols = STATS && p.col_stats != nullptr && (p.N & 3) == 0;
+#ifdef ST_EPI_MIN
+    constexpr bool emit_rows = false, emit_cols = false;
+#else
+    const bool emit_rows = FAST ? bool(MODE & EPI_F_ROWS) : (STATS && p.row_stats != nullptr);
+    const bool emit_cols = FAST ? bool(MODE & EPI_F_COLS) : (STATS && p.col_stats != nullptr && (p.N & 3) == 0);
+#endif
 
     // ---- per-column operands: once per thread ------------------------------------------------------
     // (kept as loaded - raw vectors - and converted where they are used: a conversion placed here would make the compiler
@@ -618,8 +645,8 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
     if (col_any) {
         const TO* __restrict__ bias = (const TO*)p.bias;
         // whole vectors whenever the columns exist and the arrays keep 16-byte alignment (N % VEC == 0 covers the gate half too)
-        const bool vec_cols = col_full && (p.N % VEC == 0) && (!has_bias || ((uintptr_t)bias & 15) == 0) &&
-                              (!has_ln || (((uintptr_t)p.ln_c | (uintptr_t)p.ln_d) & 15) == 0) && (!has_scale || ((uintptr_t)p.col_scale & 15) == 0);
+        const bool vec_cols = FAST || (col_full && (p.N % VEC == 0) && (!has_bias || ((uintptr_t)bias & 15) == 0) &&
+                                       (!has_ln || (((uintptr_t)p.ln_c | (uintptr_t)p.ln_d) & 15) == 0) && (!has_scale || ((uintptr_t)p.col_scale & 15) == 0));
         auto ldf = [&](const float* a, float (&dst)[VEC]) {       // VEC floats
 #pragma unroll
             for (int e4 = 0; e4 < VEC; e4 += 4) {
@@ -644,7 +671,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
             }
         }
     }
-    const float q8_inv = p.q8_out ? *p.q8_inv_scale : 0.f;         // e4m3 copy for an fp8 consumer (see GemmArgs::q8_out)
+    const float q8_inv = has_q8 ? *p.q8_inv_scale : 0.f;           // e4m3 copy for an fp8 consumer (see GemmArgs::q8_out)
     float q8_max = 0.f;
     float c1[VEC], c2[VEC];                                       // GroupNorm partials of this thread's columns over its rows
 #pragma unroll
@@ -655,6 +682,10 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
     //  waves' last fragment reads and tail DMAs against the tile that is about to overwrite the ring)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the last fragment reads of the K loop have returned ...
     __builtin_amdgcn_s_barrier();                                 // ... in every wave: the ring may be overwritten
+#ifdef ST_PROBE
+    if (ptimes) ptimes[3] = probe_now();
+#endif
+    // (unrolled over the chunks: static parking conditions; a rolled general instance measured 20 % slower and spilled)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int row_lo = c * CH;                                // first tile row of this chunk
@@ -665,12 +696,12 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
         for (int k = 0; k < IT; ++k) {
             const int row = row_lo + rloc + k * RPI;
             const int m = m0 + row;
-            rok[k] = col_any && (rloc + k * RPI < CH) && row < BM && m < p.M;
+            rok[k] = (rloc + k * RPI < CH) && row < BM && (FAST ? worker : (col_any && m < p.M));
             const int mc = rok[k] ? m : m0;                       // clamped
             res[k] = OV{}; rbv[k] = OV{};
             if (has_res) {
                 const TO* rr = (const TO*)p.residual + (size_t)mc * p.ldr + (col_any ? n : n0);
-                if (wide_res) res[k] = *reinterpret_cast<const OV*>(rr);
+                if (FAST || wide_res) res[k] = *reinterpret_cast<const OV*>(rr);
                 else {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) res[k][e] = rr[(n + e < p.N) ? e : 0];
@@ -678,7 +709,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
             }
             if (has_rb) {
                 const TO* rb = (const TO*)p.rowbias + (size_t)(mc / p.rows_per_batch) * p.N + (col_any ? n : n0);
-                if (wide_rb) rbv[k] = *reinterpret_cast<const OV*>(rb);
+                if (FAST || wide_rb) rbv[k] = *reinterpret_cast<const OV*>(rb);
                 else {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) rbv[k][e] = rb[(n + e < p.N) ? e : 0];
@@ -755,22 +786,29 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
                 OV out;
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    out[e] = Elem<TO>::from_f(val[e]);
-                    const float w = (n + e < p.N) ? Elem<TO>::to_f(out[e]) : 0.f;      // what is stored
-                    s1 += w; s2 = fmaf(w, w, s2);
-                    c1[e] += w; c2[e] = fmaf(w, w, c2[e]);
+                for (int e = 0; e < VEC; ++e) out[e] = Elem<TO>::from_f(val[e]);
+                if (emit_rows || emit_cols) {                     // (block-uniform: five VALU instructions per element that most launches skip)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float w = (FAST || n + e < p.N) ? Elem<TO>::to_f(out[e]) : 0.f;      // what is stored
+                        s1 += w; s2 = fmaf(w, w, s2);
+                        c1[e] += w; c2[e] = fmaf(w, w, c2[e]);
+                    }
                 }
-                if (p.C) {
+                if (has_c) {
                     TO* dst = (TO*)p.C + (size_t)m * p.ldc + n;
-                    if (wide) *reinterpret_cast<OV*>(dst) = out;
+                    if (FAST || wide) *reinterpret_cast<OV*>(dst) = out;
                     else {
 #pragma unroll
                         for (int e = 0; e < VEC; ++e) if (n + e < p.N) dst[e] = out[e];
                     }
                 }
                 if constexpr (VEC == 8) {
-                    if (p.q8_out && col_full) {        // eight e4m3 bytes per thread, 64..256 contiguous bytes per row
+#ifdef ST_EPI_MIN
+                    if (false) {
+#else
+                    if (has_q8 && col_full) {
+#endif        // eight e4m3 bytes per thread, 64..256 contiguous bytes per row
                         float a = 0.f;
                         unsigned int w2[2];
 #pragma unroll
@@ -789,6 +827,9 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
                 rstat[rl * VPR + v] = make_float2(0.f, 0.f);
             }
         }
+#ifdef ST_PROBE
+        if (ptimes && c == 0) ptimes[4] = probe_now();
+#endif
         if (emit_rows) {
             // LayerNorm partials of the rows just stored: one float2 per (row, N tile), the row's vectors added in order
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -806,6 +847,9 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this chunk's LDS reads are done before the next one is parked
             __builtin_amdgcn_s_barrier();
         }
+#ifdef ST_PROBE
+        if (ptimes && c == 0) ptimes[5] = probe_now();
+#endif
     }
     if (emit_cols) {
         // GroupNorm partials: per output column (sum, sum of squares) over the tile's rows - the RPI row slots through LDS,
@@ -824,11 +868,68 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
             if (n0 + col < p.N) reinterpret_cast<float2*>(p.col_stats)[(size_t)tile_m * p.N + n0 + col] = make_float2(a1, a2);
         }
     }
-    if (p.q8_out) publish_amax(p.q8_amax, q8_max, blockIdx.x * (NT / 64) + (threadIdx.x >> 6));
+    if (has_q8) publish_amax(p.q8_amax, q8_max, blockIdx.x * (NT / 64) + (threadIdx.x >> 6));
     retire_touches(touch_next);
 #ifdef ST_PROBE
     if (ptimes) ptimes[1] = probe_now();
 #endif
+}
+
+// The dispatcher: the feature set of the launch (block-uniform), and whether this tile qualifies for a specialised instance.
+// Listed are the sets the big launches of the denoise step use; anything else (and every ragged or unaligned tile) takes the
+// general instance.  SCALED: e4m3 operands (row / column scales in the epilogue).
+template <typename TO, int BM, int BN, int WGM, int WGN, int TM, int TN, bool GEGLU, int LDS_BYTES, bool STATS, bool SCALED = false, typename ColMap>
+__device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int tile_n, int wm, int r16, int q,
+                                                ColMap colmap, char* lds, const float2* lnrows, unsigned long long* ptimes = nullptr) {
+#if !defined(ST_EPI_GENERIC_ONLY)
+    constexpr int VEC = EpiVec<TO>::N;
+    constexpr int BNO = GEGLU ? BN / 2 : BN;
+    const bool has_res = p.epi & ST_EPI_RESIDUAL, has_rb = p.epi & ST_EPI_ROWBIAS;
+    const bool aligned = (m0 + BM <= p.M) && (n0 + BNO <= p.N) && (p.N % VEC == 0) &&
+                         (p.C == nullptr || ((p.ldc % VEC == 0) && ((uintptr_t)p.C & 15) == 0)) &&
+                         (!has_res || ((p.ldr % VEC == 0) && ((uintptr_t)p.residual & 15) == 0)) && (!has_rb || ((uintptr_t)p.rowbias & 15) == 0) &&
+                         ((((uintptr_t)p.bias | (uintptr_t)p.ln_c | (uintptr_t)p.ln_d | (uintptr_t)p.col_scale) & 15) == 0) &&
+                         (p.q8_out == nullptr || VEC == 8);
+    if (aligned) {
+        const int flags = ((p.epi & ST_EPI_BIAS) ? EPI_F_BIAS : 0) | (has_res ? EPI_F_RES : 0) | (has_rb ? EPI_F_RB : 0) | (p.ln_c ? EPI_F_LN : 0) |
+                          ((p.epi & ST_EPI_SILU) ? EPI_F_SILU : 0) | (p.col_scale ? EPI_F_SCALE : 0) | ((STATS && p.row_stats) ? EPI_F_ROWS : 0) |
+                          ((STATS && p.col_stats && (p.N & 3) == 0) ? EPI_F_COLS : 0) | (p.q8_out ? EPI_F_Q8 : 0) | (p.C ? 0 : EPI_F_NOC);
+#define ST_EPI_CASE(M)                                                                                                                          \
+    case (M):                                                                                                                                   \
+        staged_epilogue_impl<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, LDS_BYTES, STATS, (M)>(p, acc, m0, n0, tile_n, wm, r16, q, colmap, lds, lnrows, ptimes); \
+        return;
+        // (a folded LayerNorm carries the projection's bias in its d vector: no BIAS bit)
+        if constexpr (!STATS && !SCALED) {
+            switch (flags) { ST_EPI_CASE(EPI_F_LN) ST_EPI_CASE(EPI_F_LN | EPI_F_BIAS) default: break; }
+        } else if constexpr (!STATS && SCALED) {
+            switch (flags) {
+                ST_EPI_CASE(EPI_F_LN | EPI_F_SCALE)
+                ST_EPI_CASE(EPI_F_LN | EPI_F_SCALE | EPI_F_Q8 | EPI_F_NOC)
+                default: break;
+            }
+        } else if constexpr (STATS && !SCALED) {
+            switch (flags) {
+                ST_EPI_CASE(EPI_F_BIAS)
+                ST_EPI_CASE(EPI_F_BIAS | EPI_F_RES)
+                ST_EPI_CASE(EPI_F_BIAS | EPI_F_ROWS)
+                ST_EPI_CASE(EPI_F_BIAS | EPI_F_RES | EPI_F_ROWS)
+                ST_EPI_CASE(EPI_F_BIAS | EPI_F_RES | EPI_F_ROWS | EPI_F_Q8)
+                ST_EPI_CASE(EPI_F_BIAS | EPI_F_COLS)
+                ST_EPI_CASE(EPI_F_BIAS | EPI_F_RB | EPI_F_COLS)
+                ST_EPI_CASE(EPI_F_BIAS | EPI_F_RES | EPI_F_COLS)
+                default: break;
+            }
+        } else {
+            switch (flags) {
+                ST_EPI_CASE(EPI_F_BIAS | EPI_F_SCALE | EPI_F_RES | EPI_F_ROWS)
+                ST_EPI_CASE(EPI_F_BIAS | EPI_F_SCALE | EPI_F_RES | EPI_F_ROWS | EPI_F_Q8)
+                default: break;
+            }
+        }
+#undef ST_EPI_CASE
+    }
+#endif
+    staged_epilogue_impl<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, LDS_BYTES, STATS, -1>(p, acc, m0, n0, tile_n, wm, r16, q, colmap, lds, lnrows, ptimes);
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, bool CONV, bool GEGLU>
@@ -1577,11 +1678,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         // staged epilogue (through LDS): the wide tiles, every GEGLU tile, the implicit-GEMM convs
         // (the LayerNorm (mean, rstd) rows sit behind the ring, which the staged tile takes over)
 #ifdef ST_PROBE
-        unsigned long long ept[2] = {0, 0};
+        unsigned long long ept[6] = {0, 0, 0, 0, 0, 0};
 #else
         unsigned long long* const ept = nullptr;
 #endif
-        staged_epilogue<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, STAGES * STAGE, !LNF>(
+        staged_epilogue<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, STAGES * STAGE, !LNF, sizeof(T) == 1>(
             p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds, reinterpret_cast<const float2*>(lds + STAGES * STAGE), ept);
 #ifdef ST_PROBE
         pr_x = ept[0] - pr_end; pr_d = ept[1] - ept[0];
@@ -1600,7 +1701,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wm, wn, r16, q, split, mean, rstd);
     } else {
 #ifdef ST_PROBE
-        unsigned long long ept[2] = {0, 0};
+        unsigned long long ept[6] = {0, 0, 0, 0, 0, 0};
         gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n, ept);
         pr_x = ept[0] - pr_end; pr_d = ept[1] - ept[0];
 #else
@@ -1666,6 +1767,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+#ifdef ST_PROBE
+    unsigned long long pr_k0 = probe_now(), pr_rt0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pr_rt0)::"memory");
+#endif
     const int wm = wave / WGN, wn = wave - wm * WGN;
     const int tiles_m = p.M / BM;
     const int nblk = gridDim.x - p.helper_blocks, bid = blockIdx.x;
@@ -1848,6 +1953,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0)
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
+    PROBE_STAMP(pr_start)
     for (int kt = 0; kt < nk; ++kt) {
         const char* tile = lds + (kt & 1) * TILE_B;
         // phase 0: (A0, B0); refill B1 of tile kt+1 (last read in phase 1 of tile kt-1)
@@ -1879,8 +1985,33 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     if (wave < 4) __builtin_amdgcn_s_barrier();      // barrier counts of the two halves are equal again
     wait_vmcnt<0>();                                  // no LDS-DMA may outlive the workgroup's LDS allocation
     __builtin_amdgcn_s_barrier();
-    staged_epilogue<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, 2 * TILE_B, !LNF>(p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds,
+#ifdef ST_8P_NOEPI      // timing experiment: K loop only
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+#endif
+#ifdef ST_PROBE
+    PROBE_STAMP(pr_end)
+    unsigned long long ept[6] = {0, 0, 0, 0, 0, 0};
+    staged_epilogue<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, 2 * TILE_B, !LNF, sizeof(T) == 1>(p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds,
+                                                                        reinterpret_cast<const float2*>(lnrows), ept);
+    {
+        PROBE_STAMP(pr_fin)
+        if (p.probe && lane == 0) {
+            unsigned long long pr_rt1;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pr_rt1)::"memory");
+            unsigned long long* o = p.probe + ((size_t)blockIdx.x * NW + wave) * 12;
+            // epilogue: entry -> first barrier, -> chunk 0 parked + barrier, -> chunk 0 processed, -> its closing barrier, rest
+            o[0] = ept[3] - ept[2]; o[1] = ept[0] - ept[3]; o[2] = ept[4] - ept[0]; o[3] = pr_end - pr_start; o[4] = pr_fin - pr_end;
+            o[5] = ept[5] - ept[4]; o[6] = ept[1] - ept[5]; o[7] = nk; o[8] = pr_start - pr_k0; o[9] = pr_rt0; o[10] = pr_rt1; o[11] = 1;
+        }
+    }
+#else
+    staged_epilogue<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, 2 * TILE_B, !LNF, sizeof(T) == 1>(p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds,
                                                                         reinterpret_cast<const float2*>(lnrows));
+#endif
 }
 
 // the two shapes of gemm8p: 256 (2 x 4 waves) and 160 columns (4 x 2 waves)
@@ -1922,6 +2053,17 @@ static void gemm8p_launch(const GemmArgs& a, hipStream_t st) {
     const bool geglu = a.epi & ST_EPI_GEGLU;
     if (a.ln_c) { if (geglu) gemm8p_go<T, true, true, BN, WGM, WGN>(a, st); else gemm8p_go<T, false, true, BN, WGM, WGN>(a, st); }
     else { if (geglu) gemm8p_go<T, true, false, BN, WGM, WGN>(a, st); else gemm8p_go<T, false, false, BN, WGM, WGN>(a, st); }
+}
+
+#include "gemm4w.h"
+// (instantiated in gemm_4w.hip only)
+void gemm4w_bf16(const GemmArgs& a, hipStream_t st);
+void gemm4w_f16(const GemmArgs& a, hipStream_t st);
+void gemm4w_fp8(const GemmArgs& a, hipStream_t st);
+template <typename T> static inline void gemm4w_call(const GemmArgs& a, hipStream_t st) {
+    if constexpr (std::is_same<T, bf16>::value) gemm4w_bf16(a, st);
+    else if constexpr (std::is_same<T, f16>::value) gemm4w_f16(a, st);
+    else gemm4w_fp8(a, st);
 }
 
 // =============================================================================
@@ -2202,7 +2344,7 @@ static void launch_dma(const GemmArgs& a, hipStream_t st) {
 // overrides the heuristic for A/B runs.
 enum { CFG_64x64_S4 = 0, CFG_64x64_S8 = 1, CFG_64x64_S4_U2 = 2, CFG_128x64_S4 = 3, CFG_128x64_S3_U2 = 4,
        CFG_128x128_S3 = 5, CFG_64x64_S3 = 6, CFG_64x64_W8 = 7, CFG_128x64_W8 = 8, CFG_128x128_W8 = 9,
-       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_128x320_W8 = 23, CFG_128x256_W8 = 24, CFG_64x320_W8 = 25, CFG_64x80_W4 = 26, CFG_128x80_W8 = 27, CFG_128x160_W8 = 28, CFG_128x128_N4_S2 = 29, CFG_128x64_N4_S3 = 30, CFG_64x128_N4_S3 = 31, CFG_256x160_W8_S2 = 32, CFG_COUNT, CFG_256x256_8P = 100, CFG_256x160_8P = 101 };
+       CFG_64x128_W8 = 10, CFG_64x128_W8_S6 = 11, CFG_128x64_W8_S6 = 12, CFG_128x128_W8_S4 = 13, CFG_64x64_W8_S8 = 14, CFG_64x128_W8_U2 = 15, CFG_128x64_W8_U2 = 16, CFG_64x64_W8_U2 = 17, CFG_256x256_W8 = 18, CFG_256x128_W8 = 19, CFG_128x128_W8_S2 = 20, CFG_128x64_W8_S3 = 21, CFG_64x128_W8_S3 = 22, CFG_128x320_W8 = 23, CFG_128x256_W8 = 24, CFG_64x320_W8 = 25, CFG_64x80_W4 = 26, CFG_128x80_W8 = 27, CFG_128x160_W8 = 28, CFG_128x128_N4_S2 = 29, CFG_128x64_N4_S3 = 30, CFG_64x128_N4_S3 = 31, CFG_256x160_W8_S2 = 32, CFG_COUNT, CFG_256x256_8P = 100, CFG_256x160_8P = 101, CFG_256x256_4W = 102 };
 
 static inline int cfg_bn(int cfg) {
     switch (cfg) {
@@ -2298,6 +2440,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             // (e4m3: a K step is 128 k - the same bytes, fragment reads and phases as a 64-k bf16 step, twice the product)
             if (gemm8p_applies(a, 256, KB)) c256 = (double)((tiles(256, 256) + 255) / 256) * (nk * 1.65 + 4.0);
             if (gemm8p_applies(a, 160, KB)) c160 = (double)((tiles(256, 160) + 255) / 256) * (nk * 1.52 + 4.0);
+            if (f == CFG_256x256_4W && gemm4w_applies(a, KB)) { gemm4w_call<T>(a, st); return st_check_launch(who); }
             const bool take256 = f == CFG_256x256_8P || (f < 0 && c256 <= c160 && c256 < 1.3 * best);
             const bool take160 = f == CFG_256x160_8P || (f < 0 && c160 < c256 && c160 < 1.3 * best);
             if (take256 && c256 < 1e29) { gemm8p_launch<T, 256, 2, 4>(a, st); return st_check_launch(who); }

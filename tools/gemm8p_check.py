@@ -1,4 +1,4 @@
-"""Developer check of the 256x256 eight-phase GEMM against torch (fp32 reference on the bf16-rounded operands) and A/B
+"""Developer check of the 256-row GEMM kernels (eight-phase 256x256 / 256x160 = cfg 100 / 101, four-wave 256x256 = cfg 102) against torch (fp32 reference on the bf16-rounded operands) and A/B
 timing against the cost model's choice.  Needs the dev library:  tools/build_variant.sh dev -DST_DEV_CONFIGS  and
 ST_VARIANT=dev."""
 import ctypes
@@ -34,7 +34,7 @@ def check(M, K, N, geglu=False, ln=False, residual=False, stats=False):
     x, w, b = rnd(M, K), rnd(rows, K) * K ** -0.5, rnd(rows)
     res = rnd(M, N) if residual else None
     out = {}
-    for cfg in (100, 101, -1):
+    for cfg in (100, 101, 102, -1):
         force(cfg, -1)
         if ln:
             g, be = rnd(K) * 0.1 + 1.0, rnd(K) * 0.1
@@ -66,13 +66,11 @@ def check(M, K, N, geglu=False, ln=False, residual=False, stats=False):
         us = timeit(fn)
         out[cfg] = (err, us, extra)
     fl = 2.0 * M * K * rows
-    e8, u8, x8 = out[100]
-    e6, u6, x6 = out[101]
-    e0, u0, _ = out[-1]
-    print(f"M={M:6d} K={K:5d} N={N:5d} geglu={int(geglu)} ln={int(ln)} res={int(residual)} stats={int(stats)}: "
-          f"8p-256 err {e8:.2e} {u8:7.1f} us {fl / u8 / 1e6:7.1f} TF/s | 8p-160 err {e6:.2e} {u6:7.1f} us {fl / u6 / 1e6:7.1f} TF/s | "
-          f"model err {e0:.2e} {u0:7.1f} us {fl / u0 / 1e6:7.1f} TF/s{x8}{x6}", flush=True)
-    assert e8 < 2e-2 and e6 < 2e-2, "gemm8p result is wrong"
+    names = {100: "8p-256", 101: "8p-160", 102: "4w-256", -1: "model"}
+    print(f"M={M:6d} K={K:5d} N={N:5d} geglu={int(geglu)} ln={int(ln)} res={int(residual)} stats={int(stats)}: " +
+          " | ".join(f"{names[c]} err {out[c][0]:.2e} {out[c][1]:7.1f} us {fl / out[c][1] / 1e6:7.1f} TF/s" for c in out) +
+          "".join(out[c][2] for c in out), flush=True)
+    assert all(out[c][0] < 2e-2 for c in out), "a 256-row kernel's result is wrong"
     force(-1, -1)
 
 

@@ -25,6 +25,17 @@ for cfg in [int(c) for c in sys.argv[4:]] or [-1]:
     if len(used) == 0:
         print(f"cfg {cfg}: kernel writes no probe (not gemm_dma_kernel)"); continue
     nk = used[0, 7].item()
+    if used[0, 11].item() == 1:         # gemm8p_kernel: epilogue broken down
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): ops.linear(x, w, b)
+        e1.record(); torch.cuda.synchronize()
+        m = lambda c: used[:, c].mean().item()
+        print(f"M={M} K={K} N={N} cfg={cfg} (eight-phase): {e0.elapsed_time(e1) / 20 * 1e3:.1f} us eager; waves={len(used)} trips={int(nk)} cycles: prologue={m(8):.0f} loop={m(3):.0f} "
+              f"({m(3) / nk:.0f} per trip) epilogue={m(4):.0f} = operands+first barrier {m(0):.0f} + park chunk 0 + barrier {m(1):.0f} + process chunk 0 {m(2):.0f} + closing barrier {m(5):.0f} "
+              f"+ other chunks {m(6):.0f} | wall (100 MHz ticks -> us): first entry -> last entry {(used[:,9].max()-used[:,9].min())/100:.2f}, "
+              f"first entry -> last exit {(used[:,10].max()-used[:,9].min())/100:.2f}, mean block life {(used[:,10]-used[:,9]).mean()/100:.2f}")
+        continue
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20): ops.linear(x, w, b)
