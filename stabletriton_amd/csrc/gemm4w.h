@@ -49,17 +49,8 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const GemmArgs p) {
         retire_touches(sink);
         return;
     }
-    const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
-    const int tw = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    int tile_m, tile_n;
-    {
-        const int tiles_n_all = nblk / tiles_m;
-        const int per_panel = p.panel_h * tiles_n_all;
-        const int pn = tw / per_panel, rem = tw - pn * per_panel;
-        const int rows = min(p.panel_h, tiles_m - pn * p.panel_h);
-        tile_n = rem / rows;
-        tile_m = pn * p.panel_h + (rem - tile_n * rows);
-    }
+    const TileId tid = tile_of_block(p, bid, nblk);
+    const int tile_m = tid.tile_m, tile_n = tid.tile_n;
     const int m0 = tile_m * BM, n0 = tile_n * BNO;
     const char* const zeros = reinterpret_cast<const char*>(g_zero16);
 
@@ -278,10 +269,12 @@ static void gemm4w_go(const GemmArgs& a, hipStream_t st) {
     }
     const int main_blocks = tiles_m * tiles_n;
     b.splitk = 1;
+    fill_tile_map(b, tiles_m, tiles_n, 0);
     b.helper_blocks = (b.next_w && main_blocks <= 208) ? (256 - main_blocks > 96 ? 96 : 256 - main_blocks) : 0;
     b.stats_chunks = tiles_n;
     if (a.stats_chunks_out) *a.stats_chunks_out = a.row_stats ? b.stats_chunks : 0;
     if (!colstats_ok(a, 256, LNF)) b.col_stats = nullptr;
+    fill_next_per(b, main_blocks + b.helper_blocks);
     hipLaunchKernelGGL(kfn, dim3(main_blocks + b.helper_blocks), dim3(256), lds, st, b);
 }
 

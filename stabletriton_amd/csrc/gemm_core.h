@@ -44,6 +44,15 @@ struct GemmArgs {
     size_t partial_bytes;
     int* tile_counters;          // one arrival counter per output tile (zero between launches)
     int panel_h;                 // tile rows per panel of the block order (see gemm_dma_kernel); >= 1
+    // block -> tile map, prepared on the host (fill_tile_map).  Every wave of a block used to work it out with four integer
+    // divisions by launch constants, ~25 scalar instructions each on the CU's one scalar unit: with the 64-bit divisions
+    // of the K slices about 400 of the ~900 instructions in front of the first MFMA (2.4 us of a 12-us launch,
+    // tools/gemm_probe.py).  Now: multiply-high by magic numbers (0 = divisor 1); tm_slow keeps the divisions for sizes
+    // whose products leave 32 bits.
+    int tm_tiles_m, tm_per_panel, tm_last_rows, tm_slow;
+    unsigned tm_mg_splitk, tm_mg_per_panel, tm_mg_rows, tm_mg_last;
+    int nk_base, nk_rem;         // K stages per slice: slice s takes nk_base + (s < nk_rem), slices in order
+    unsigned next_per;           // 128-byte lines of next_w per touching block (0: the kernel divides)
     // fp8 operands (st_linear_fp8): acc * row_scale[m] * col_scale[n] before anything else (col_scale has 2N entries with GEGLU)
     const float* row_scale; const float* col_scale;
     int rs_stride;               // stride of row_scale: 1 = a scale per row, 0 = one scale for the whole activation tensor
@@ -178,7 +187,7 @@ __device__ __forceinline__ void touch_next_weights(const GemmArgs& p, unsigned i
     // slices: over the helper blocks (the last helper_blocks of the grid) when there are any, else over all blocks
     const size_t nsl = helper ? p.helper_blocks : gridDim.x;
     const size_t me = helper ? blockIdx.x - (gridDim.x - p.helper_blocks) : blockIdx.x;
-    const size_t per = (lines + nsl - 1) / nsl;
+    const size_t per = p.next_per ? (size_t)p.next_per : (lines + nsl - 1) / nsl;      // (host-prepared: a 64-bit division is ~130 scalar instructions)
     const size_t lo = me * per, hi = lo + per < lines ? lo + per : lines;
     const size_t step = blockDim.x;                  // read once: inside the loop the asm's memory clobber would force a reload (and a vmcnt(0)) per trip
     for (size_t l = lo + threadIdx.x; l < hi; l += step) {
@@ -189,6 +198,62 @@ __device__ __forceinline__ void touch_next_weights(const GemmArgs& p, unsigned i
 // End of a touch destination's life: the loads are invisible to the compiler's waitcnt pass, so the register may only be
 // handed back once they have returned.
 __device__ __forceinline__ void retire_touches(unsigned int& sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory"); }
+
+// ---- block -> tile map ---------------------------------------------------------------------------------------------
+// floor(n / d) = mulhi(n, floor(2^32 / d) + 1) whenever n * d < 2^32 (the error term n * e / (d * 2^32), e <= d, stays below 1 / d)
+static inline unsigned magic_u32(unsigned d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / d + 1); }
+__device__ __forceinline__ int mg_div(int n, unsigned mg) { return mg ? (int)__umulhi((unsigned)n, mg) : n; }
+
+struct TileId { int tile_m, tile_n, split, tw; };
+// XCD-aware block order: blocks that share an XCD (blockIdx % 8) take consecutive tiles, so the W panel of a tile column is
+// fetched into one L2, not eight.  Split-K: tile-major, so a tile's slices sit next to each other on one XCD, where the block
+// that sums their slabs reads them fastest.  Tiles are ordered panel by panel (panel_h tile rows each), column-major inside
+// a panel, so the eight contiguous XCD shares of that order are rectangles: with one panel an XCD owns whole tile columns
+// (every XCD re-reads all of A, W is read once); with two or four panels an XCD re-reads 1/2 or 1/4 of A and W is read by 2
+// or 4 XCDs.  The host picks what moves fewer bytes.
+__device__ __forceinline__ TileId tile_of_block(const GemmArgs& p, int bid, int nblk) {
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
+    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    TileId r;
+    if (p.tm_slow) {
+        r.split = wg % p.splitk; r.tw = wg / p.splitk;
+        const int pn = r.tw / p.tm_per_panel, rem = r.tw - pn * p.tm_per_panel;
+        const int rows = min(p.panel_h, p.tm_tiles_m - pn * p.panel_h);
+        r.tile_n = rem / rows;
+        r.tile_m = pn * p.panel_h + (rem - r.tile_n * rows);
+        return r;
+    }
+    r.tw = mg_div(wg, p.tm_mg_splitk);
+    r.split = wg - r.tw * p.splitk;
+    const int pn = mg_div(r.tw, p.tm_mg_per_panel), rem = r.tw - pn * p.tm_per_panel;
+    const bool last = (pn + 1) * p.panel_h > p.tm_tiles_m;               // the short panel at the bottom
+    const int rows = last ? p.tm_last_rows : p.panel_h;
+    r.tile_n = mg_div(rem, last ? p.tm_mg_last : p.tm_mg_rows);
+    r.tile_m = pn * p.panel_h + (rem - r.tile_n * rows);
+    return r;
+}
+// (b.panel_h and b.splitk set; nk_stages = K stages of the whole problem)
+static inline void fill_tile_map(GemmArgs& b, int tiles_m, int tiles_n, int nk_stages) {
+    const int sk = b.splitk > 1 ? b.splitk : 1;
+    b.splitk = sk;
+    b.tm_tiles_m = tiles_m;
+    b.tm_per_panel = b.panel_h * tiles_n;
+    b.tm_last_rows = tiles_m % b.panel_h ? tiles_m % b.panel_h : b.panel_h;
+    b.tm_mg_splitk = magic_u32((unsigned)sk);
+    b.tm_mg_per_panel = magic_u32((unsigned)b.tm_per_panel);
+    b.tm_mg_rows = magic_u32((unsigned)b.panel_h);
+    b.tm_mg_last = magic_u32((unsigned)b.tm_last_rows);
+    const unsigned long long blocks = (unsigned long long)tiles_m * tiles_n * sk;
+    b.tm_slow = (blocks * (unsigned long long)(b.tm_per_panel > sk ? b.tm_per_panel : sk) >= (1ull << 32)) ? 1 : 0;
+    b.nk_base = nk_stages / sk;
+    b.nk_rem = nk_stages % sk;
+}
+// (after helper_blocks is decided; `grid` = blocks of the launch including helpers)
+static inline void fill_next_per(GemmArgs& b, unsigned grid) {
+    const size_t lines = b.next_bytes >> 7;
+    const size_t nsl = b.helper_blocks > 0 ? (size_t)b.helper_blocks : (size_t)grid;
+    b.next_per = (b.next_w && nsl) ? (unsigned)((lines + nsl - 1) / nsl) : 0u;
+}
 
 template <typename T> struct Raw4;
 template <> struct Raw4<bf16> { typedef bf16x4 type; };
@@ -1275,25 +1340,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         retire_touches(sink);
         return;
     }
-    const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
-    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     constexpr int BNO = GEGLU ? BN / 2 : BN;
-    // split-K: tile-major block order, so a tile's slices sit next to each other on one XCD, where the
-    // block that sums their slabs reads them fastest
-    const int split = wg % p.splitk, tw = wg / p.splitk;
-    // Tiles are ordered panel by panel (panel_h tile rows each), column-major inside a panel, so the
-    // eight contiguous XCD shares of that order are rectangles: with one panel an XCD owns whole tile
-    // columns (every XCD re-reads all of A, W is read once); with two or four panels an XCD re-reads
-    // 1/2 or 1/4 of A and W is read by 2 or 4 XCDs.  The host picks what moves fewer bytes.
-    int tile_m, tile_n;
-    {
-        const int tiles_n_all = nblk / p.splitk / tiles_m;
-        const int per_panel = p.panel_h * tiles_n_all;
-        const int pn = tw / per_panel, rem = tw - pn * per_panel;
-        const int rows = min(p.panel_h, tiles_m - pn * p.panel_h);
-        tile_n = rem / rows;
-        tile_m = pn * p.panel_h + (rem - tile_n * rows);
-    }
+    const TileId tid = tile_of_block(p, bid, nblk);
+    const int split = tid.split, tw = tid.tw, tile_m = tid.tile_m, tile_n = tid.tile_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BNO;
 
@@ -1381,8 +1430,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     }
 
     // K range of this block in stages (host guarantees K % (KB*U) == 0); split-K slices are balanced
-    const int nk_all = p.K / (KB * U);
-    const int nk_lo = (int)((long)split * nk_all / p.splitk), nk_hi = (int)((long)(split + 1) * nk_all / p.splitk);
+    const int nk_lo = split * p.nk_base + min(split, p.nk_rem), nk_hi = nk_lo + p.nk_base + (split < p.nk_rem ? 1 : 0);
     const int kbase = nk_lo * U;
     // DMA list of a stage: for each of its U tiles, A_IT activation pieces then B_IT weight pieces.
     // `issue_range` emits entries [lo, hi) so the loop can spread them between MFMA groups
@@ -1780,17 +1828,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
         retire_touches(sink);
         return;
     }
-    const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
-    const int tw = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    int tile_m, tile_n;
-    {
-        const int tiles_n_all = nblk / tiles_m;
-        const int per_panel = p.panel_h * tiles_n_all;
-        const int pn = tw / per_panel, rem = tw - pn * per_panel;
-        const int rows = min(p.panel_h, tiles_m - pn * p.panel_h);
-        tile_n = rem / rows;
-        tile_m = pn * p.panel_h + (rem - tile_n * rows);
-    }
+    const TileId tid = tile_of_block(p, bid, nblk);
+    const int tile_m = tid.tile_m, tile_n = tid.tile_n;
     const int m0 = tile_m * BM, n0 = tile_n * BNO;
     const T* __restrict__ Ap = (const T*)p.A;
     const T* __restrict__ Wp = (const T*)p.W;
@@ -2041,10 +2080,12 @@ static void gemm8p_go(const GemmArgs& a, hipStream_t st) {
     }
     const int main_blocks = tiles_m * tiles_n;
     b.splitk = 1;
+    fill_tile_map(b, tiles_m, tiles_n, 0);
     b.helper_blocks = (b.next_w && main_blocks <= 208) ? (256 - main_blocks > 96 ? 96 : 256 - main_blocks) : 0;
     b.stats_chunks = tiles_n;
     if (a.stats_chunks_out) *a.stats_chunks_out = a.row_stats ? b.stats_chunks : 0;
     if (!colstats_ok(a, 256, LNF)) b.col_stats = nullptr;
+    fill_next_per(b, main_blocks + b.helper_blocks);
     hipLaunchKernelGGL(kfn, dim3(main_blocks + b.helper_blocks), dim3(512), lds, st, b);
 }
 
@@ -2109,14 +2150,15 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
     const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const int split = wg % p.splitk, tw = wg / p.splitk;
-    const int tile_n = tw / tiles_m, tile_m = tw - tile_n * tiles_m;
+    // (divisions by launch constants as multiply-high, see GemmArgs::tm_*: here tm_mg_per_panel is the magic of tiles_m and
+    //  tm_mg_rows that of the tiles per image)
+    const int tw = mg_div(wg, p.tm_mg_splitk), split = wg - tw * p.splitk;
+    const int tile_n = mg_div(tw, p.tm_mg_per_panel), tile_m = tw - tile_n * tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int rows_per_img = p.Hout / TH;
-    const int img = tile_m / rows_per_img, ty0 = (tile_m - img * rows_per_img) * TH;      // first OUTPUT row of the tile
+    const int img = mg_div(tile_m, p.tm_mg_rows), ty0 = (tile_m - img * rows_per_img) * TH;      // first OUTPUT row of the tile
     const int iy_base = UPS ? (ty0 >> 1) - 1 : ty0 - 1;                                    // input row of patch row 0
-    const int ncs = p.Cin / KB;
-    const int cs_lo = (int)((long)split * ncs / p.splitk), cs_hi = (int)((long)(split + 1) * ncs / p.splitk);
+    const int cs_lo = split * p.nk_base + min(split, p.nk_rem), cs_hi = cs_lo + p.nk_base + (split < p.nk_rem ? 1 : 0);
 
     const T* __restrict__ Xb = (const T*)p.A + (size_t)img * Hh * WI * p.Cin;
     const T* __restrict__ Wp = (const T*)p.W;
@@ -2313,11 +2355,14 @@ static void launch_dma_one(const GemmArgs& a, hipStream_t st, int tiles_n) {
         b.panel_h = cdiv(tiles_m, best_p);
     }
     const int main_blocks = cdiv(a.M, BM) * tiles_n * sk;
+    b.splitk = sk;
+    fill_tile_map(b, cdiv(a.M, BM), tiles_n, a.K / ((128 / (int)sizeof(T)) * U));
     // launches that leave CUs idle hand the next-weights touches to helper blocks on those CUs (they run beside the K
     // loops instead of extending the epilogues)
     static const bool no_helpers = dev_env_int("ST_NO_HELPER_BLOCKS", 0) != 0;
     b.helper_blocks = (b.next_w && main_blocks <= 208 && !no_helpers) ? (256 - main_blocks > 96 ? 96 : 256 - main_blocks) : 0;
     if (!emit_cols) b.col_stats = nullptr;
+    fill_next_per(b, main_blocks + b.helper_blocks);
     hipLaunchKernelGGL(kfn, dim3(main_blocks + b.helper_blocks), dim3(WGM * WGN * 64), lds, st, b);
 }
 
@@ -2563,6 +2608,8 @@ static void conv_halo_go(const GemmArgs& b, int blocks, hipStream_t st) {
     ensure_dynamic_lds(kfn, lds, &lds_ok);
     GemmArgs c = b;
     if (!colstats_ok(b, TH * W, false)) c.col_stats = nullptr;
+    c.helper_blocks = 0;
+    fill_next_per(c, blocks);
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, st, c);
 }
 
@@ -2584,6 +2631,14 @@ static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
         while (sk > 1 && ((size_t)sk * tiles * bm * bn * 4 + 65536 > a.partial_bytes || tiles > 16384)) --sk;
     }
     if (sk > 1) { b.splitk = sk; b.tile_counters = (int*)a.partial; b.partial = a.partial + 16384; }
+    else b.splitk = 1;
+    {   // the kernel's divisions as multiply-high (GemmArgs::tm_*): by the K slices, the tile rows, the tiles per image
+        const int tiles_m = a.M / bm, th = bm / a.Wout;
+        b.tm_mg_splitk = magic_u32((unsigned)b.splitk);
+        b.tm_mg_per_panel = magic_u32((unsigned)tiles_m);
+        b.tm_mg_rows = magic_u32((unsigned)(a.Hout / th));
+        b.nk_base = ncs / b.splitk; b.nk_rem = ncs % b.splitk;
+    }
     b.stats_chunks = cdiv(a.N, bn);
     if (a.row_stats && b.stats_chunks > a.stats_capacity) return st_fail("conv2d: row_stats buffer holds %d chunks, %d needed", a.stats_capacity, b.stats_chunks);
     if (a.stats_chunks_out) *a.stats_chunks_out = a.row_stats ? b.stats_chunks : 0;

@@ -7,13 +7,15 @@ name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/tools/_variants/$name
 mkdir -p "$out/obj"
-srcs=(); flags=()
+srcs=(); flags=(); pids=()
 for a in "$@"; do case "$a" in *.hip) srcs+=("$a");; *) flags+=("$a");; esac; done
 for src in "${srcs[@]}"; do
   base=$(basename "${src%.hip}")
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form "${flags[@]}" -c "$root/stabletriton_amd/csrc/$base.hip" -o "$out/obj/$base.o" &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form "${flags[@]}" -c "$root/stabletriton_amd/csrc/$base.hip" -o "$out/obj/$base.o.new" &
+  pids+=($!)
 done
-wait
+for pid in "${pids[@]}"; do wait "$pid" || { echo "compile failed"; exit 1; }; done      # (a failed compile must not link a stale object)
+for src in "${srcs[@]}"; do base=$(basename "${src%.hip}"); mv "$out/obj/$base.o.new" "$out/obj/$base.o"; done
 objs=()
 for f in "$root"/stabletriton_amd/csrc/*.hip; do
   b=$(basename "${f%.hip}")
