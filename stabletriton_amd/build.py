@@ -89,5 +89,21 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return out
 
 
+def stale_sources() -> list:
+    """Sources whose object (or the linked library) was not built from what is in the tree now: [] = the .so is this source.
+    A failed compile leaves the previous .so in place; tests and bench.py refuse to measure that (tests/conftest.py)."""
+    objdir = os.path.join(LIBDIR, "obj")
+    out = []
+    lib_m = os.path.getmtime(lib_path()) if os.path.exists(lib_path()) else 0.0
+    for src in _sources():
+        obj = os.path.join(objdir, src[:-4] + ".o")
+        stamp = obj + ".sha"
+        if not (os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == _digest(os.path.join(CSRC, src))):
+            out.append(src)
+        elif os.path.getmtime(obj) > lib_m + 1.0:
+            out.append(src + " (not linked)")
+    return out
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))

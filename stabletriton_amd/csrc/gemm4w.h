@@ -75,11 +75,11 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const GemmArgs p) {
     rp[3] = rp[2] + (size_t)64 * p.K * ES;
     const int nk = p.K / KB;
     int kstep = 128;
-    char* const dma_dst = lds + wave * 4096;
+    const unsigned dma_dst = lds_addr_of(lds) + wave * 4096;
 
     // region r of a K tile: 0 = A0, 1 = A1, 2 = B0, 3 = B1; four DMAs per wave (piece e), then the region's pointer moves one K tile on
     auto issue_piece = [&](int stage, int region, int e) {
-        dma16<0>(rp[region] + (region < 2 ? a_vo[e] : b_vo[e]), dma_dst + stage * TILE_B + region * HB + e * 1024);
+        dma16_at<0>(rp[region] + (region < 2 ? a_vo[e] : b_vo[e]), dma_dst + stage * TILE_B + region * HB + e * 1024);
         if (e == 3) rp[region] += kstep;
     };
     auto issue_region = [&](int stage, int region) {

@@ -1201,6 +1201,16 @@ constexpr int dma_in_group(int G, int NG, int g) {
     return n;
 }
 
+// The same with the destination as an LDS byte address (what an address_space(3) pointer is).  For destinations picked by
+// a select (live piece or dump area): the generic -> LDS conversion of a selected pointer carries a null test, and on one
+// instantiation (128 x 160, GEGLU, LayerNorm fold) hipcc 7.2 emitted "V_CMP_NE_U32 0, src_shared_base" for it and
+// stopped with "Illegal instruction detected".
+template <int AUX = 0>
+__device__ __forceinline__ void dma16_at(const void* src, unsigned lds_addr) {
+    __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)src, (lds_void_t*)(uintptr_t)lds_addr, 16, 0, AUX);
+}
+__device__ __forceinline__ unsigned lds_addr_of(const char* p) { return (unsigned)(uintptr_t)(lds_void_t*)p; }
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -1472,10 +1482,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
             cs_r += w2 ? 1 : 0;
         }
     };
+    const unsigned lds_base = lds_addr_of(lds), dump_addr = lds_base + STAGES * STAGE + BM * 8;       // (= dump)
     auto issue_one = [&](int st, int buf, int e) {
         const int u = e / PER_TILE, i = e - u * PER_TILE;
         const int kt = kbase + st * U + u;
-        char* base = lds + buf * STAGE + u * TILE;
+        const unsigned base = lds_base + buf * STAGE + u * TILE;
         if (i < A_IT) {
             const T* src;
             if (CONV) {
@@ -1503,14 +1514,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
                 src = a_ptr[i] + (size_t)kt * a_adv[i];
             }
             const int pa = wave + i * NW;
-            dma16<ST_AUX_A>(src, (!UNEVEN || pa < A_PIECES) ? base + pa * 1024 : dump);
+            dma16_at<ST_AUX_A>(src, (!UNEVEN || pa < A_PIECES) ? base + pa * 1024 : dump_addr);
         } else {
             const int j = i - A_IT;
             const int pb = wave + j * NW;
             const T* bsrc;
             if (CONV && U == 1) bsrc = b_ptr[j] + (b_adv[j] ? (size_t)((cs_r * p.S + cs_s) * p.Cin + cs_c0) : 0);     // W[n][tap][c]
             else bsrc = b_ptr[j] + (size_t)kt * b_adv[j];
-            dma16<ST_AUX_B>(bsrc, (!UNEVEN || pb < B_PIECES) ? base + A_BYTES + pb * 1024 : dump);
+            dma16_at<ST_AUX_B>(bsrc, (!UNEVEN || pb < B_PIECES) ? base + A_BYTES + pb * 1024 : dump_addr);
         }
     };
     auto issue = [&](int st, int buf) {
@@ -1860,13 +1871,13 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     auto issue_half = [&](int kt, int region) {
         const int roff = region == 0 ? 0 : region == 1 ? HA : region == 2 ? 2 * HA : 2 * HA + HB0;
         const int rrows = region < 2 ? RA : region == 2 ? RB0 : RB1;
-        char* dst = lds + (kt & 1) * TILE_B + roff + (2 * wave) * 1024;
+        const unsigned dst = lds_addr_of(lds) + (kt & 1) * TILE_B + roff + (2 * wave) * 1024;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const bool live = kt < nk && (2 * wave + e) * 8 < rrows;
             const T* src = region < 2 ? a_src[e] + (region & 1) * a_half : region == 2 ? b0_src[e] : b1_src[e];
             src = live ? src + (size_t)kt * KB : zeros;
-            dma16<0>(src, live ? dst + e * 1024 : dump);
+            dma16_at<0>(src, live ? dst + e * 1024 : lds_addr_of(lds) + 2 * TILE_B + BM * 8);        // (= dump)
         }
     };
 
@@ -2187,7 +2198,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
         const int pidx = e * NW + wave;
         const bool live = pidx < PIECES_P && cs < cs_hi;
         const T* src = (live && pa_ptr[e]) ? pa_ptr[e] + cs * KB : zeros;
-        dma16<0>(src, live ? lds + (cs & 1) * PB + pidx * 1024 : dump);
+        dma16_at<0>(src, live ? lds_addr_of(lds) + (cs & 1) * PB + pidx * 1024 : lds_addr_of(lds) + 2 * PB + STAGES * WT_B);      // (= dump)
     };
     auto issue_w = [&](int cs, int tap, int slot) {  // the weight tile of trip (cs, tap); cs >= cs_hi: dummy
 #pragma unroll
@@ -2196,7 +2207,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
             // the trip straight-line code with one vmcnt for all waves; measured faster than a per-wave branch)
             const bool live = cs < cs_hi && wave + j * NW < B_PIECES;
             const T* src = (live && pb_ptr[j]) ? pb_ptr[j] + (size_t)tap * p.Cin + cs * KB : zeros;
-            dma16<0>(src, live ? ring + slot * WT_B + (wave + j * NW) * 1024 : dump);
+            dma16_at<0>(src, live ? lds_addr_of(lds) + 2 * PB + slot * WT_B + (wave + j * NW) * 1024 : lds_addr_of(lds) + 2 * PB + STAGES * WT_B);
         }
     };
 

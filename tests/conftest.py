@@ -22,7 +22,10 @@ def lib():
 @pytest.fixture(scope="session")
 def gpu():
     import torch
+    from stabletriton_amd import build
     assert torch.cuda.is_available(), "GPU tests selected but no GPU is visible"
+    stale = build.stale_sources()      # a failed compile leaves the previous .so in place: never test that by accident
+    assert not stale, f"libstabletriton_amd.so was not built from this source tree (run python -m stabletriton_amd.build): {stale}"
     return torch.device("cuda:0")
 
 

@@ -58,3 +58,10 @@ def test_ops_reject_cpu_tensors():
                  lambda: ops.attention(torch.randn(1, 8, 64), torch.randn(1, 8, 64), torch.randn(1, 8, 64), 1, 0.125)):
         with pytest.raises(ops.BackendError, match="no CPU fallback"):
             call()
+
+
+def test_library_is_built_from_this_source():
+    """Every object was compiled from the sources (and headers, flags) in the tree and the .so links them: a failed compile
+    keeps the previous library, and everything measured afterwards would silently be the old code."""
+    from stabletriton_amd import build
+    assert build.stale_sources() == []
