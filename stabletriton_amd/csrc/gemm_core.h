@@ -379,18 +379,26 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n,
     epilogue_put4<T>(p, m, n, v);
 }
 
+// The feature set of an epilogue as bits (see staged_epilogue_impl): MODE >= 0 = exactly that set, tile inside the matrix.
+enum { EPI_F_BIAS = 1, EPI_F_RES = 2, EPI_F_RB = 4, EPI_F_LN = 8, EPI_F_SILU = 16, EPI_F_SCALE = 32, EPI_F_ROWS = 64, EPI_F_COLS = 128,
+       EPI_F_Q8 = 256, EPI_F_NOC = 512 };
+
 // lane (r16, q) holds rows m = .. + r16, columns n = .. + 4q .. 4q+3 of every 16x16 tile.
-template <typename T, int TM, int TN, int WTM, int WTN, bool GEGLU, int WGM_ = 0, int WGN_ = 0, bool ALIGNED_N = false>
+template <typename T, int TM, int TN, int WTM, int WTN, bool GEGLU, int WGM_ = 0, int WGN_ = 0, bool ALIGNED_N = false, int MODE = -1>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
                                               int r16, int q, int split = 0, const float* row_mean = nullptr,
                                               const float* row_rstd = nullptr, char* lds_scratch = nullptr, int tile_n = 0,
                                               unsigned long long* ptimes = nullptr) {
+    constexpr bool FAST = MODE >= 0;
     float rs1[TM], rs2[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) { rs1[i] = 0.f; rs2[i] = 0.f; }
     constexpr int TNO = GEGLU ? TN / 2 : TN;
     constexpr int WTNO = GEGLU ? WTN / 2 : WTN;
-    if (!ALIGNED_N && (p.N & 3) != 0) {
+    const bool has_q8 = FAST ? bool(MODE & EPI_F_Q8) : (p.q8_out != nullptr);
+    const bool emit_rows = FAST ? bool(MODE & EPI_F_ROWS) : (p.row_stats != nullptr);
+    const bool emit_cols = FAST ? bool(MODE & EPI_F_COLS) : (p.col_stats != nullptr && (p.N & 3) == 0);
+    if (!FAST && !ALIGNED_N && (p.N & 3) != 0) {
         // ragged N: per-tile loads, arithmetic and element stores
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -413,14 +421,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
         // and cost ONE round trip), then the arithmetic, then nothing but stores.  On gfx950 vmcnt
         // counts stores too, so a load behind a store would also wait for that store's acknowledgement.
         typedef typename Raw4<T>::type R4;
-        const bool has_bias = p.epi & ST_EPI_BIAS, has_res = p.epi & ST_EPI_RESIDUAL, has_rb = p.epi & ST_EPI_ROWBIAS;
-        const bool has_ln = p.ln_c != nullptr, do_silu = p.epi & ST_EPI_SILU, has_scale = p.col_scale != nullptr;
+        const bool has_bias = FAST ? bool(MODE & EPI_F_BIAS) : bool(p.epi & ST_EPI_BIAS), has_res = FAST ? bool(MODE & EPI_F_RES) : bool(p.epi & ST_EPI_RESIDUAL);
+        const bool has_rb = FAST ? bool(MODE & EPI_F_RB) : bool(p.epi & ST_EPI_ROWBIAS), has_ln = FAST ? bool(MODE & EPI_F_LN) : (p.ln_c != nullptr);
+        const bool do_silu = FAST ? bool(MODE & EPI_F_SILU) : bool(p.epi & ST_EPI_SILU), has_scale = FAST ? bool(MODE & EPI_F_SCALE) : (p.col_scale != nullptr);
         int ncol[TNO], mrow[TM];
         bool nok[TNO], mok[TM];
 #pragma unroll
-        for (int j = 0; j < TNO; ++j) { const int n = n0 + wn * WTNO + j * 16 + 4 * q; nok[j] = n < p.N; ncol[j] = nok[j] ? n : 0; }
+        for (int j = 0; j < TNO; ++j) { const int n = n0 + wn * WTNO + j * 16 + 4 * q; nok[j] = FAST || n < p.N; ncol[j] = nok[j] ? n : 0; }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) { const int m = m0 + wm * WTM + i * 16 + r16; mok[i] = m < p.M; mrow[i] = mok[i] ? m : 0; }
+        for (int i = 0; i < TM; ++i) { const int m = m0 + wm * WTM + i * 16 + r16; mok[i] = FAST || m < p.M; mrow[i] = mok[i] ? m : 0; }
         const T* __restrict__ bias = (const T*)p.bias;
         unsigned int touch_next = 0;                       // destination of the next-weights touches (kept live to the end)
         // wide wave tiles take the load + arithmetic passes in column chunks of JC tiles (registers)
@@ -527,7 +536,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 #ifdef ST_PROBE
         if (ptimes) ptimes[0] = probe_now();
 #endif
-        const float q8_inv = p.q8_out ? *p.q8_inv_scale : 0.f;
+        const float q8_inv = has_q8 ? *p.q8_inv_scale : 0.f;
         float q8_max = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -536,13 +545,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                 if (mok[i] && nok[j]) {
                     const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                     Out4<T>::store((T*)p.C + (size_t)mrow[i] * p.ldc + ncol[j], v);
-                    if (p.q8_out) {            // e4m3 copy of the stored values (4 bytes per lane)
+                    if (has_q8) {            // e4m3 copy of the stored values (4 bytes per lane)
                         q8_max = fmaxf(fmaxf(q8_max, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                         *reinterpret_cast<unsigned int*>((unsigned char*)p.q8_out + (size_t)mrow[i] * p.q8_ld + ncol[j]) =
                             pack4_fp8(clamp_fp8(v[0] * q8_inv), clamp_fp8(v[1] * q8_inv), clamp_fp8(v[2] * q8_inv), clamp_fp8(v[3] * q8_inv));
                     }
                 }
-        if (p.q8_out) publish_amax(p.q8_amax, q8_max, blockIdx.x * 8 + (threadIdx.x >> 6));
+        if (has_q8) publish_amax(p.q8_amax, q8_max, blockIdx.x * 8 + (threadIdx.x >> 6));
         retire_touches(touch_next);
     }
 #ifdef ST_PROBE
@@ -552,7 +561,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
         // LayerNorm partials of the rows this block just stored (consumed by the next st_ln_linear):
         // lane sums -> the four q lanes -> the WGN waves of this tile row (through LDS) -> one float2
         // per (row, N tile).  Fixed order throughout: bit-reproducible.
-        if (p.row_stats) {
+        if (emit_rows) {
             float2* sm = reinterpret_cast<float2*>(lds_scratch);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -573,7 +582,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
         // GroupNorm partials: per output column of this tile, (sum, sum of squares) over the tile's rows of the values just
         // stored (acc holds them, zero for rows / columns outside the problem).  In-lane over the row tiles, a fixed
         // butterfly over the sixteen row lanes, then the WGM waves of the column through LDS: bit-reproducible.
-        if (p.col_stats && (p.N & 3) == 0) {
+        if (emit_cols) {
             constexpr int TNO_ = GEGLU ? TN / 2 : TN;
             constexpr int WTNO_ = GEGLU ? WTN / 2 : WTN;
             float2* cm = reinterpret_cast<float2*>(lds_scratch + WGM_ * WTM * WGN_ * 8);      // behind the row-statistics area
@@ -657,8 +666,6 @@ struct EpiGeom {
 // branches, no code for the absent features); MODE = -1 is the general instance that reads the set from the arguments.
 // Why: with run-time flags the bias-only epilogue of a 256 x 256 tile took 24,000 cycles, the bare accumulators -> LDS ->
 // 16-byte stores round trip 9,400 (tools/gemm_probe.py): twelve microseconds of a 48-us launch went into testing flags.
-enum { EPI_F_BIAS = 1, EPI_F_RES = 2, EPI_F_RB = 4, EPI_F_LN = 8, EPI_F_SILU = 16, EPI_F_SCALE = 32, EPI_F_ROWS = 64, EPI_F_COLS = 128,
-       EPI_F_Q8 = 256, EPI_F_NOC = 512 };
 
 template <typename TO, int BM, int BN, int WGM, int WGN, int TM, int TN, bool GEGLU, int LDS_BYTES, bool STATS, int MODE, typename ColMap>
 __device__ __forceinline__ void staged_epilogue_impl(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int tile_n, int wm, int r16, int q,
@@ -1757,14 +1764,48 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
             const float2 v = lnst[wm * WTM + i * 16 + r16];
             mean[i] = v.x; rstd[i] = v.y;
         }
-        gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wm, wn, r16, q, split, mean, rstd);
+        // (specialised instances for the feature sets of the step, as in staged_epilogue)
+        const bool inside = (m0 + BM <= p.M) && (n0 + BNO <= p.N) && (p.N & 3) == 0 && p.C != nullptr && !p.q8_out;
+        const int flags = inside ? (((p.epi & ST_EPI_BIAS) ? EPI_F_BIAS : 0) | (p.epi & (ST_EPI_RESIDUAL | ST_EPI_ROWBIAS | ST_EPI_SILU) ? 1024 : 0) |
+                                    (p.col_scale ? EPI_F_SCALE : 0) | EPI_F_LN) : -1;
+        if (sizeof(T) != 1 && flags == EPI_F_LN) gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, 0, 0, false, EPI_F_LN>(p, acc, m0, n0, wm, wn, r16, q, split, mean, rstd);
+        else if (sizeof(T) != 1 && flags == (EPI_F_LN | EPI_F_BIAS))
+            gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, 0, 0, false, EPI_F_LN | EPI_F_BIAS>(p, acc, m0, n0, wm, wn, r16, q, split, mean, rstd);
+        else if (sizeof(T) == 1 && flags == (EPI_F_LN | EPI_F_SCALE))
+            gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, 0, 0, false, EPI_F_LN | EPI_F_SCALE>(p, acc, m0, n0, wm, wn, r16, q, split, mean, rstd);
+        else gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wm, wn, r16, q, split, mean, rstd);
     } else {
 #ifdef ST_PROBE
         unsigned long long ept[6] = {0, 0, 0, 0, 0, 0};
         gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n, ept);
         pr_x = ept[0] - pr_end; pr_d = ept[1] - ept[0];
 #else
-        gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n);
+        const bool inside = (m0 + BM <= p.M) && (n0 + BNO <= p.N) && (p.N & 3) == 0 && p.C != nullptr;
+        const int flags = inside ? (((p.epi & ST_EPI_BIAS) ? EPI_F_BIAS : 0) | ((p.epi & ST_EPI_RESIDUAL) ? EPI_F_RES : 0) | ((p.epi & ST_EPI_ROWBIAS) ? EPI_F_RB : 0) |
+                                    ((p.epi & ST_EPI_SILU) ? EPI_F_SILU : 0) | (p.col_scale ? EPI_F_SCALE : 0) | (p.ln_c ? EPI_F_LN : 0) | (p.row_stats ? EPI_F_ROWS : 0) |
+                                    ((p.col_stats && (p.N & 3) == 0) ? EPI_F_COLS : 0) | (p.q8_out ? EPI_F_Q8 : 0)) : -1;
+#define ST_FRAG_CASE(M)                                                                                                                        \
+    case (M):                                                                                                                                  \
+        gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, WGM, WGN, false, (M)>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n); \
+        break;
+        if constexpr (sizeof(T) != 1) {
+            switch (flags) {
+                ST_FRAG_CASE(EPI_F_BIAS)
+                ST_FRAG_CASE(EPI_F_BIAS | EPI_F_RES)
+                ST_FRAG_CASE(EPI_F_BIAS | EPI_F_ROWS)
+                ST_FRAG_CASE(EPI_F_BIAS | EPI_F_RES | EPI_F_ROWS)
+                ST_FRAG_CASE(EPI_F_BIAS | EPI_F_RES | EPI_F_ROWS | EPI_F_Q8)
+                ST_FRAG_CASE(EPI_F_BIAS | EPI_F_RES | EPI_F_COLS)
+                default: gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n);
+            }
+        } else {
+            switch (flags) {
+                ST_FRAG_CASE(EPI_F_BIAS | EPI_F_SCALE | EPI_F_RES | EPI_F_ROWS)
+                ST_FRAG_CASE(EPI_F_BIAS | EPI_F_SCALE | EPI_F_RES | EPI_F_ROWS | EPI_F_Q8)
+                default: gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, WGM, WGN>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n);
+            }
+        }
+#undef ST_FRAG_CASE
 #endif
     }
 #ifdef ST_PROBE
