@@ -3,8 +3,11 @@
 //  reads the fragments straight into AGPRs; without the flag it shuffles accumulators between the halves and spills.)
 #include "gemm_core.h"
 
+#ifdef ST_DEV_CONFIGS      // developer builds only (tools/build_one_variant.sh ... -DST_DEV_CONFIGS): not dispatched by the product
+
 void gemm4w_bf16(const GemmArgs& a, hipStream_t st) { gemm4w_launch<bf16>(a, st); }
 #ifndef ST_4W_BF16_ONLY      // (developer builds of one element type compile in a third of the time)
 void gemm4w_f16(const GemmArgs& a, hipStream_t st) { gemm4w_launch<f16>(a, st); }
 void gemm4w_fp8(const GemmArgs& a, hipStream_t st) { gemm4w_launch<f8>(a, st); }
 #endif
+#endif      // ST_DEV_CONFIGS

@@ -646,11 +646,7 @@ struct EpiGeom {
     static constexpr int ROW_BYTES = LDW * 4 + VPR * 8;          // + one (sum, sum of squares) partial per vector (row statistics)
     // passes per chunk (bounds the residual / row-bias vectors in flight; the 256 x 256 tile still holds up to 96 accumulator
     // registers of later chunks while it works on one: two passes keep it from spilling)
-#ifdef ST_EPI_MAXIT_256T
-    static constexpr int MAX_IT = (BM * BN >= 256 * 256) ? (NT == 256 ? ST_EPI_MAXIT_256T : 2) : 4;
-#else
-    static constexpr int MAX_IT = (BM * BN >= 256 * 256) ? 2 : 4;
-#endif
+    static constexpr int MAX_IT = (BM * BN >= 256 * 256) ? 2 : 4;      // (four passes on the 256 x 256 tiles: no faster, and the GEGLU ones spill)
     static constexpr int ch0 = (LDS_BYTES / ROW_BYTES) / 16 * 16;
     static constexpr int ch1 = ch0 < MAX_IT * RPI ? ch0 : (MAX_IT * RPI) / 16 * 16;
     static constexpr int ch2 = ch1 < BM ? ch1 : BM;
@@ -2537,7 +2533,9 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             // (e4m3: a K step is 128 k - the same bytes, fragment reads and phases as a 64-k bf16 step, twice the product)
             if (gemm8p_applies(a, 256, KB)) c256 = (double)((tiles(256, 256) + 255) / 256) * (nk * 1.65 + 4.0);
             if (gemm8p_applies(a, 160, KB)) c160 = (double)((tiles(256, 160) + 255) / 256) * (nk * 1.52 + 4.0);
+#ifdef ST_DEV_CONFIGS      // the four-wave kernel is a developer build's: level with the eight-phase one on the step's shapes
             if (f == CFG_256x256_4W && gemm4w_applies(a, KB)) { gemm4w_call<T>(a, st); return st_check_launch(who); }
+#endif
             const bool take256 = f == CFG_256x256_8P || (f < 0 && c256 <= c160 && c256 < 1.3 * best);
             const bool take160 = f == CFG_256x160_8P || (f < 0 && c160 < c256 && c160 < 1.3 * best);
             if (take256 && c256 < 1e29) { gemm8p_launch<T, 256, 2, 4>(a, st); return st_check_launch(who); }
