@@ -40,11 +40,12 @@ enum {
     ST_EPI_ROWBIAS   = 16   /* + rowbias[batch(m)][n]     (time-embedding add)    */
 };
 
-int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 11
+int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 12
                                               (6: next-weights hint passed per call, st_timestep_sincos; 7: fp8 entry points; 8: GroupNorm partials from the
                                               producer; 9: st_ln_linear_xattn; 10: ST_F16 accepted by every entry point
                                               that takes a dtype, st_ln_linear_xattn takes a dtype; 11: fp8 plan with
-                                              delayed per-tensor scaling - st_linear_emit8, st_linear_fp8x, st_fp8_update_scales) */
+                                              delayed per-tensor scaling - st_linear_emit8, st_linear_fp8x, st_fp8_update_scales; 12: readers of a channel
+                                              concatenation that is never written - st_group_norm_from_stats_cat, st_conv1x1_cat) */
 const char* st_last_error(void);           /* host string, thread-local     */
 
 /* GroupNorm (+SiLU).  Replaces reference group_norm_wrapper
@@ -66,6 +67,14 @@ int st_group_norm(const void* x, const void* gamma, const void* beta, void* y,
 int st_group_norm_from_stats(const void* x, const void* gamma, const void* beta, void* y, int N, int C, int HW,
                              int groups, float eps, int silu, int dtype, const float* stats0, int C0, int rows0,
                              const float* stats1, int C1, int rows1, void* workspace, void* stream);
+
+/* The same for x = the channel concatenation [x0 | x1] of two NHWC tensors (C0 / C1 = C - C0 channels, multiples of one
+ * 16-byte vector), each with the statistics of its own producer; the concatenated tensor is never written (the decoder's
+ * skip connections, unet_pt.py:352-357: torch.cat -> norm1).  Bit-identical to st_group_norm_from_stats on the
+ * concatenated tensor. */
+int st_group_norm_from_stats_cat(const void* x0, const void* x1, const void* gamma, const void* beta, void* y, int N, int C, int HW,
+                                 int groups, float eps, int silu, int dtype, const float* stats0, int C0, int rows0,
+                                 const float* stats1, int C1, int rows1, void* workspace, void* stream);
 
 /* LayerNorm over the last dimension.  Replaces layer_norm_wrapper
  * (optimizers/replace_layernorm.py:17-24 -> kernels/layer_norm.py:282-335);
@@ -165,6 +174,15 @@ int st_conv2d(const void* x, const void* W, const void* bias, const void* residu
               int epilogue, int dtype, void* workspace, size_t workspace_bytes,
               float* col_stats, int col_stats_tiles, int* col_stats_rows,
               const void* next_weights, size_t next_weights_bytes, void* stream);
+
+/* 1x1 convolution (stride 1, no padding) of the channel concatenation [x0 | x1] (NHWC, C0 / C1 channels, multiples of a
+ * K tile: 64 for 16-bit types, 32 for fp32) without the concatenated tensor: the resnet shortcut behind a skip connection
+ * (unet_pt.py:352-357 -> 74-95).  W is (Cout, 1, 1, C0 + C1).  Epilogue flags BIAS / SILU / RESIDUAL; workspace, col_stats,
+ * next_weights as st_conv2d.  Bit-identical to st_conv2d on the concatenated tensor. */
+int st_conv1x1_cat(const void* x0, int C0, const void* x1, int C1, const void* W, const void* bias, const void* residual, void* y,
+                   int N, int H, int Wd, int Cout, int epilogue, int dtype, void* workspace, size_t workspace_bytes,
+                   float* col_stats, int col_stats_tiles, int* col_stats_rows,
+                   const void* next_weights, size_t next_weights_bytes, void* stream);
 
 /* Euler-discrete update of the fp32 latent and preparation of the next UNet
  * input (restated diffusers EulerDiscreteScheduler, see

@@ -16,7 +16,7 @@ from .build import lib_path
 ST_F32, ST_BF16, ST_F16 = 0, 1, 2
 ST_NCHW, ST_NHWC = 0, 1
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_RESIDUAL, EPI_ROWBIAS = 1, 2, 4, 8, 16
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _p, _i, _l, _f, _z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
@@ -34,6 +34,8 @@ SIGNATURES = {
     "st_attention": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _l, _l, _f, _i, _p]),
     "st_conv2d": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _i, _p, _p, _z, _p]),
     "st_group_norm_from_stats": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p, _i, _i, _p, _i, _i, _p, _p]),
+    "st_group_norm_from_stats_cat": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p, _i, _i, _p, _i, _i, _p, _p]),
+    "st_conv1x1_cat": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p, _i, _p, _p, _z, _p]),
     "st_euler_step": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p]),
     "st_step_advance": (_i, [_p, _i, _p]),
     "st_timestep_features": (_i, [_p, _l, _p, _p, _i, _i, _i, _p]),

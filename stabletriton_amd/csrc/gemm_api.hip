@@ -226,3 +226,35 @@ extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const v
     ST_REQUIRE(a.K <= 64 && Cout % 16 == 0, "conv2d: Cin=%d is neither a multiple of %d (implicit GEMM) nor thin (R*S*Cin <= 64, Cout %% 16 == 0)", Cin, kb);
     return conv_thin_run(a, R, dtype, st);
 }
+
+// 1x1 convolution (stride 1, no padding) over the channel concatenation [x0 | x1] without the concatenated tensor: the skip
+// connections of the decoder (unet_pt.py:352-357) feed a resnet whose 1x1 shortcut is the only GEMM-shaped reader of the
+// concatenation.  Bit-identical to st_conv2d on torch.cat([x0, x1], 1): same K order, same tiles.
+extern "C" int st_conv1x1_cat(const void* x0, int C0, const void* x1, int C1, const void* W, const void* bias, const void* residual, void* y,
+                              int N, int H, int Wd, int Cout, int epilogue, int dtype, void* workspace, size_t workspace_bytes,
+                              float* col_stats, int col_stats_tiles, int* col_stats_rows,
+                              const void* next_weights, size_t next_weights_bytes, void* stream) {
+    if (col_stats_rows) *col_stats_rows = 0;
+    ST_REQUIRE(x0 && x1 && W && y, "conv1x1_cat: null pointer");
+    ST_REQUIRE(N > 0 && H > 0 && Wd > 0 && C0 > 0 && C1 > 0 && Cout > 0, "conv1x1_cat: bad geometry");
+    ST_REQUIRE(st_dtype_ok(dtype), "conv1x1_cat: unsupported dtype %d", dtype);
+    ST_REQUIRE(!(epilogue & (ST_EPI_GEGLU | ST_EPI_ROWBIAS)), "conv1x1_cat: GEGLU / row-bias epilogues not supported");
+    ST_REQUIRE(Cout % 4 == 0, "conv1x1_cat: Cout=%d must be a multiple of 4", Cout);
+    const int kb = st_dtype_is16(dtype) ? 64 : 32;
+    ST_REQUIRE(C0 % kb == 0 && C1 % kb == 0, "conv1x1_cat: both channel counts (%d, %d) must be multiples of %d", C0, C1, kb);
+    ST_REQUIRE(((uintptr_t)x0 | (uintptr_t)x1 | (uintptr_t)W | (uintptr_t)y) % 16 == 0, "conv1x1_cat: pointers must be 16-byte aligned");
+    GemmArgs a = {};
+    a.A = x0; a.A2 = x1; a.Csplit = C0; a.W = W; a.bias = bias; a.residual = residual; a.C = y;
+    a.Hin = H; a.Win = Wd; a.Cin = C0 + C1; a.S = 1; a.stride = 1; a.pad = 0; a.ups = 0; a.R_ = 1; a.korder = 0;
+    a.Hout = H; a.Wout = Wd;
+    a.M = N * H * Wd; a.N = Cout; a.K = C0 + C1;
+    a.lda = 0; a.ldc = Cout; a.ldr = Cout; a.rows_per_batch = H * Wd; a.epi = epilogue;
+    a.splitk = 1; a.partial = (float*)workspace; a.partial_bytes = workspace ? workspace_bytes : 0;
+    a.col_stats = col_stats; a.col_tiles_cap = col_stats_tiles; a.col_rows_out = col_stats_rows;
+    take_hint(a, next_weights, next_weights_bytes);
+    if (int e = check_epilogue("conv1x1_cat", a)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ST_BF16) return gemm_conv_bf16(a, 1, 0, st);
+    if (dtype == ST_F16) return gemm_conv_f16(a, 1, 0, st);
+    return gemm_conv_f32(a, st);
+}

@@ -44,6 +44,9 @@ struct GemmArgs {
     size_t partial_bytes;
     int* tile_counters;          // one arrival counter per output tile (zero between launches)
     int panel_h;                 // tile rows per panel of the block order (see gemm_dma_kernel); >= 1
+    // 1x1 conv over a channel concatenation that is never materialised (st_conv1x1_cat): input channels [0, Csplit) of a
+    // pixel come from A (pixel stride Csplit), the rest from A2 (pixel stride Cin - Csplit); Csplit is a multiple of a K tile
+    const void* A2; int Csplit;
     // block -> tile map, prepared on the host (fill_tile_map).  Every wave of a block used to work it out with four integer
     // divisions by launch constants, ~25 scalar instructions each on the CU's one scalar unit: with the 64-bit divisions
     // of the K slices about 400 of the ~900 instructions in front of the first MFMA (2.4 us of a 12-us launch,
@@ -1367,13 +1370,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     const int lr = lane >> 3;                     // row inside the 8-row block
     const int lc = (lane & 7) ^ lr;               // logical 16-byte chunk this lane fetches (source-side swizzle)
     const T* a_ptr[A_IT];
+    const T* a2_ptr[CONV ? A_IT : 1];              // two-source 1x1 conv: the pixel's row in the second tensor
     int a_adv[A_IT], a_iy[A_IT], a_ix[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int row = (wave + i * NW) * 8 + lr;
         const int m = m0 + row;
         const bool ok = m < p.M && (!UNEVEN || wave + i * NW < A_PIECES);
-        if (CONV) {
+        if (CONV && p.A2) {        // 1x1, stride 1: input pixel = output pixel m
+            a_ptr[i] = Ap + (size_t)(ok ? m : 0) * p.Csplit + lc * VEC;
+            a2_ptr[i] = (const T*)p.A2 + (size_t)(ok ? m : 0) * (p.Cin - p.Csplit) + lc * VEC;
+            a_iy[i] = ok ? 0 : -(1 << 28); a_ix[i] = 0; a_adv[i] = 0;
+        } else if (CONV) {
             const int hw = p.Hout * p.Wout;
             const int mm = ok ? m : 0;
             const int img = mm / hw, rem = mm - img * hw;
@@ -1510,6 +1518,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
                     ok = iy >= 0 && ix >= 0 && iy < p.Hin && ix < p.Win;
                 }
                 src = ok ? a_ptr[i] + ((size_t)iy * p.Win + ix) * p.Cin + c0 : zeros;
+                if (p.A2) src = a_iy[i] < 0 ? zeros : (c0 < p.Csplit ? a_ptr[i] + c0 : a2_ptr[CONV ? i : 0] + (c0 - p.Csplit));
 #ifdef ST_CONV_SKIP_A
                 if (r != 0 || s_ != 0) src = zeros;          // timing experiment: fetch the input for one tap in nine
 #endif

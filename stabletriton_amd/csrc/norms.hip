@@ -146,7 +146,10 @@ __global__ __launch_bounds__(256) void gn_finalize(const float4* __restrict__ pa
 template <typename T, bool SILU>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_nhwc(const T* __restrict__ x, const T* __restrict__ gamma,
                                                             const T* __restrict__ beta, const float2* __restrict__ stats,
-                                                            T* __restrict__ y, int C, int HW, int G, int VC, int RP, int P) {
+                                                            T* __restrict__ y, int C, int HW, int G, int VC, int RP, int P,
+                                                            const T* __restrict__ x1 = nullptr, int C0 = 0) {
+    // x1 != nullptr: the input is the channel concatenation [x | x1] that was never materialised - channels [0, C0) of a pixel
+    // from x (pixel stride C0), the rest from x1 (pixel stride C - C0); a thread's channel vector lies in one of them
     constexpr int VEC = Elem<T>::VEC;
     const int n = blockIdx.y, b = blockIdx.x;
     const int t = threadIdx.x;
@@ -162,8 +165,11 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_nhwc(const T* __restrict_
         mu[i] = st.x; a[i] = st.y * gv.get(i); bt[i] = bv.get(i);
     }
     const size_t base = ((size_t)n * HW) * C + (size_t)col * VEC;
+    const bool second = x1 != nullptr && col * VEC >= C0;
+    const int Cs = x1 == nullptr ? C : (second ? C - C0 : C0);          // pixel stride of this thread's source
+    const T* __restrict__ xs = (second ? x1 + ((size_t)n * HW) * Cs + (size_t)(col * VEC - C0) : x + ((size_t)n * HW) * Cs + (size_t)col * VEC);
     for (int p = p0 + rp; p < p1; p += RP) {
-        Vec16<T> v = load16(x + base + (size_t)p * C), o;
+        Vec16<T> v = load16(xs + (size_t)p * Cs), o;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float f = (v.get(i) - mu[i]) * a[i] + bt[i];
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(256) void gn_cols_finalize(GnSource s0, GnSource s1
 
 template <typename T>
 static int gn_from_stats_launch(const void* x, const void* gamma, const void* beta, void* y, int N, int C, int HW, int G, float eps,
-                                int silu, GnSource s0, GnSource s1, void* ws, hipStream_t st) {
+                                int silu, GnSource s0, GnSource s1, void* ws, hipStream_t st, const void* x1 = nullptr, int C0 = 0) {
     ST_REQUIRE(C % Elem<T>::VEC == 0, "group_norm_from_stats: C=%d must be a multiple of %d", C, Elem<T>::VEC);
     GnGeom g = gn_geom<T>(C, HW);
     ST_REQUIRE(g.VC <= GN_THREADS, "group_norm_from_stats: C=%d too wide", C);
@@ -311,10 +317,10 @@ static int gn_from_stats_launch(const void* x, const void* gamma, const void* be
                        (double)(C / G) * (double)HW, eps);
     if (silu)
         hipLaunchKernelGGL((gn_apply_nhwc<T, true>), dim3(g.NB, N), dim3(GN_THREADS), 0, st, (const T*)x, (const T*)gamma,
-                           (const T*)beta, stats, (T*)y, C, HW, G, g.VC, g.RP, g.P);
+                           (const T*)beta, stats, (T*)y, C, HW, G, g.VC, g.RP, g.P, (const T*)x1, C0);
     else
         hipLaunchKernelGGL((gn_apply_nhwc<T, false>), dim3(g.NB, N), dim3(GN_THREADS), 0, st, (const T*)x, (const T*)gamma,
-                           (const T*)beta, stats, (T*)y, C, HW, G, g.VC, g.RP, g.P);
+                           (const T*)beta, stats, (T*)y, C, HW, G, g.VC, g.RP, g.P, (const T*)x1, C0);
     return st_check_launch("group_norm_from_stats");
 }
 
@@ -334,6 +340,28 @@ extern "C" int st_group_norm_from_stats(const void* x, const void* gamma, const 
     if (dtype == ST_F16) return gn_from_stats_launch<f16>(x, gamma, beta, y, N, C, HW, groups, eps, silu, s0, s1, workspace, st);
     if (dtype == ST_F32) return gn_from_stats_launch<float>(x, gamma, beta, y, N, C, HW, groups, eps, silu, s0, s1, workspace, st);
     return st_fail("group_norm_from_stats: unsupported dtype %d", dtype);
+}
+
+// The same for an input that is the channel concatenation [x0 | x1] of two NHWC tensors (C0 and C1 = C - C0 channels, each
+// with the statistics of its producer): the concatenated tensor is never written (torch.cat of the decoder's skip
+// connections, unet_pt.py:352-357).  Bit-identical to st_group_norm_from_stats on torch.cat([x0, x1], 1).
+extern "C" int st_group_norm_from_stats_cat(const void* x0, const void* x1, const void* gamma, const void* beta, void* y, int N, int C, int HW,
+                                            int groups, float eps, int silu, int dtype, const float* stats0, int C0, int rows0,
+                                            const float* stats1, int C1, int rows1, void* workspace, void* stream) {
+    ST_REQUIRE(x0 && x1 && gamma && beta && y && workspace && stats0 && stats1, "group_norm_from_stats_cat: null pointer");
+    ST_REQUIRE(N > 0 && C > 0 && HW > 0 && groups > 0 && C % groups == 0, "group_norm_from_stats_cat: bad shape N=%d C=%d HW=%d G=%d", N, C, HW, groups);
+    ST_REQUIRE(groups <= 1024 && N <= 65535, "group_norm_from_stats_cat: shape exceeds launch limits");
+    ST_REQUIRE(C0 > 0 && C1 > 0 && C0 + C1 == C && rows0 > 0 && rows1 > 0 && HW % rows0 == 0 && HW % rows1 == 0,
+               "group_norm_from_stats_cat: sources cover %d + %d channels, input has %d", C0, C1, C);
+    const int vec = dtype == ST_F32 ? 4 : 8;
+    ST_REQUIRE(C0 % vec == 0 && C1 % vec == 0, "group_norm_from_stats_cat: channel counts (%d, %d) must be multiples of %d", C0, C1, vec);
+    GnSource s0 = {(const float2*)stats0, C0, HW / rows0};
+    GnSource s1 = {(const float2*)stats1, C1, HW / rows1};
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ST_BF16) return gn_from_stats_launch<bf16>(x0, gamma, beta, y, N, C, HW, groups, eps, silu, s0, s1, workspace, st, x1, C0);
+    if (dtype == ST_F16) return gn_from_stats_launch<f16>(x0, gamma, beta, y, N, C, HW, groups, eps, silu, s0, s1, workspace, st, x1, C0);
+    if (dtype == ST_F32) return gn_from_stats_launch<float>(x0, gamma, beta, y, N, C, HW, groups, eps, silu, s0, s1, workspace, st, x1, C0);
+    return st_fail("group_norm_from_stats_cat: unsupported dtype %d", dtype);
 }
 
 // =============================================================================

@@ -338,6 +338,36 @@ def group_norm_from_stats(x: torch.Tensor, sources, num_groups: int, weight: tor
     return y
 
 
+def group_norm_from_stats_cat(x0: torch.Tensor, x1: torch.Tensor, sources, num_groups: int, weight: torch.Tensor, bias: torch.Tensor,
+                              eps: float, silu: bool) -> torch.Tensor:
+    """GroupNorm(+SiLU) of torch.cat([x0, x1], 1) (channels_last) without writing the concatenated tensor: both halves bring
+    the statistics of their producers (`sources`: two ColStats).  Anything the two-source kernel does not take (a missing
+    source, channel counts that are not whole 16-byte vectors, NCHW inputs) goes through torch.cat and `group_norm_from_stats`.
+    Bit-identical to that path."""
+    vec = 4 if x0.dtype == torch.float32 else 8
+    ok = (len(sources) == 2 and all(s is not None for s in sources) and _is_nhwc(x0) and _is_nhwc(x1) and x0.dtype == x1.dtype
+          and x0.shape[0] == x1.shape[0] and x0.shape[2:] == x1.shape[2:] and x0.shape[1] % vec == 0 and x1.shape[1] % vec == 0)
+    if ok:
+        N, C0, C1 = x0.shape[0], x0.shape[1], x1.shape[1]
+        HW = x0.numel() // (N * C0)
+        ok = sources[0].channels == C0 and sources[1].channels == C1 and not any(HW % s.rows for s in sources) and (C0 + C1) % num_groups == 0
+    if not ok:
+        return group_norm_from_stats(torch.cat([x0, x1], dim=1), sources, num_groups, weight, bias, eps, silu)
+    _C.require_device(x0, x1, weight, bias)
+    lib = _C.load()
+    Cc = C0 + C1
+    y = torch.empty((N, Cc) + tuple(x0.shape[2:]), dtype=x0.dtype, device=x0.device, memory_format=torch.channels_last)
+    w = weight if weight.dtype == x0.dtype else weight.to(x0.dtype)
+    b = bias if bias.dtype == x0.dtype else bias.to(x0.dtype)
+    ws = torch.empty(lib.st_group_norm_workspace_bytes(N, Cc, HW, num_groups), dtype=torch.uint8, device=x0.device)
+    s0, s1 = sources
+    _C.check(lib.st_group_norm_from_stats_cat(x0.data_ptr(), x1.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups,
+                                              float(eps), int(bool(silu)), _C.dtype_code(x0.dtype), s0.buf.data_ptr(), s0.channels, s0.rows,
+                                              s1.buf.data_ptr(), s1.channels, s1.rows, ws.data_ptr(), _C.stream_ptr()),
+             "group_norm_from_stats_cat")
+    return y
+
+
 def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> torch.Tensor:
     _C.require_device(x, weight, bias)
     lib = _C.load()
@@ -781,6 +811,52 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
                            N, H, W, Cin, Cout, R, S, stride, padding, int(upsample2x), epi,
                            _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(), _ptr(cbuf), ctiles or 0,
                            None if crows is None else ctypes.byref(crows), nxt_p, nxt_b, _C.stream_ptr()), "conv2d")
+    if emit_colstats:
+        return out, (ColStats(cbuf, crows.value, Cout) if crows.value > 0 else None)
+    return out
+
+
+def conv2d_cat(x0: torch.Tensor, x1: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
+               residual: Optional[torch.Tensor] = None, emit_colstats: bool = False):
+    """1x1 convolution (stride 1, no padding) of torch.cat([x0, x1], 1) without writing the concatenated tensor (the resnet
+    shortcut behind a skip connection).  Inputs the two-source kernel does not take go through torch.cat and `conv2d`.
+    Bit-identical to that path (same K order, same tiles)."""
+    kb = 32 if x0.dtype == torch.float32 else 64
+    ok = (x0.dim() == 4 and x1.dim() == 4 and weight.dim() == 4 and tuple(weight.shape[2:]) == (1, 1) and x0.dtype == x1.dtype == weight.dtype
+          and x0.shape[0] == x1.shape[0] and x0.shape[2:] == x1.shape[2:] and x0.shape[1] % kb == 0 and x1.shape[1] % kb == 0
+          and weight.shape[1] == x0.shape[1] + x1.shape[1] and weight.shape[0] % 4 == 0)
+    if not ok:
+        return conv2d(torch.cat([x0, x1], dim=1), weight, bias, 1, 0, residual=residual, emit_colstats=emit_colstats)
+    _C.require_device(x0, x1, weight, bias, residual)
+    lib = _C.load()
+    if not x0.is_contiguous(memory_format=torch.channels_last):
+        x0 = x0.contiguous(memory_format=torch.channels_last)
+    if not x1.is_contiguous(memory_format=torch.channels_last):
+        x1 = x1.contiguous(memory_format=torch.channels_last)
+    w = weight if weight.is_contiguous(memory_format=torch.channels_last) else weight.contiguous(memory_format=torch.channels_last)
+    N, C0, H, W = x0.shape
+    C1, Cout = x1.shape[1], w.shape[0]
+    out = torch.empty((N, Cout, H, W), dtype=x0.dtype, device=x0.device, memory_format=torch.channels_last)
+    epi = 0
+    if bias is not None:
+        epi |= _C.EPI_BIAS
+        if bias.dtype != x0.dtype:
+            bias = bias.to(x0.dtype)
+    if residual is not None:
+        if residual.shape != out.shape or residual.dtype != x0.dtype:
+            raise BackendError("conv2d_cat: residual must match the output")
+        if not residual.is_contiguous(memory_format=torch.channels_last):
+            residual = residual.contiguous(memory_format=torch.channels_last)
+        epi |= _C.EPI_RESIDUAL
+    gws = _gemm_workspace(x0.device)
+    nxt_p, nxt_b = _next_weights(w)
+    cbuf = ctiles = crows = None
+    if emit_colstats:
+        import ctypes
+        cbuf, ctiles, crows = _colstats_buffer(N * H * W, Cout, x0.device)
+    _C.check(lib.st_conv1x1_cat(x0.data_ptr(), C0, x1.data_ptr(), C1, w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
+                                N, H, W, Cout, epi, _C.dtype_code(x0.dtype), gws.data_ptr(), gws.numel(), _ptr(cbuf), ctiles or 0,
+                                None if crows is None else ctypes.byref(crows), nxt_p, nxt_b, _C.stream_ptr()), "conv2d_cat")
     if emit_colstats:
         return out, (ColStats(cbuf, crows.value, Cout) if crows.value > 0 else None)
     return out

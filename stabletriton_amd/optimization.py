@@ -16,7 +16,7 @@ import torch
 from torch import fx, nn
 
 from . import _C, ops
-from .optimizers import (dedupe_pure_calls, fuse_token_residual, fuse_attention, fuse_geglu, fuse_geglu_into_linear, fuse_groupnorm_stats, fuse_layernorm_into_linear, fuse_query_projection_into_attention, fuse_residual_adds,
+from .optimizers import (dedupe_pure_calls, fuse_token_residual, fuse_attention, fuse_geglu, fuse_geglu_into_linear, fuse_groupnorm_stats, fuse_skip_cat, fuse_layernorm_into_linear, fuse_query_projection_into_attention, fuse_residual_adds,
                          fuse_shared_input_linears,
                          fuse_temb_add, fuse_timesteps, split_context, split_region, keep_channels_last, make_dynamic_graphed_callable, plan_fp8, remove_dropout,
                          replace_conv, replace_group_norm, replace_group_norm_activation, replace_layer_norm,
@@ -51,6 +51,7 @@ def replace_backend(gm: fx.GraphModule, fuse: bool = True, fp8: bool = False, xa
         stats["layer_norm_in_gemm"] = fuse_layernorm_into_linear(gm)
         stats["query_projection_in_attention"] = fuse_query_projection_into_attention(gm) if xattn_fusion else 0
         stats["group_norm_stats"] = fuse_groupnorm_stats(gm) if gn_stats else 0
+        stats["skip_cats_removed"] = fuse_skip_cat(gm) if gn_stats else 0      # (the decoder's torch.cat: both readers take the two halves)
         if fp8:      # the three big projections of every transformer block on the fp8 matrix pipe, fed by e4m3 copies their
             stats["fp8_plan"] = plan_fp8(gm)      # producers' epilogues leave (no quantisation launches): optimizers/plan_fp8.py
     stats["channels_last_views"] = keep_channels_last(gm)

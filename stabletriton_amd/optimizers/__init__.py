@@ -11,6 +11,7 @@ from .fuse_projections import (fuse_layernorm_into_linear, fuse_query_projection
                                split_region)
 from .plan_fp8 import plan_fp8
 from .fuse_groupnorm_stats import fuse_groupnorm_stats
+from .fuse_skip_cat import fuse_skip_cat
 from .cleanup import dedupe_pure_calls, fuse_token_residual
 from .layout import keep_channels_last
 from .graphs import make_dynamic_graphed_callable

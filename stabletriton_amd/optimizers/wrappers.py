@@ -81,10 +81,20 @@ def conv2d_wrapper(v: torch.Tensor, conv: nn.Conv2d, upsample2x: bool = False,
                       emit_colstats=emit_colstats)
 
 
-def group_norm_stats_wrapper(v: torch.Tensor, stats, groupnorm: nn.GroupNorm, activation: bool) -> torch.Tensor:
+def group_norm_stats_wrapper(v, stats, groupnorm: nn.GroupNorm, activation: bool) -> torch.Tensor:
     """group_norm_wrapper whose statistics come from the launch(es) that produced `v` (`stats`: one ColStats, or two
-    for a channel concatenation): finalize + apply, no statistics pass over v."""
+    for a channel concatenation): finalize + apply, no statistics pass over v.  `v` may be the pair of tensors of a
+    channel concatenation that was never written (optimizers/fuse_skip_cat.py)."""
+    if isinstance(v, (tuple, list)):
+        return ops.group_norm_from_stats_cat(v[0], v[1], tuple(stats), groupnorm.num_groups, groupnorm.weight, groupnorm.bias,
+                                             groupnorm.eps, activation)
     return ops.group_norm_from_stats(v, tuple(stats), groupnorm.num_groups, groupnorm.weight, groupnorm.bias, groupnorm.eps, activation)
+
+
+def conv2d_cat_wrapper(a: torch.Tensor, b: torch.Tensor, conv: nn.Conv2d, residual: Optional[torch.Tensor] = None,
+                       emit_colstats: bool = False):
+    """conv2d_wrapper(torch.cat([a, b], 1), conv) for a 1x1 / stride-1 / unpadded conv, without the concatenated tensor."""
+    return ops.conv2d_cat(a, b, conv.weight, conv.bias, residual=residual, emit_colstats=emit_colstats)
 
 
 def linear_geglu_wrapper(v: torch.Tensor, linear: nn.Linear) -> torch.Tensor:
@@ -99,7 +109,7 @@ def linear_residual_wrapper(v: torch.Tensor, linear: nn.Linear, residual: torch.
 
 for _name in ("attention_wrapper", "geglu_triton", "group_norm_wrapper", "layer_norm_wrapper", "linear_wrapper",
               "linear_wrapper_functional", "timestep_wrapper", "timestep_embedding_wrapper", "conv2d_wrapper", "linear_geglu_wrapper",
-              "linear_residual_wrapper", "group_norm_stats_wrapper"):
+              "linear_residual_wrapper", "group_norm_stats_wrapper", "conv2d_cat_wrapper"):
     torch.fx.wrap(_name)
 
 

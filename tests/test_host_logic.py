@@ -60,6 +60,11 @@ def test_pass_counts_match_reference_probe_on_sdxl():
     assert gm.rewrite_stats["geglu_in_gemm"] == 70 and gm.rewrite_stats["temb_rowbias"] == 17
     assert gm.rewrite_stats["layer_norm_in_gemm"] == 210 and gm.rewrite_stats["shared_input_gemms"] == 72
     assert gm.rewrite_stats["group_norm_stats"] == 46          # every GroupNorm reads a conv / GEMM output or a cat of two
+    assert gm.rewrite_stats["skip_cats_removed"] == 9          # the decoder's nine torch.cat: norm1 and the 1x1 shortcut read the two halves
+    assert not any(n.op == "call_function" and n.target is torch.cat and n.kwargs.get("dim", n.args[1] if len(n.args) > 1 else 0) == 1
+                   and n.meta.get("skip_cat", True) and len(n.args[0]) == 2 and n.users
+                   and all(getattr(u.target, "__name__", "") in ("group_norm_stats_wrapper", "conv2d_wrapper") for u in n.users)
+                   for n in gm.graph.nodes)
     assert gm.rewrite_stats["query_projection_in_attention"] == 70     # every cross-attention: to_q's GEMM runs the attention
     _install_context_split(gm)
     assert gm.rewrite_stats["context_outputs"] == 140 and gm.rewrite_stats["time_outputs"] == 1
@@ -114,6 +119,10 @@ def _cpu_backend(monkeypatch):
         assert all(s == "colstats" for s in sources) and 1 <= len(sources) <= 2
         return (F.silu if silu else (lambda t: t))(F.group_norm(x, g, w, b, eps))
     monkeypatch.setattr(ops, "group_norm_from_stats", group_norm_from_stats)
+    monkeypatch.setattr(ops, "group_norm_from_stats_cat",
+                        lambda x0, x1, sources, g, w, b, eps, silu: group_norm_from_stats(torch.cat([x0, x1], 1), sources, g, w, b, eps, silu))
+    monkeypatch.setattr(ops, "conv2d_cat", lambda x0, x1, w, b, *, residual=None, emit_colstats=False:
+                        conv2d(torch.cat([x0, x1], 1), w, b, 1, 0, residual=residual, emit_colstats=emit_colstats))
     monkeypatch.setattr(ops, "timestep_features", lambda t, dim, dtype, **kw: orc.timestep_features(t, dim).to(dtype))
 
 

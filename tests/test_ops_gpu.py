@@ -375,6 +375,9 @@ def test_group_norm_from_two_sources_unaligned_groups(gpu, dtype):
     cat = torch.cat([a_img, bb], dim=1).contiguous(memory_format=cl)
     g, be = rnd("g2.g", (1920,)) * 0.2 + 1.0, rnd("g2.be", (1920,)) * 0.2
     y = ops.group_norm_from_stats(cat, (sa, sb), 32, g.to(gpu, dtype), be.to(gpu, dtype), 1e-5, True)
+    # the same without the concatenated tensor: the apply pass reads the two halves where they lie - bit for bit the same
+    y2 = ops.group_norm_from_stats_cat(a_img, bb, (sa, sb), 32, g.to(gpu, dtype), be.to(gpu, dtype), 1e-5, True)
+    assert y2.shape == y.shape and y2.is_contiguous(memory_format=cl) and torch.equal(y2, y)
     ref = F.silu(F.group_norm(cat.float().cpu(), 32, rounded(g, dtype), rounded(be, dtype), 1e-5))
     assert_close(y, ref, dtype, "group_norm_from_stats(cat)")
     # a producer that cannot emit (thin conv_in kernel) -> the wrapper falls back to the three-launch GroupNorm
@@ -384,3 +387,43 @@ def test_group_norm_from_two_sources_unaligned_groups(gpu, dtype):
     assert si is None
     y2 = ops.group_norm_from_stats(ci, (si,), 32, g[:320].to(gpu, dtype), be[:320].to(gpu, dtype), 1e-5, False)
     assert_close(y2, F.group_norm(ci.float().cpu(), 32, rounded(g[:320], dtype), rounded(be[:320], dtype), 1e-5), dtype, "fallback")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,C0,C1,H,Cout,res,stats", [(1, 1280, 640, 32, 1280, False, True), (2, 640, 320, 64, 640, True, False),
+                                                       (1, 320, 320, 128, 320, False, True), (1, 64, 192, 16, 128, True, True)])
+def test_conv1x1_over_a_concatenation_that_is_never_written(gpu, dtype, N, C0, C1, H, Cout, res, stats):
+    """The resnet shortcut behind a skip connection (unet_pt.py:352-357 -> 74-95): a 1x1 conv of cat([a, b], 1) that reads the
+    two tensors where they lie - against the oracle's conv on the concatenation, and bit for bit what ops.conv2d gives on
+    the concatenated tensor (same K order, same tiles), statistics included."""
+    cl = torch.channels_last
+    a, b = rnd("cc.a", (N, C0, H, H)), rnd("cc.b", (N, C1, H, H))
+    w, bias = rnd("cc.w", (Cout, C0 + C1, 1, 1), (C0 + C1) ** -0.5), rnd("cc.bias", (Cout,), 0.5)
+    r = rnd("cc.r", (N, Cout, H, H)) if res else None
+    ag, bg = a.to(gpu, dtype).contiguous(memory_format=cl), b.to(gpu, dtype).contiguous(memory_format=cl)
+    wg, biasg = w.to(gpu, dtype).contiguous(memory_format=cl), bias.to(gpu, dtype)
+    rg = None if r is None else r.to(gpu, dtype).contiguous(memory_format=cl)
+    got = ops.conv2d_cat(ag, bg, wg, biasg, residual=rg, emit_colstats=stats)
+    want = ops.conv2d(torch.cat([ag, bg], dim=1), wg, biasg, 1, 0, residual=rg, emit_colstats=stats)
+    if stats:
+        (got, sg), (want, sw) = got, want
+        assert (sg is None) == (sw is None)
+        if sg is not None:
+            assert sg.rows == sw.rows and sg.channels == sw.channels
+            tiles = N * H * H // sg.rows
+            assert torch.equal(sg.buf[:tiles], sw.buf[:tiles])
+    assert got.is_contiguous(memory_format=cl) and torch.equal(got, want)
+    ref = F.conv2d(torch.cat([rounded(a, dtype), rounded(b, dtype)], 1), rounded(w, dtype), rounded(bias, dtype))
+    if r is not None:
+        ref = ref + rounded(r, dtype)
+    assert_close(got, ref, dtype, "conv2d_cat")
+
+
+def test_conv1x1_cat_falls_back_to_the_concatenation(gpu):
+    """Channel counts that are not whole K tiles (or a 3x3 kernel) take torch.cat + conv2d: same result, one more launch."""
+    cl = torch.channels_last
+    a, b = rnd("cf.a", (1, 48, 16, 16)).to(gpu, torch.bfloat16), rnd("cf.b", (1, 80, 16, 16)).to(gpu, torch.bfloat16)
+    w = rnd("cf.w", (64, 128, 1, 1), 128 ** -0.5).to(gpu, torch.bfloat16)
+    got = ops.conv2d_cat(a, b, w, None)
+    want = ops.conv2d(torch.cat([a, b], dim=1), w, None, 1, 0)
+    assert torch.equal(got, want)

@@ -1,6 +1,7 @@
 """Developer A/B of whole denoise steps on ONE box: the product library against tools/_variants/<name> builds (same ABI),
 alternating processes so that device-to-device and thermal drift cancel.
-usage: python tools/ab_step.py [--batch B] [--dtype bf16|fp16] [--rounds R] variantA variantB ...     ('product' = the in-tree build)"""
+usage: python tools/ab_step.py [--batch B] [--dtype bf16|fp16] [--rounds R] variantA variantB ...     ('product' = the in-tree build;
+       'product:<pass>' = the same with the graph pass stabletriton_amd.optimization.<pass> switched off)"""
 import argparse, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,7 +10,12 @@ sys.path.insert(0, ROOT)
 def one(variant, batch, dtype_name, latent):
     import torch
     from tools.devlib import use_variant
+    variant, _, without = variant.partition(":")          # "product:fuse_skip_cat" = the build with that graph pass switched off
     use_variant(None if variant == "product" else variant)
+    if without:
+        import stabletriton_amd.optimization as opt_mod
+        assert hasattr(opt_mod, without), f"no pass {without}"
+        setattr(opt_mod, without, lambda gm, *a, **k: 0)
     from stabletriton_amd import synth
     from stabletriton_amd.optimization import optimize_model
     from stabletriton_amd.pipeline import DenoiseLoop
@@ -36,7 +42,7 @@ def one(variant, batch, dtype_name, latent):
             loop.run_steps(20)
             torch.cuda.synchronize()
             best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
-    print(f"RESULT {variant} {best:.4f}")
+    print(f"RESULT {variant}{':' + without if without else ''} {best:.4f}")
 
 
 if __name__ == "__main__":

@@ -54,6 +54,18 @@ def _group_norm_from_stats(a):
     return "group_norm", 0.0, 2.0 * N * C * HW * ES[dt], f"N={N} C={C} HW={HW} silu={silu} from-stats"
 
 
+def _group_norm_from_stats_cat(a):
+    N, C, HW, silu, dt = a[5], a[6], a[7], a[10], a[11]
+    return "group_norm", 0.0, 2.0 * N * C * HW * ES[dt], f"N={N} C={C} HW={HW} silu={silu} from-stats, two sources"
+
+
+def _conv1x1_cat(a):
+    C0, C1, N, H, W, Cout, epi, dt = a[1], a[3], a[8], a[9], a[10], a[11], a[12], a[13]
+    Cin = C0 + C1
+    return ("conv2d", 2.0 * N * H * W * Cout * Cin, float((N * H * W * Cin + Cout * Cin + N * H * W * Cout) * ES[dt]),
+            f"Cin={C0}+{C1} H={H} Cout={Cout} k=1 s=1 ups=0 epi={epi}" + (" colstats" if a[16] else ""))
+
+
 def _layer_norm(a):
     rows, C, dt = a[4], a[5], a[7]
     return "layer_norm", 0.0, 2.0 * rows * C * ES[dt], f"rows={rows} C={C}"
@@ -94,6 +106,7 @@ def _linear_fp8x(a):
 
 DECODERS = {"st_linear": _linear, "st_linear_emit8": _linear_emit8, "st_linear_fp8x": _linear_fp8x, "st_ln_linear": _ln_linear, "st_ln_linear_xattn": _ln_linear_xattn, "st_attention": _attention,
             "st_conv2d": _conv2d, "st_group_norm": _group_norm, "st_group_norm_from_stats": _group_norm_from_stats,
+            "st_group_norm_from_stats_cat": _group_norm_from_stats_cat, "st_conv1x1_cat": _conv1x1_cat,
             "st_layer_norm": _layer_norm, "st_geglu": _geglu, "st_quantize_fp8": _quantize_fp8,
             "st_layer_norm_quantize_fp8": _ln_quantize_fp8, "st_linear_fp8": _linear_fp8}
 
