@@ -1295,10 +1295,14 @@ __device__ __forceinline__ bool splitk_combine(const GemmArgs& p, f32x4 (&acc)[T
     __syncthreads();
     if (*flag != p.splitk - 1) return false;
     if (t == 0) __hip_atomic_store(p.tile_counters + tw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+    // This block's own slice is in its registers: it is added from there, at its place in the slice order (the slab holds
+    // the very same fp32 values, so the sum is the one a read-back would give), and a sixth to a half of the slab reads
+    // of the last arriver - which pulls them through ONE CU's load path - disappear.
+    f32x4 own[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) { own[i][j] = acc[i][j]; acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     // Every slab load carries sc1 (served past this CU's L1, which other CUs' write-through stores never refresh), as a
     // raw buffer load so that it stays compiler-visible: the destination of an inline-asm load may be copied or spilled by
     // the compiler before the data has arrived (seen as soon as a 128-accumulator tile put the register file under
@@ -1306,6 +1310,13 @@ __device__ __forceinline__ bool splitk_combine(const GemmArgs& p, f32x4 (&acc)[T
     typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t slabs = __builtin_amdgcn_make_buffer_rsrc((void*)slab0, 0, (int)((size_t)p.splitk * TILE_ELEMS * 4), 0x00020000);
     for (int sl = 0; sl < p.splitk; ++sl) {
+        if (sl == split) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] += own[i][j];
+            continue;
+        }
         const int off = (sl * TILE_ELEMS + wave * (TM * TN * 256) + lane * 4) * 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
