@@ -2536,7 +2536,14 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
                 const double slab_mb = (double)k_ * nt * c.bm * c.bn * 4.0 / 1e6;
                 if (k_ > 1 && slab_mb * 1e6 + 65536 > (double)a.partial_bytes) break;
                 const double rounds = (double)((nt * k_ + 255) / 256);
-                const double cost = rounds * (cdiv(nk, k_) * trip + 3.0) + (k_ > 1 ? 2.1 + 0.4 * slab_mb : 0.0);
+                // with (nearly) every CU pulling, the K tiles of a round leave L2 at ~14 TB/s together: 256 blocks of
+                // 128 x 80 need 6.8 MB per trip = 0.49 us, not the 0.37 us one of them takes among 160
+                // (tools/gemm_sweep.py: 2048 x 1280 x 5120 on that tile 43 us against 33 predicted)
+                const double in_round = (double)(nt * k_ < 256 ? nt * k_ : 256);
+                const double trip_bw = in_round * (c.bm + c.bn) * 128.0 / 14.0e6;
+                // (the per-trip constants were fitted on one-round launches; launches of several rounds run 25-45 % over them
+                //  - tools/gemm_sweep.py: 2048 x 10240 x 1280 on 256 x 128 tiles 73 us against 52 predicted - hence the factor)
+                const double cost = rounds * (cdiv(nk, k_) * (trip > trip_bw ? trip : trip_bw) + 3.0) * (rounds > 1.0 ? 1.3 : 1.0) + (k_ > 1 ? 2.1 + 0.4 * slab_mb : 0.0);
                 if (cost < best) { best = cost; cfg = c.cfg; sk = k_; }
             }
         }
@@ -2556,8 +2563,10 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
 #ifdef ST_DEV_CONFIGS      // the four-wave kernel is a developer build's: level with the eight-phase one on the step's shapes
             if (f == CFG_256x256_4W && gemm4w_applies(a, KB)) { gemm4w_call<T>(a, st); return st_check_launch(who); }
 #endif
-            const bool take256 = f == CFG_256x256_8P || (f < 0 && c256 <= c160 && c256 < 1.3 * best);
-            const bool take160 = f == CFG_256x160_8P || (f < 0 && c160 < c256 && c160 < 1.3 * best);
+            // (near ties go to this kernel: 1.1 - it was 1.3 while the small-tile predictions above still lacked their
+            //  several-rounds and all-CUs-pulling corrections, and then took 8192 x 1920 x 640 at 40 us against 33)
+            const bool take256 = f == CFG_256x256_8P || (f < 0 && c256 <= c160 && c256 < 1.1 * best);
+            const bool take160 = f == CFG_256x160_8P || (f < 0 && c160 < c256 && c160 < 1.1 * best);
             if (take256 && c256 < 1e29) { gemm8p_launch<T, 256, 2, 4>(a, st); return st_check_launch(who); }
             if (take160 && c160 < 1e29) { gemm8p_launch<T, 160, 4, 2>(a, st); return st_check_launch(who); }
         }

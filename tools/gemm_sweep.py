@@ -16,7 +16,7 @@ force = lib.st_debug_force_gemm
 force.argtypes, force.restype = [ctypes.c_int, ctypes.c_int], None
 # only configurations the product dispatch can select (the other developer tilings are not maintained: 256x256_W8 faults)
 NAMES = {7: "64x64_W8", 8: "128x64_W8", 9: "128x128_W8", 10: "64x128_W8", 19: "256x128_W8", 23: "128x320_W8",
-         25: "64x320_W8", 27: "128x80_W8", 28: "128x160_W8", 100: "256x256_8P"}
+         25: "64x320_W8", 27: "128x80_W8", 28: "128x160_W8", 100: "256x256_8P", 101: "256x160_8P"}
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 which = sys.argv[2] if len(sys.argv) > 2 else "all"
 shapes = [(1024 * B, 1280, 1280, 0), (1024 * B, 1280, 3840, 0), (1024 * B, 1280, 5120, 1), (1024 * B, 5120, 1280, 0),
@@ -41,7 +41,7 @@ for M, K, N, geglu in shapes:
         if geglu and name in ("64x320_W8", "128x80_W8"):
             continue
         for sk in (1, 2, 3, 4):
-            if cfg == 100 and sk > 1:
+            if cfg >= 100 and sk > 1:
                 continue
             force(cfg, sk)
             try:
@@ -50,6 +50,8 @@ for M, K, N, geglu in shapes:
                 continue
             rows_out.append((us, name, sk))
     force(-1, -1)
+    base2 = timeit(call, iters=max(20, ncopy))          # again, after the sweep: the first timing of a shape reads high
+    base = min(base, base2)
     rows_out.sort()
     best = ", ".join(f"{n}/k{sk} {us:.1f}" for us, n, sk in rows_out[:5])
     print(f"M={M:6d} K={K:5d} N={N:5d} g={geglu}: model {base:7.1f} us ({fl / base / 1e6:6.1f} TF/s) | best {best} ({fl / rows_out[0][0] / 1e6:6.1f} TF/s)", flush=True)
