@@ -226,3 +226,17 @@ def test_refiner_spec_and_fp8_pass_counts():
     assert st["fp8_plan"]["ln_projections"] == 2 * 44 and st["fp8_plan"]["ff_out_projections"] == 44 and st["layer_norm_in_gemm"] == 3 * 44
     left = [n for n in gm.graph.nodes if n.op == "call_module"]
     assert not [n for n in left if isinstance(gm.get_submodule(n.target), (nn.Linear, nn.Conv2d, nn.GroupNorm, nn.LayerNorm, nn.Dropout))]
+
+
+def test_magic_number_division_is_exact_where_the_kernels_use_it():
+    """csrc/gemm_core.h magic_u32 / mg_div: floor(n / d) = (n * (floor(2^32 / d) + 1)) >> 32 whenever n * d < 2^32 - the
+    block -> tile map of every GEMM-shaped launch (fill_tile_map falls back to real divisions beyond that)."""
+    import random
+    rng = random.Random(7)
+    for d in list(range(2, 600)) + [rng.randrange(600, 1 << 16) for _ in range(400)]:
+        mg = (1 << 32) // d + 1
+        assert mg < (1 << 32)
+        lim = ((1 << 32) - 1) // d
+        for n in [0, 1, d - 1, d, d + 1, 2 * d - 1, lim - 1, lim] + [rng.randrange(0, lim + 1) for _ in range(60)]:
+            if 0 <= n <= lim:
+                assert (n * mg) >> 32 == n // d, (n, d)
