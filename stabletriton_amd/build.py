@@ -81,27 +81,39 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(jobs))) as ex:
         objs = list(ex.map(compile_one, jobs))
     out = lib_path()
-    if force or not os.path.exists(out) or any(not j[4] for j in jobs):
+    link_stamp = os.path.join(LIBDIR, "link.sha")
+    want = _link_digest([j[3] for j in jobs])
+    linked = os.path.exists(link_stamp) and open(link_stamp).read() == want
+    if force or not os.path.exists(out) or not linked or any(not j[4] for j in jobs):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", *objs, "-o", out]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
+        with open(link_stamp, "w") as f:
+            f.write(want)
     return out
+
+
+def _link_digest(source_digests) -> str:
+    """What the linked library was made of: the digests of all its sources, in order (no file times: a copied tree keeps none)."""
+    return hashlib.sha256("\n".join(source_digests).encode()).hexdigest()
 
 
 def stale_sources() -> list:
     """Sources whose object (or the linked library) was not built from what is in the tree now: [] = the .so is this source.
     A failed compile leaves the previous .so in place; tests and bench.py refuse to measure that (tests/conftest.py)."""
     objdir = os.path.join(LIBDIR, "obj")
-    out = []
-    lib_m = os.path.getmtime(lib_path()) if os.path.exists(lib_path()) else 0.0
+    out, digests = [], []
     for src in _sources():
         obj = os.path.join(objdir, src[:-4] + ".o")
         stamp = obj + ".sha"
-        if not (os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == _digest(os.path.join(CSRC, src))):
+        dg = _digest(os.path.join(CSRC, src))
+        digests.append(dg)
+        if not (os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dg):
             out.append(src)
-        elif os.path.getmtime(obj) > lib_m + 1.0:
-            out.append(src + " (not linked)")
+    link_stamp = os.path.join(LIBDIR, "link.sha")
+    if not out and not (os.path.exists(lib_path()) and os.path.exists(link_stamp) and open(link_stamp).read() == _link_digest(digests)):
+        out.append(LIBNAME + " (objects not linked)")
     return out
 
 
