@@ -365,13 +365,19 @@ def rccl_report(path):
             "channels": len(set(re.findall(r"Channel (\d+)", txt)))}
 
 
-def rccl_self_check(report, world):
-    """Under backend=nccl the communicator RCCL built must span every rank: a mismatch (or no init record at all) fails
-    the run - the caller exits non-zero, which `self_launch` / torchrun turn into a failed job.  Returns the message or None."""
-    if report is None:
-        return "RCCL wrote no init log (NCCL_DEBUG_FILE missing): the communicator cannot be verified"
-    if report.get("nranks_logged") != world:
-        return f"RCCL logged a communicator of {report.get('nranks_logged')} ranks, the job has {world}"
+def rccl_self_check(report, world, ranks_seen=None):
+    """Under backend=nccl the communicator RCCL built must span every rank.  Two witnesses: the all-reduce of ones every
+    rank took part in (`ranks_seen`), and RCCL's own init log.  A witness that contradicts `world` fails the run - the caller
+    exits non-zero, which `self_launch` / torchrun turn into a failed job.  A log that is missing or holds no init record
+    (NCCL_DEBUG preset by the environment, another log format) fails the run only when there is no all-reduce witness
+    either: a working 8-GPU job must not die of a parser.  Returns the message or None."""
+    if ranks_seen is not None and ranks_seen != world:
+        return f"the all-reduce over the communicator saw {ranks_seen} ranks, the job has {world}"
+    logged = None if report is None else report.get("nranks_logged")
+    if logged is None:
+        return None if ranks_seen == world else "RCCL wrote no init record and no all-reduce witness exists: the communicator cannot be verified"
+    if logged != world:
+        return f"RCCL logged a communicator of {logged} ranks, the job has {world}"
     return None
 
 
@@ -470,7 +476,9 @@ def main():
             result["backend"] = args.backend
             if rccl_log:
                 result["rccl"] = rccl_report(rccl_log)
-                rccl_problem = rccl_self_check(result["rccl"], world) if rank == 0 else None
+                rccl_problem = rccl_self_check(result["rccl"], world, ranks_seen) if rank == 0 else None
+                if result["rccl"] is None or result["rccl"].get("nranks_logged") is None:
+                    result["rccl_note"] = "no init record in RCCL's log (NCCL_DEBUG preset?): verified by the all-reduce witness only"
         if rank == 0 and world == 1:
             if not args.no_census:
                 fam, census_ms, marker_ms, glue_ms = census(loop)

@@ -112,4 +112,8 @@ def test_rccl_self_check_fails_a_partial_communicator(tmp_path):
     """backend=nccl: the first real multi-GPU run checks itself - a communicator that does not span the job is an error."""
     assert bench.rccl_self_check({"nranks_logged": 8, "transports": ["P2P/IPC"], "channels": 2}, 8) is None
     assert "8" in bench.rccl_self_check({"nranks_logged": 4, "transports": [], "channels": 0}, 8)
-    assert bench.rccl_self_check(None, 2) is not None
+    assert bench.rccl_self_check(None, 2) is not None                      # no log and no all-reduce witness
+    assert bench.rccl_self_check(None, 2, ranks_seen=2) is None              # the all-reduce saw every rank: a missing log does not kill the job
+    assert bench.rccl_self_check({"nranks_logged": None, "transports": [], "channels": 0}, 8, ranks_seen=8) is None
+    assert "4" in bench.rccl_self_check({"nranks_logged": 8, "transports": [], "channels": 0}, 8, ranks_seen=4)
+    assert "4" in bench.rccl_self_check({"nranks_logged": 4, "transports": [], "channels": 0}, 8, ranks_seen=8)
