@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--latent", type=int, default=128)
     ap.add_argument("--mode", choices=["auto", "loop", "step", "eager"], default="auto")
-    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
+    ap.add_argument("--dtype", choices=["bf16", "fp16", "fp32"], default="bf16",
                     help="compute / storage type of the timed run (same matrix-pipe rate; fp16 is the reference call site's own type)")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements of the N=1 line (loop-graph replay when the "
                                                              "timed mode is 'step', the other 16-bit type, strict fp32)")
@@ -408,7 +408,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
     if args.fp8 and dtype != torch.bfloat16:
         raise SystemExit("--fp8 runs on a bf16 model")
     n_sched = 50

@@ -100,8 +100,8 @@ def _linear_emit8(a):
 def _linear_fp8x(a):
     M, N, K, epi = a[8], a[9], a[10], a[14]
     rows = 2 * N if epi & GEGLU else N
-    out_bytes = (2 * M * N if a[7] else 0) + (M * N if a[24] else 0)
-    return "linear_fp8", 2.0 * M * rows * K, float(M * K + rows * K + out_bytes), f"M={M} N={N} K={K} fp8x epi={epi}" + (" ln" if a[17] else "") + (" +e4m3 copy" if a[24] else "")
+    out_bytes = (2 * M * N if a[7] else 0) + (M * N if a[23] else 0)
+    return "linear_fp8", 2.0 * M * rows * K, float(M * K + rows * K + out_bytes), f"M={M} N={N} K={K} fp8x epi={epi}" + (" ln" if a[17] else "") + (" +e4m3 copy" if a[23] else "")
 
 
 DECODERS = {"st_linear": _linear, "st_linear_emit8": _linear_emit8, "st_linear_fp8x": _linear_fp8x, "st_ln_linear": _ln_linear, "st_ln_linear_xattn": _ln_linear_xattn, "st_attention": _attention,
