@@ -26,7 +26,13 @@ extern "C" {
 /* element types of activations/weights; accumulation is always fp32.  ST_F16 (IEEE half) is the type the reference's
  * own call site computes in (implementations/Diffusers/load_sdxl_pipeline.py:17-28 passes a .half() module;
  * optimizers/replace_attention.py:91 casts q/k/v to fp16): same matrix-pipe rate as bf16, 10 mantissa bits. */
-enum { ST_F32 = 0, ST_BF16 = 1, ST_F16 = 2 };
+enum { ST_F32 = 0, ST_BF16 = 1, ST_F16 = 2,
+       /* ST_F32S, accepted by the GEMM-shaped entry points only (st_linear, st_ln_linear, st_conv2d, st_conv1x1_cat): the
+        * matrix operands x and W are "split fp32" images written by st_split_f32 (or by a producer's epilogue) - every value
+        * as two IEEE halves, x ~ hi + lo * 2^-11, 4 bytes per value, row segments of 32 values = [32 hi | 32 lo] - and the
+        * product runs as three 16-bit MFMAs per 32 k with fp32 accumulation (22 significant bits per operand); bias,
+        * residual, row bias, statistics and y are plain fp32.  The strict (fp32-parity) mode's matrix path. */
+       ST_F32S = 3 };
 
 /* activation-tensor layouts for the image-shaped ops */
 enum { ST_NCHW = 0, ST_NHWC = 1 };
@@ -40,12 +46,12 @@ enum {
     ST_EPI_ROWBIAS   = 16   /* + rowbias[batch(m)][n]     (time-embedding add)    */
 };
 
-int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 12
+int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 13
                                               (6: next-weights hint passed per call, st_timestep_sincos; 7: fp8 entry points; 8: GroupNorm partials from the
                                               producer; 9: st_ln_linear_xattn; 10: ST_F16 accepted by every entry point
                                               that takes a dtype, st_ln_linear_xattn takes a dtype; 11: fp8 plan with
                                               delayed per-tensor scaling - st_linear_emit8, st_linear_fp8x, st_fp8_update_scales; 12: readers of a channel
-                                              concatenation that is never written - st_group_norm_from_stats_cat, st_conv1x1_cat) */
+                                              concatenation that is never written - st_group_norm_from_stats_cat, st_conv1x1_cat; 13: ST_F32S split fp32 matrix operands, st_split_f32) */
 const char* st_last_error(void);           /* host string, thread-local     */
 
 /* GroupNorm (+SiLU).  Replaces reference group_norm_wrapper
@@ -255,6 +261,12 @@ int st_linear_fp8x(const void* xq, const float* a_scale, int a_scale_stride, con
                    void* q8, long ldq8, const float* q8_inv_scale, unsigned int* q8_amax,
                    void* workspace, size_t workspace_bytes, const void* next_weights, size_t next_weights_bytes, void* stream);
 int st_fp8_update_scales(float* scale, float* inv_scale, unsigned int* amax_parts, int n_tensors, float margin, void* stream);
+
+/* Split fp32 images (ST_F32S above; the matrix operands of the strict mode): x (rows, K) fp32, row stride ldx elements ->
+ * xs (rows, K) contiguous, 4 bytes per value: per row and per group of 32 consecutive k one 128-byte segment, bytes [0, 64)
+ * hi[k] = f16(x[k]), bytes [64, 128) lo[k] = f16((x[k] - hi[k]) * 2048).  K % 32 == 0.  No reference counterpart: the
+ * reference's strict path is torch eager fp32 (optimizers/unet_pt.py:469-542). */
+int st_split_f32(const float* x, void* xs, long rows, int K, long ldx, void* stream);
 
 /* The reference's own timestep operator, elementwise (optimizers/replace_timesteps.py:33-40 ->
  * kernels/timestep.py:13-45): x is fp32 of shape (..., half), n elements in all;

@@ -13,10 +13,10 @@ import torch  # noqa: F401  (loads torch's libamdhip64 first so ours binds to th
 
 from .build import lib_path
 
-ST_F32, ST_BF16, ST_F16 = 0, 1, 2
+ST_F32, ST_BF16, ST_F16, ST_F32S = 0, 1, 2, 3
 ST_NCHW, ST_NHWC = 0, 1
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_RESIDUAL, EPI_ROWBIAS = 1, 2, 4, 8, 16
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _p, _i, _l, _f, _z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
@@ -46,6 +46,7 @@ SIGNATURES = {
     "st_linear_emit8": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _p, _z, _p, _i, _p, _p, _i, _p, _p, _l, _p, _p, _p, _z, _p]),
     "st_linear_fp8x": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _i, _p, _p, _f, _p, _i, _p, _p, _l, _p, _p, _p, _z, _p, _z, _p]),
     "st_fp8_update_scales": (_i, [_p, _p, _p, _i, _f, _p]),
+    "st_split_f32": (_i, [_p, _p, _l, _i, _l, _p]),
 }
 
 _lib = None

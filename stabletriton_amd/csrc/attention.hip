@@ -13,7 +13,7 @@
 //     is reused directly as the B operand of O^T = V^T P^T (no LDS round trip for P); V^T fragments come from
 //     ds_read_b64_tr_b16 on the row-major V image; K and V images are XOR-swizzled per 16-byte chunk on the DMA source
 //     side so the fragment reads are conflict-free; keys beyond S are zero-filled and masked.
-// fp32 kernel ("strict" parity mode): plain FMA online softmax, one query row per thread.
+// fp32 ("strict" parity mode): attention_f32.hip.
 #define ST_ATTENTION_TU 1
 #include "attention_core.h"
 
@@ -375,78 +375,9 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
     }
 }
 
-// ---- fp32 strict kernel: thread = one query row, keys in tiles of 32 via LDS ----
-__global__ __launch_bounds__(128) void attn_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K,
-                                                       const float* __restrict__ V, float* __restrict__ O, int T, int S,
-                                                       long ldq, long ldk, long ldv, long ldo, float scale) {
-    constexpr int KT = 32;
-    __shared__ __attribute__((aligned(16))) float ks[KT][ATT_D];
-    __shared__ __attribute__((aligned(16))) float vs[KT][ATT_D];
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int qi = blockIdx.x * 128 + threadIdx.x;
-    const int qrow = min(qi, T - 1);
-    const float* qp = Q + (size_t)b * T * ldq + (size_t)qrow * ldq + (size_t)head * ATT_D;
-    const float* Kb = K + (size_t)b * S * ldk + (size_t)head * ATT_D;
-    const float* Vb = V + (size_t)b * S * ldv + (size_t)head * ATT_D;
-    float q[ATT_D], o[ATT_D];
-#pragma unroll
-    for (int d = 0; d < ATT_D; d += 4) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(qp + d);
-        q[d] = v[0]; q[d + 1] = v[1]; q[d + 2] = v[2]; q[d + 3] = v[3];
-        o[d] = o[d + 1] = o[d + 2] = o[d + 3] = 0.f;
-    }
-    float m = -1e30f, l = 0.f;
-    for (int k0 = 0; k0 < S; k0 += KT) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < KT * ATT_D / 4; i += 128) {
-            const int row = i / (ATT_D / 4), c = (i - row * (ATT_D / 4)) * 4;
-            const int key = k0 + row;
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (key < S) {
-                kv = *reinterpret_cast<const f32x4*>(Kb + (size_t)key * ldk + c);
-                vv = *reinterpret_cast<const f32x4*>(Vb + (size_t)key * ldv + c);
-            }
-            *reinterpret_cast<f32x4*>(&ks[row][c]) = kv;
-            *reinterpret_cast<f32x4*>(&vs[row][c]) = vv;
-        }
-        __syncthreads();
-        const int nk = min(KT, S - k0);
-        float sc[KT];
-        float mx = -1e30f;
-#pragma unroll
-        for (int j = 0; j < KT; ++j) {
-            float a = 0.f;
-#pragma unroll
-            for (int d = 0; d < ATT_D; ++d) a = fmaf(q[d], ks[j][d], a);
-            a *= scale;
-            sc[j] = j < nk ? a : -1e30f;
-            mx = fmaxf(mx, sc[j]);
-        }
-        const float m_new = fmaxf(m, mx);
-        const float alpha = expf(m - m_new);
-        m = m_new;
-        l *= alpha;
-#pragma unroll
-        for (int d = 0; d < ATT_D; ++d) o[d] *= alpha;
-#pragma unroll
-        for (int j = 0; j < KT; ++j) {
-            const float pj = j < nk ? expf(sc[j] - m_new) : 0.f;
-            l += pj;
-#pragma unroll
-            for (int d = 0; d < ATT_D; ++d) o[d] = fmaf(pj, vs[j][d], o[d]);
-        }
-    }
-    if (qi < T) {
-        float* op = O + (size_t)b * T * ldo + (size_t)qi * ldo + (size_t)head * ATT_D;
-        const float inv = 1.0f / l;
-#pragma unroll
-        for (int d = 0; d < ATT_D; d += 4) {
-            f32x4 v = {o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv};
-            *reinterpret_cast<f32x4*>(op + d) = v;
-        }
-    }
-}
-
+// fp32 ("strict" parity mode): attention_f32.hip - split operands on the 16-bit matrix pipe, fp32 softmax
+int attention_f32_launch(const float* q, const float* k, const float* v, float* out, int B, int T, int S, int H,
+                         long ldq, long ldk, long ldv, long ldo, float scale, hipStream_t st);
 
 template <typename E>
 static int attention16_launch(const void* q, const void* k, const void* v, void* out, int B, int T, int S, int H,
@@ -500,11 +431,6 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ST_BF16) return attention16_launch<bf16>(q, k, v, out, B, T, S, H, ldq, ldk, ldv, ldo, scale, st);
     if (dtype == ST_F16) return attention16_launch<f16>(q, k, v, out, B, T, S, H, ldq, ldk, ldv, ldo, scale, st);
-    if (dtype == ST_F32) {
-        hipLaunchKernelGGL(attn_f32_kernel, dim3(cdiv(T, 128), H, B), dim3(128), 0, st, (const float*)q, (const float*)k,
-                           (const float*)v, (float*)out, T, S, ldq, ldk, ldv, ldo, scale);
-    } else {
-        return st_fail("attention: unsupported dtype %d", dtype);
-    }
-    return st_check_launch("attention");
+    if (dtype == ST_F32) return attention_f32_launch((const float*)q, (const float*)k, (const float*)v, (float*)out, B, T, S, H, ldq, ldk, ldv, ldo, scale, st);
+    return st_fail("attention: unsupported dtype %d", dtype);
 }

@@ -149,3 +149,5 @@ static inline void ensure_dynamic_lds(K kernel, size_t bytes, unsigned long long
 // dtype code of the C ABI -> element size / checks shared by the entry points
 static inline bool st_dtype_is16(int dtype) { return dtype == ST_BF16 || dtype == ST_F16; }
 static inline bool st_dtype_ok(int dtype) { return dtype == ST_F32 || st_dtype_is16(dtype); }
+// the GEMM-shaped entry points also take ST_F32S (split fp32 matrix operands; everything the epilogue touches is fp32)
+static inline bool st_dtype_ok_gemm(int dtype) { return st_dtype_ok(dtype) || dtype == ST_F32S; }

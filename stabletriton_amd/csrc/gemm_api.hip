@@ -16,6 +16,7 @@ static int run_dense(const GemmArgs& a, int dtype, hipStream_t st) {
     switch (dtype) {
         case ST_BF16: return gemm_dense_bf16(a, st);
         case ST_F16: return gemm_dense_f16(a, st);
+        case ST_F32S: return gemm_dense_f32s(a, st);
         default: return gemm_dense_f32(a, st);
     }
 }
@@ -37,8 +38,8 @@ static int linear_impl(const void* x, const void* W, const void* bias, const voi
     if (col_stats_rows) *col_stats_rows = 0;
     ST_REQUIRE(x && W && y, "linear: null pointer");
     ST_REQUIRE(M > 0 && N > 0 && K > 0, "linear: bad shape M=%d N=%d K=%d", M, N, K);
-    ST_REQUIRE(st_dtype_ok(dtype), "linear: unsupported dtype %d", dtype);
-    const int vec = st_dtype_is16(dtype) ? 8 : 4;
+    ST_REQUIRE(st_dtype_ok_gemm(dtype), "linear: unsupported dtype %d", dtype);
+    const int vec = st_dtype_is16(dtype) ? 8 : (dtype == ST_F32S ? 32 : 4);      // (split operands: whole 32-value segments)
     ST_REQUIRE(K % vec == 0 && lda % vec == 0, "linear: K=%d and lda=%ld must be multiples of %d", K, lda, vec);
     ST_REQUIRE(ldc % 4 == 0 && (!(epilogue & ST_EPI_RESIDUAL) || ldr % 4 == 0), "linear: ldc/ldr must be multiples of 4");
     ST_REQUIRE(((uintptr_t)x | (uintptr_t)W) % 16 == 0 && (uintptr_t)y % 16 == 0, "linear: pointers must be 16-byte aligned");
@@ -91,9 +92,9 @@ extern "C" int st_ln_linear(const void* x, const float* row_stats, int row_stats
     ST_REQUIRE(x && Wg && c && d && y && row_stats, "ln_linear: null pointer");
     ST_REQUIRE(row_stats_chunks > 0, "ln_linear: the producer emitted no row statistics");
     ST_REQUIRE(M > 0 && N > 0 && K > 0, "ln_linear: bad shape M=%d N=%d K=%d", M, N, K);
-    ST_REQUIRE(st_dtype_ok(dtype), "ln_linear: unsupported dtype %d", dtype);
+    ST_REQUIRE(st_dtype_ok_gemm(dtype), "ln_linear: unsupported dtype %d", dtype);
     const int kb = st_dtype_is16(dtype) ? 64 : 32;
-    ST_REQUIRE(K % kb == 0 && lda % (kb / 8) == 0, "ln_linear: K=%d must be a multiple of %d", K, kb);
+    ST_REQUIRE(K % kb == 0 && lda % (dtype == ST_F32S ? 32 : kb / 8) == 0, "ln_linear: K=%d must be a multiple of %d", K, kb);
     ST_REQUIRE(ldc % 4 == 0, "ln_linear: ldc must be a multiple of 4");
     ST_REQUIRE((epilogue & ~ST_EPI_GEGLU) == 0, "ln_linear: only the GEGLU epilogue flag is accepted (bias lives in d)");
     ST_REQUIRE(((uintptr_t)x | (uintptr_t)Wg | (uintptr_t)y) % 16 == 0, "ln_linear: pointers must be 16-byte aligned");
@@ -194,7 +195,7 @@ extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const v
     ST_REQUIRE(x && W && y, "conv2d: null pointer");
     ST_REQUIRE(N > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0,
                "conv2d: bad geometry");
-    ST_REQUIRE(st_dtype_ok(dtype), "conv2d: unsupported dtype %d", dtype);
+    ST_REQUIRE(st_dtype_ok_gemm(dtype), "conv2d: unsupported dtype %d", dtype);
     ST_REQUIRE(!(epilogue & ST_EPI_GEGLU), "conv2d: GEGLU epilogue not supported");
     ST_REQUIRE(Cout % 4 == 0, "conv2d: Cout=%d must be a multiple of 4", Cout);
     const int He = upsample2x ? 2 * Hin : Hin, We = upsample2x ? 2 * Win : Win;
@@ -220,8 +221,10 @@ extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const v
         ST_REQUIRE(((uintptr_t)x | (uintptr_t)W | (uintptr_t)y) % 16 == 0, "conv2d: pointers must be 16-byte aligned");
         if (dtype == ST_BF16) return gemm_conv_bf16(a, R, upsample2x, st);
         if (dtype == ST_F16) return gemm_conv_f16(a, R, upsample2x, st);
+        if (dtype == ST_F32S) return gemm_conv_f32s(a, st);
         return gemm_conv_f32(a, st);
     }
+    ST_REQUIRE(dtype != ST_F32S, "conv2d: split fp32 operands need Cin=%d to be a multiple of 32 (thin inputs take plain ST_F32)", Cin);
     // thin-input path: K = R*S*Cin small enough to keep one pixel's inputs in registers
     ST_REQUIRE(a.K <= 64 && Cout % 16 == 0, "conv2d: Cin=%d is neither a multiple of %d (implicit GEMM) nor thin (R*S*Cin <= 64, Cout %% 16 == 0)", Cin, kb);
     return conv_thin_run(a, R, dtype, st);
@@ -237,7 +240,7 @@ extern "C" int st_conv1x1_cat(const void* x0, int C0, const void* x1, int C1, co
     if (col_stats_rows) *col_stats_rows = 0;
     ST_REQUIRE(x0 && x1 && W && y, "conv1x1_cat: null pointer");
     ST_REQUIRE(N > 0 && H > 0 && Wd > 0 && C0 > 0 && C1 > 0 && Cout > 0, "conv1x1_cat: bad geometry");
-    ST_REQUIRE(st_dtype_ok(dtype), "conv1x1_cat: unsupported dtype %d", dtype);
+    ST_REQUIRE(st_dtype_ok_gemm(dtype), "conv1x1_cat: unsupported dtype %d", dtype);
     ST_REQUIRE(!(epilogue & (ST_EPI_GEGLU | ST_EPI_ROWBIAS)), "conv1x1_cat: GEGLU / row-bias epilogues not supported");
     ST_REQUIRE(Cout % 4 == 0, "conv1x1_cat: Cout=%d must be a multiple of 4", Cout);
     const int kb = st_dtype_is16(dtype) ? 64 : 32;
@@ -256,5 +259,6 @@ extern "C" int st_conv1x1_cat(const void* x0, int C0, const void* x1, int C1, co
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ST_BF16) return gemm_conv_bf16(a, 1, 0, st);
     if (dtype == ST_F16) return gemm_conv_f16(a, 1, 0, st);
+    if (dtype == ST_F32S) return gemm_conv_f32s(a, st);
     return gemm_conv_f32(a, st);
 }

@@ -121,9 +121,36 @@ template <> struct Mma<f8> {
         acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc, 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
     }
 };
+// Split fp32 operands (ST_F32S, the strict mode's matrix operands): a value x is held as two IEEE halves,
+//     x ~ hi + lo * 2^-11,   hi = f16(x),   lo = f16((x - hi) * 2^11)          (22 significant bits, csrc/split.h)
+// laid out so that a 128-byte row segment still holds 32 consecutive k: bytes [0, 64) the 32 hi halves, [64, 128) the 32 lo
+// halves - every address computation of the fp32 path (4 bytes per element, K tiles of 32) holds unchanged, and a lane
+// (row r, lane group q) finds the k = 8q .. 8q+7 of its row in the 16-byte chunks q (hi) and q + 4 (lo), exactly where
+// the e4m3 path reads its two chunks.  A product takes three v_mfma_f32_16x16x32_f16 (hi.hi into the main accumulator,
+// hi.lo and lo.hi into a correction accumulator that joins it times 2^-11 after the K loop; lo.lo ~ 2^-22 of the product
+// is dropped): 3 x 16 cycles for 32 k against 8 x 32 cycles of v_mfma_f32_16x16x4_f32, with the same fp32 accumulation.
+struct fsp { float raw; };
+template <> struct Mma<fsp> {
+    typedef i32x8 Frag;              // 32 bytes of one row: [0, 16) eight hi halves, [16, 32) the eight lo halves of the same k
+    static __device__ __forceinline__ void run2(f32x4& acc, f32x4& corr, const Frag& a, const Frag& b) {
+        typedef __attribute__((ext_vector_type(4))) int i32x4_;
+        const f16x8 ah = __builtin_bit_cast(f16x8, (i32x4_)__builtin_shufflevector(a, a, 0, 1, 2, 3));
+        const f16x8 al = __builtin_bit_cast(f16x8, (i32x4_)__builtin_shufflevector(a, a, 4, 5, 6, 7));
+        const f16x8 bh = __builtin_bit_cast(f16x8, (i32x4_)__builtin_shufflevector(b, b, 0, 1, 2, 3));
+        const f16x8 bl = __builtin_bit_cast(f16x8, (i32x4_)__builtin_shufflevector(b, b, 4, 5, 6, 7));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+        corr = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, corr, 0, 0, 0);
+        corr = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, corr, 0, 0, 0);
+    }
+};
+static constexpr float ST_SPLIT_INV = 1.0f / 2048.0f;      // weight of the lo halves (csrc/split.h: ST_SPLIT_SCALE = 2^11)
+template <typename T> constexpr bool is_fp8() { return std::is_same<T, f8>::value; }
+template <typename T> constexpr bool is_split() { return std::is_same<T, fsp>::value; }
+template <typename T> constexpr bool frag2() { return is_fp8<T>() || is_split<T>(); }      // an MFMA operand = chunks q and q + 4 of the 128-byte row
 template <typename T> struct OutT { typedef T type; };
 template <> struct OutT<f8> { typedef bf16 type; };
-template <typename T> constexpr int mfma_per_frag() { return sizeof(T) == 4 ? 4 : 1; }
+template <> struct OutT<fsp> { typedef float type; };
+template <typename T> constexpr int mfma_per_frag() { return is_split<T>() ? 3 : (sizeof(T) == 4 ? 4 : 1); }
 
 template <typename T> struct Out4;
 template <> struct Out4<bf16> {
@@ -1558,6 +1585,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // split fp32 operands: the cross products (hi.lo + lo.hi, in units of 2^-11) accumulate apart from the main products
+    f32x4 corr[is_split<T>() ? TM : 1][is_split<T>() ? TN : 1];
+    if constexpr (is_split<T>()) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) corr[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     const int r16 = lane & 15, q = lane >> 4;
     const int nk = nk_hi - nk_lo;
 
@@ -1596,14 +1631,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     // Software pipeline (one wave per SIMD has nobody else to hide LDS latency behind):
     // the fragments of MFMA group g+1 are read while group g multiplies, and the LAST group
     // of a stage multiplies after the stage barrier, under the first reads of the next stage.
-    constexpr int GPT = sizeof(T) == 1 ? 1 : 2;    // MFMA groups per K tile: two 64-byte halves; fp8: the whole 128-byte row per instruction
+    constexpr int GPT = frag2<T>() ? 1 : 2;        // MFMA groups per K tile: two 64-byte halves; fp8 / split fp32: the whole 128-byte row per operand
     constexpr int NG = GPT * U;                   // MFMA groups per stage
-    constexpr int RPF = sizeof(T) == 1 ? 2 : 1;   // 16-byte LDS reads per fragment
+    constexpr int RPF = frag2<T>() ? 2 : 1;        // 16-byte LDS reads per fragment
     // with only two buffers the whole prefetch must be issued before the stage barrier (group 0)
     constexpr bool EARLY = (STAGES == 2);
     Frag fa[2][TM], fb[2][TN];
     auto read_frag = [&](const char* base, int row, int g) -> Frag {
-        if constexpr (sizeof(T) == 1) {
+        if constexpr (frag2<T>()) {
             const u32x4 lo = *reinterpret_cast<const u32x4*>(base + row * 128 + ((q ^ (row & 7)) << 4));
             const u32x4 hi = *reinterpret_cast<const u32x4*>(base + row * 128 + (((q + 4) ^ (row & 7)) << 4));
             return Frag{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
@@ -1636,7 +1671,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], fb[set][j], fa[set][i]);
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (is_split<T>()) Mma<T>::run2(acc[i][j], corr[i][j], fb[set][j], fa[set][i]);
+                else Mma<T>::run(acc[i][j], fb[set][j], fa[set][i]);
+            }
     };
 
     int cur = 0, nxt = STAGES - 1;
@@ -1710,6 +1748,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         }
     }
     wait_vmcnt<0>();                              // no LDS-DMA may outlive the workgroup's LDS allocation
+    if constexpr (is_split<T>()) {                // one fused multiply-add per element: the same bits whatever follows
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = __builtin_fmaf(corr[i][j][e], ST_SPLIT_INV, acc[i][j][e]);
+    }
     PROBE_STAMP(pr_end)
     if (p.splitk > 1) {
         if (!splitk_combine<TM, TN, BM * BN>(p, acc, tw, split, lds, t, wave, lane)) {
@@ -1764,7 +1810,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
 #else
         unsigned long long* const ept = nullptr;
 #endif
-        staged_epilogue<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, STAGES * STAGE, !LNF, sizeof(T) == 1>(
+        staged_epilogue<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, STAGES * STAGE, !LNF, is_fp8<T>()>(
             p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds, reinterpret_cast<const float2*>(lds + STAGES * STAGE), ept);
 #ifdef ST_PROBE
         pr_x = ept[0] - pr_end; pr_d = ept[1] - ept[0];
@@ -1784,10 +1830,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         const bool inside = (m0 + BM <= p.M) && (n0 + BNO <= p.N) && (p.N & 3) == 0 && p.C != nullptr && !p.q8_out;
         const int flags = inside ? (((p.epi & ST_EPI_BIAS) ? EPI_F_BIAS : 0) | (p.epi & (ST_EPI_RESIDUAL | ST_EPI_ROWBIAS | ST_EPI_SILU) ? 1024 : 0) |
                                     (p.col_scale ? EPI_F_SCALE : 0) | EPI_F_LN) : -1;
-        if (sizeof(T) != 1 && flags == EPI_F_LN) gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, 0, 0, false, EPI_F_LN>(p, acc, m0, n0, wm, wn, r16, q, split, mean, rstd);
-        else if (sizeof(T) != 1 && flags == (EPI_F_LN | EPI_F_BIAS))
+        if (!is_fp8<T>() && flags == EPI_F_LN) gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, 0, 0, false, EPI_F_LN>(p, acc, m0, n0, wm, wn, r16, q, split, mean, rstd);
+        else if (!is_fp8<T>() && flags == (EPI_F_LN | EPI_F_BIAS))
             gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, 0, 0, false, EPI_F_LN | EPI_F_BIAS>(p, acc, m0, n0, wm, wn, r16, q, split, mean, rstd);
-        else if (sizeof(T) == 1 && flags == (EPI_F_LN | EPI_F_SCALE))
+        else if (is_fp8<T>() && flags == (EPI_F_LN | EPI_F_SCALE))
             gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, 0, 0, false, EPI_F_LN | EPI_F_SCALE>(p, acc, m0, n0, wm, wn, r16, q, split, mean, rstd);
         else gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wm, wn, r16, q, split, mean, rstd);
     } else {
@@ -1804,7 +1850,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
     case (M):                                                                                                                                  \
         gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, WGM, WGN, false, (M)>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n); \
         break;
-        if constexpr (sizeof(T) != 1) {
+        if constexpr (!is_fp8<T>()) {
             switch (flags) {
                 ST_FRAG_CASE(EPI_F_BIAS)
                 ST_FRAG_CASE(EPI_F_BIAS | EPI_F_RES)
@@ -2489,8 +2535,8 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
     auto tiles = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(n_eff, bn); };
     constexpr int KB = 128 / (int)sizeof(T);
     const char* who = CONV ? "conv2d" : "linear";
-    if constexpr (sizeof(T) == 1) {
-        if (a.K % KB != 0) return st_fail("%s: fp8 operands need K to be a multiple of %d", who, KB);
+    if constexpr (frag2<T>()) {
+        if (a.K % KB != 0) return st_fail("%s: fp8 / split fp32 operands need K to be a multiple of %d", who, KB);
     } else if (a.K % KB != 0) {                  // ragged K: register-staged kernel (no LayerNorm partials)
         if (a.stats_chunks_out) *a.stats_chunks_out = 0;
         if (tiles(128, 128) >= 240) launch_cfg<T, 128, 128, 2, 2, CONV>(a, st);
@@ -2498,7 +2544,7 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
         else launch_cfg<T, 64, 64, 2, 2, CONV>(a, st);
         return st_check_launch(who);
     }
-    if constexpr (sizeof(T) == 4) {              // strict fp32 mode: one configuration, speed is not the point
+    if constexpr (std::is_same<T, float>::value) {      // plain fp32 operands on the exact fp32 MFMA (ragged shapes of the strict mode; its matrix work runs on split operands): one configuration
         GemmArgs b = a;
         b.stats_chunks = cdiv(a.N, 64);
         if (a.stats_chunks_out) *a.stats_chunks_out = a.row_stats ? b.stats_chunks : 0;
@@ -2527,7 +2573,8 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
         int cfg = CFG_64x64_W8, sk = 1;
         double best = 1e30;
         for (const Cand& c : cands) {
-            if (sizeof(T) == 1 && c.bn == 320) continue;                 // fp8 fragments are 32 bytes: the 320-wide wave tiles spill
+            if (frag2<T>() && c.bn == 320) continue;                     // fp8 / split fragments are 32 bytes: the 320-wide wave tiles spill
+            if (is_split<T>() && (c.cfg == CFG_256x128_W8 || c.cfg == CFG_128x160_W8)) continue;      // two accumulator sets: wave tiles of at most 8 x 16 x 16
             if ((a.epi & ST_EPI_GEGLU) && c.bn % 32 != 0) continue;      // GEGLU: the value / gate halves of a tile are whole accumulator tiles (BN = 80 is not)
             const long nt = tiles(c.bm, c.bn);
             const double trip = c.trip_us * (CONV ? 1.6 : 1.0);
@@ -2841,10 +2888,12 @@ static int conv_thin_launch(const GemmArgs& a, int R, hipStream_t st) {
 int gemm_dense_bf16(const GemmArgs& a, hipStream_t st);
 int gemm_dense_f16(const GemmArgs& a, hipStream_t st);
 int gemm_dense_f32(const GemmArgs& a, hipStream_t st);
+int gemm_dense_f32s(const GemmArgs& a, hipStream_t st);
 int gemm_dense_fp8(const GemmArgs& a, hipStream_t st);
 int gemm_xattn_bf16(const GemmArgs& a, hipStream_t st);
 int gemm_xattn_f16(const GemmArgs& a, hipStream_t st);
 int gemm_conv_bf16(const GemmArgs& a, int R, int ups, hipStream_t st);      // halo kernel when it applies, else implicit GEMM
 int gemm_conv_f16(const GemmArgs& a, int R, int ups, hipStream_t st);
 int gemm_conv_f32(const GemmArgs& a, hipStream_t st);
+int gemm_conv_f32s(const GemmArgs& a, hipStream_t st);
 int conv_thin_run(const GemmArgs& a, int R, int dtype, hipStream_t st);

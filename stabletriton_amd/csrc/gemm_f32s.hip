@@ -1,0 +1,5 @@
+// One element type of the GEMM-shaped kernels (see gemm_core.h, "per-element-type runners"): split fp32 operands (ST_F32S).
+#include "gemm_core.h"
+
+int gemm_dense_f32s(const GemmArgs& a, hipStream_t st) { return gemm_dispatch<fsp, false>(a, st); }
+int gemm_conv_f32s(const GemmArgs& a, hipStream_t st) { return gemm_dispatch<fsp, true>(a, st); }

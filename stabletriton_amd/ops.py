@@ -265,6 +265,66 @@ def _is_nhwc(x: torch.Tensor) -> bool:
     return x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
 
 
+# ----------------------------------------------------------------------------- split fp32 operands (strict mode)
+# fp32 tensors meet the matrix pipe as "split" images (csrc/split.h, ST_F32S): every value as two IEEE halves, 22 significant
+# bits, three 16-bit MFMAs per product with fp32 accumulation - about five times the rate of the exact fp32 MFMA the strict
+# mode used to run on, inside the same 1e-3 gates.  STRICT_SPLIT = False takes the exact-fp32 kernels instead (tests compare).
+STRICT_SPLIT = True
+SPLIT_K = 32                  # values per 128-byte segment of a split row
+
+
+class SplitAct:
+    """A matrix operand as a split image: `s` holds the (rows, K) image in a float32-typed tensor of that shape (4 bytes per
+    value, NOT readable as floats), `shape` the logical shape of the tensor it was made from."""
+    __slots__ = ("s", "shape")
+
+    def __init__(self, s: torch.Tensor, shape):
+        self.s, self.shape = s, tuple(shape)
+
+
+def split_rows(x2: torch.Tensor, shape=None) -> SplitAct:
+    """(rows, K) fp32 with unit column stride -> its split image (one launch, 4 B in / 4 B out per value)."""
+    _C.require_device(x2)
+    rows, K = x2.shape
+    if x2.dtype != torch.float32 or K % SPLIT_K or x2.stride(1) != 1:
+        raise BackendError(f"split_rows: (rows, K) float32 with K % {SPLIT_K} == 0 expected, got {tuple(x2.shape)} {x2.dtype}")
+    out = torch.empty((rows, K), dtype=torch.float32, device=x2.device)
+    _C.check(_C.load().st_split_f32(x2.data_ptr(), out.data_ptr(), rows, K, x2.stride(0), _C.stream_ptr()), "split_f32")
+    return SplitAct(out, x2.shape if shape is None else shape)
+
+
+def split_usable(dtype: torch.dtype, K: int) -> bool:
+    return STRICT_SPLIT and dtype == torch.float32 and K % SPLIT_K == 0
+
+
+@torch.no_grad()
+def _split_weight(owner: torch.Tensor, as_rows=None, want_rowsum: bool = False):
+    """Split image of a weight, kept by the current execution context and re-derived in place when `owner` changes.
+    `as_rows(owner)` gives the (N, K) row-major view to split (default: the tensor itself); with want_rowsum also
+    c[n] = sum_k of the values the image holds (what a folded LayerNorm subtracts)."""
+
+    def compute():
+        w2 = owner.detach() if as_rows is None else as_rows(owner.detach())
+        if w2.dim() != 2 or not w2.is_contiguous():
+            raise BackendError("split weight: a row-major (N, K) view is needed")
+        img = split_rows(w2).s
+        if not want_rowsum:
+            return (img,)
+        h = img.view(torch.float16).view(w2.shape[0], w2.shape[1] // SPLIT_K, 2, SPLIT_K).double()
+        c = (h[:, :, 0, :].sum(dim=(1, 2)) + h[:, :, 1, :].sum(dim=(1, 2)) / 2048.0).float().contiguous()
+        return (img, c)
+
+    ctx = current_context(owner.device)
+    if ctx.plan is None:          # the shared default context keeps nothing alive: a launch outside a compiled module splits on the spot
+        return compute()
+    return ctx.derived_weights(("split", id(owner), want_rowsum), [owner], compute).value
+
+
+def _conv_weight_rows(w: torch.Tensor) -> torch.Tensor:
+    """(Cout, Cin, R, S) channels_last = memory [Cout][R][S][Cin] -> the (Cout * R * S, Cin) view of it"""
+    return w.permute(0, 2, 3, 1).reshape(-1, w.shape[1])
+
+
 # ----------------------------------------------------------------------------- norms
 def group_norm(x: torch.Tensor, num_groups: int, weight: torch.Tensor, bias: torch.Tensor,
                eps: float, silu: bool) -> torch.Tensor:
@@ -438,6 +498,10 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     x2, M, lda = _rows2d(x)
     N = w.shape[0] // 2 if geglu else w.shape[0]
     out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+    code = _C.dtype_code(x.dtype)
+    if split_usable(x.dtype, K) and emit_q8 is None and weight.is_contiguous():
+        # strict mode: both matrix operands as split images (the weight's is kept by the context), everything else fp32
+        x2, lda, w, code = split_rows(x2 if x2.dim() == 2 else x2.reshape(M, K)).s, K, _split_weight(weight)[0], _C.ST_F32S
     epi = 0
     if bias is not None:
         epi |= _C.EPI_BIAS
@@ -473,7 +537,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     act8 = None
     if emit_q8 is None:
         _C.check(lib.st_linear(x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
-                        lda, N, ldr, rows_per_image, epi, _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(),
+                        lda, N, ldr, rows_per_image, epi, code, gws.data_ptr(), gws.numel(),
                         _ptr(stats), 0 if stats is None else stats.shape[1],
                         None if chunks is None else ctypes.byref(chunks), _ptr(cbuf), ctiles or 0,
                         None if crows is None else ctypes.byref(crows), nxt_p, nxt_b, _C.stream_ptr()), "linear")
@@ -520,10 +584,15 @@ def ln_linear(x: torch.Tensor, stats: "RowStats", w_folded: torch.Tensor, c: tor
     x2, M, lda = _rows2d(x)
     N = w_folded.shape[0] // 2 if geglu else w_folded.shape[0]
     out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+    code = _C.dtype_code(x.dtype)
+    if split_usable(x.dtype, K) and w_folded.is_contiguous():
+        # (c must be the row sums of the values the split image holds: the fold subtracts mean * c from their products)
+        w_folded, c = _split_weight(w_folded, want_rowsum=True)
+        x2, lda, code = split_rows(x2 if x2.dim() == 2 else x2.reshape(M, K)).s, K, _C.ST_F32S
     nxt_p, nxt_b = _next_weights(w_folded)
     _C.check(lib.st_ln_linear(x2.data_ptr(), stats.buf.data_ptr(), stats.chunks, w_folded.data_ptr(),
                     c.data_ptr(), d.data_ptr(), out.data_ptr(), M, N, K,
-                    lda, N, float(eps), _C.EPI_GEGLU if geglu else 0, _C.dtype_code(x.dtype), nxt_p, nxt_b, _C.stream_ptr()), "ln_linear")
+                    lda, N, float(eps), _C.EPI_GEGLU if geglu else 0, code, nxt_p, nxt_b, _C.stream_ptr()), "ln_linear")
     return out
 
 
@@ -802,6 +871,11 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
             residual = residual.contiguous(memory_format=torch.channels_last)
         epi |= _C.EPI_RESIDUAL
     gws = _gemm_workspace(x.device)
+    code = _C.dtype_code(x.dtype)
+    if split_usable(x.dtype, Cin) and w is weight:
+        # strict mode: the pixels' channel vectors and the filter taps as split images (32 channels per segment)
+        x = split_rows(x.permute(0, 2, 3, 1).reshape(-1, Cin)).s
+        w, code = _split_weight(weight, _conv_weight_rows)[0], _C.ST_F32S
     nxt_p, nxt_b = _next_weights(w)
     cbuf = ctiles = crows = None
     if emit_colstats:
@@ -809,7 +883,7 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
         cbuf, ctiles, crows = _colstats_buffer(N * Ho * Wo, Cout, x.device)
     _C.check(lib.st_conv2d(x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(rowbias), out.data_ptr(),
                            N, H, W, Cin, Cout, R, S, stride, padding, int(upsample2x), epi,
-                           _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(), _ptr(cbuf), ctiles or 0,
+                           code, gws.data_ptr(), gws.numel(), _ptr(cbuf), ctiles or 0,
                            None if crows is None else ctypes.byref(crows), nxt_p, nxt_b, _C.stream_ptr()), "conv2d")
     if emit_colstats:
         return out, (ColStats(cbuf, crows.value, Cout) if crows.value > 0 else None)
@@ -849,13 +923,18 @@ def conv2d_cat(x0: torch.Tensor, x1: torch.Tensor, weight: torch.Tensor, bias: O
             residual = residual.contiguous(memory_format=torch.channels_last)
         epi |= _C.EPI_RESIDUAL
     gws = _gemm_workspace(x0.device)
+    code = _C.dtype_code(x0.dtype)
+    if split_usable(x0.dtype, C0) and C1 % SPLIT_K == 0 and w is weight:
+        x0 = split_rows(x0.permute(0, 2, 3, 1).reshape(-1, C0)).s
+        x1 = split_rows(x1.permute(0, 2, 3, 1).reshape(-1, C1)).s
+        w, code = _split_weight(weight, _conv_weight_rows)[0], _C.ST_F32S
     nxt_p, nxt_b = _next_weights(w)
     cbuf = ctiles = crows = None
     if emit_colstats:
         import ctypes
         cbuf, ctiles, crows = _colstats_buffer(N * H * W, Cout, x0.device)
     _C.check(lib.st_conv1x1_cat(x0.data_ptr(), C0, x1.data_ptr(), C1, w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
-                                N, H, W, Cout, epi, _C.dtype_code(x0.dtype), gws.data_ptr(), gws.numel(), _ptr(cbuf), ctiles or 0,
+                                N, H, W, Cout, epi, code, gws.data_ptr(), gws.numel(), _ptr(cbuf), ctiles or 0,
                                 None if crows is None else ctypes.byref(crows), nxt_p, nxt_b, _C.stream_ptr()), "conv2d_cat")
     if emit_colstats:
         return out, (ColStats(cbuf, crows.value, Cout) if crows.value > 0 else None)

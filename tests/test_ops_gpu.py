@@ -136,7 +136,10 @@ def test_ln_linear(gpu, dtype, M, K, N, geglu):
     # x itself must come out of a GEMM that emits the row partials: x = x0 @ I + 0 (exact in both dtypes)
     eye = torch.eye(K)
     xg, stats = ops.linear(x.to(gpu, dtype), eye.to(gpu, dtype), None, emit_stats=True)
-    assert torch.equal(xg.cpu().float(), xr)
+    if dtype == torch.float32:        # strict mode multiplies split images: 22 significant bits per operand (tests/test_split_gpu.py)
+        assert float(((xg.cpu() - xr).abs() / xr.abs().clamp_min(1e-3)).max()) <= 2.0 ** -21
+    else:
+        assert torch.equal(xg.cpu().float(), xr)
     s = stats.buf.double().sum(1).cpu()
     assert torch.allclose(s[:, 0], xr.double().sum(1), rtol=1e-5, atol=1e-3)
     assert torch.allclose(s[:, 1], (xr.double() ** 2).sum(1), rtol=1e-5, atol=1e-3)

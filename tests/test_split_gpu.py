@@ -1,0 +1,129 @@
+"""The strict mode's matrix path: split fp32 operands (csrc/split.h, ST_F32S) on the 16-bit matrix pipe.
+
+north_star's parity bound is the reference's own (optimizers/replace_attention.py:139-152: abs < 1e-3 against eager fp32);
+the strict mode meets it with every GEMM-shaped product taken as hi.hi + (hi.lo + lo.hi) * 2^-11 over two IEEE halves per
+value.  Checked here: the image is bit-for-bit the definition, the products sit within a small factor of the exact-fp32
+kernels' own error against a float64 reference, and values at both ends of the half range behave as documented."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from stabletriton_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(name, shape, scale=1.0):
+    return synth.normal(name, shape, 11) * scale
+
+
+def split_ref(x):
+    """the definition, on the CPU: (hi, lo) halves of every value"""
+    hi = x.half()
+    lo = ((x - hi.float()) * 2048.0).half()
+    return hi, lo
+
+
+@pytest.mark.parametrize("rows,K,scale", [(5, 32, 1.0), (77, 2048, 3.0), (1024, 1280, 1e-3), (3, 64, 1e-6), (16, 96, 2e4)])
+def test_split_image_is_the_definition(gpu, rows, K, scale):
+    x = rnd("sp.x", (rows, K + 32)) * scale
+    xs = ops.split_rows(x.to(gpu)[:, :K]).s          # a row stride that is not K
+    img = xs.cpu().view(torch.float16).view(rows, K // 32, 2, 32)
+    hi, lo = split_ref(x[:, :K])
+    assert torch.equal(img[:, :, 0, :].reshape(rows, K).view(torch.int16), hi.view(torch.int16))
+    assert torch.equal(img[:, :, 1, :].reshape(rows, K).view(torch.int16), lo.view(torch.int16))
+    back = hi.double() + lo.double() / 2048.0
+    normal = x[:, :K].abs() >= 2.0 ** -14
+    rel = ((back - x[:, :K].double()).abs() / x[:, :K].abs().double().clamp_min(1e-30))[normal]
+    assert rel.numel() == 0 or float(rel.max()) <= 2.0 ** -22, float(rel.max())
+    assert float((back - x[:, :K].double()).abs()[~normal].max() if (~normal).any() else 0.0) <= 2.0 ** -35
+
+
+def _err(out, ref64):
+    return float((out.double().cpu() - ref64).abs().max() / ref64.abs().max())
+
+
+@pytest.mark.parametrize("M,K,N", [(1024, 1280, 1280), (77, 2048, 640), (4096, 640, 640), (1024, 5120, 1280), (2, 320, 1280), (130, 2816, 1280)])
+def test_linear_split_against_float64(gpu, M, K, N):
+    x, w, b = rnd("spl.x", (M, K)), rnd("spl.w", (N, K)) * K ** -0.5, rnd("spl.b", (N,))
+    ref = F.linear(x.double(), w.double(), b.double())
+    xg, wg, bg = x.to(gpu), w.to(gpu), b.to(gpu)
+    assert ops.STRICT_SPLIT
+    e_split = _err(ops.linear(xg, wg, bg), ref)
+    ops.STRICT_SPLIT = False
+    try:
+        e_exact = _err(ops.linear(xg, wg, bg), ref)
+    finally:
+        ops.STRICT_SPLIT = True
+    # 22-bit operands against 24: the rounding of the operands (2^-23 each, independent) adds to the fp32 accumulation error
+    assert e_split <= 2e-6, (e_split, e_exact)
+    assert e_split <= 8 * e_exact + 2e-7, (e_split, e_exact)
+
+
+def test_linear_split_is_deterministic_and_matches_operand_rounding(gpu):
+    """The product of the split images equals, to accumulation order, the fp64 product of the values the images hold."""
+    M, K, N = 256, 640, 320
+    x, w = rnd("spd.x", (M, K)) * 4, rnd("spd.w", (N, K)) * K ** -0.5
+    xh, xl = split_ref(x)
+    wh, wl = split_ref(w)
+    xv, wv = xh.double() + xl.double() / 2048, wh.double() + wl.double() / 2048
+    ref = xv @ wv.T - (xl.double() / 2048) @ (wl.double() / 2048).T          # the lo.lo term is dropped by design
+    out = ops.linear(x.to(gpu), w.to(gpu), None)
+    assert torch.equal(out, ops.linear(x.to(gpu), w.to(gpu), None))
+    assert _err(out, ref) <= 5e-7
+
+
+@pytest.mark.parametrize("scale,bound", [(1e-6, 5e-5), (1e-3, 3e-6), (1.0, 3e-6), (3e3, 3e-6)])
+def test_split_magnitudes(gpu, scale, bound):
+    """Both ends of the half range.  Activations of a few thousand (SDXL's residual stream) are ordinary values.  Below
+    2^-14 = 6e-5 the halves are subnormal: such values keep an ABSOLUTE precision of 2^-36, not 22 bits - a tensor that is
+    1e-6 everywhere multiplies to 1e-5 relative (invisible next to the O(1) activations the 1e-3 gate is about)."""
+    M, K, N = 128, 1280, 256
+    x, w = rnd("spm.x", (M, K)) * scale, rnd("spm.w", (N, K)) * K ** -0.5
+    ref = x.double() @ w.double().T
+    assert _err(ops.linear(x.to(gpu), w.to(gpu), None), ref) <= bound
+
+
+def test_split_overflow_is_loud(gpu):
+    x = torch.full((4, 64), 1.0e5)
+    w = torch.ones(8, 64)
+    assert not torch.isfinite(ops.linear(x.to(gpu), w.to(gpu), None)).all()      # beyond the half range: inf / NaN, never a saturated product
+
+
+@pytest.mark.parametrize("cfg", [(1, 320, 32, 32, 320, 3, 1, 1, False), (2, 640, 16, 16, 640, 3, 2, 1, False), (1, 1280, 16, 16, 640, 3, 1, 1, True),
+                                 (1, 960, 16, 16, 320, 1, 1, 0, False)])
+def test_conv_split_against_float64(gpu, cfg):
+    N, Cin, H, W, Cout, k, stride, pad, ups = cfg
+    x = rnd("spc.x", (N, Cin, H, W))
+    w = rnd("spc.w", (Cout, Cin, k, k)) * (Cin * k * k) ** -0.5
+    b = rnd("spc.b", (Cout,))
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    ref = F.conv2d(xin.double(), w.double(), b.double(), stride, pad)
+    xg = x.to(gpu).contiguous(memory_format=torch.channels_last)
+    wg = w.to(gpu).contiguous(memory_format=torch.channels_last)
+    out = ops.conv2d(xg, wg, b.to(gpu), stride, pad, upsample2x=ups)
+    assert _err(out, ref) <= 2e-6
+
+
+@pytest.mark.parametrize("B,T,S,H", [(1, 1024, 1024, 4), (2, 256, 77, 3), (1, 333, 330, 2), (1, 64, 4096, 1), (1, 50, 1, 1)])
+def test_attention_fp32_against_float64(gpu, B, T, S, H):
+    q, k, v = rnd("spa.q", (B, T, H * 64)), rnd("spa.k", (B, S, H * 64)), rnd("spa.v", (B, S, H * 64))
+    qh = q.double().view(B, T, H, 64).transpose(1, 2)
+    kh = k.double().view(B, S, H, 64).transpose(1, 2)
+    vh = v.double().view(B, S, H, 64).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, dim=-1) @ vh).transpose(1, 2).reshape(B, T, H * 64)
+    out = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), H, 0.125)
+    assert _err(out, ref) <= 3e-6
+
+
+def test_attention_fp32_peaked_rows(gpu):
+    """Scores far apart (one key dominates, the maximum moves late in the row): the lazy reference maximum's slow path."""
+    B, T, S, H = 1, 128, 512, 2
+    q, k, v = rnd("spp.q", (B, T, H * 64)) * 6, rnd("spp.k", (B, S, H * 64)) * 6, rnd("spp.v", (B, S, H * 64))
+    k[:, -3, :] *= 4.0
+    qh = q.double().view(B, T, H, 64).transpose(1, 2)
+    kh = k.double().view(B, S, H, 64).transpose(1, 2)
+    vh = v.double().view(B, S, H, 64).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, dim=-1) @ vh).transpose(1, 2).reshape(B, T, H * 64)
+    out = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), H, 0.125)
+    assert _err(out, ref) <= 2e-5          # exponents of a few hundred: the scores' 2^-22 shows in the probabilities

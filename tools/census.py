@@ -8,7 +8,7 @@ launchers (ops.py) look their entry points up on the library object at every cal
 import torch
 
 GEGLU = 4
-ES = {0: 4, 1: 2, 2: 2}          # ST_F32, ST_BF16, ST_F16
+ES = {0: 4, 1: 2, 2: 2, 3: 4}    # ST_F32, ST_BF16, ST_F16, ST_F32S (split fp32: 4 bytes per value)
 
 
 def _linear(a):
