@@ -31,8 +31,8 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 / fp16 MFMA (guide: ~2.5 PF)
 PEAK_FP8_TFLOPS = 5000.0       # dense fp8 through the block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (guide: ~5 PF)
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
 BOUND = {"linear": "mfma", "linear_xattn": "mfma", "linear_fp8": "mfma", "quantize_fp8": "hbm", "conv2d": "mfma", "attention_self": "mfma", "attention_cross": "hbm",
-         "group_norm": "hbm", "layer_norm": "hbm", "geglu": "hbm"}
-KERNEL = {"linear_fp8": "gemm_dma_kernel<f8, CONV=false> (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 x e4m3)", "quantize_fp8": "quant_fp8_kernel",
+         "group_norm": "hbm", "layer_norm": "hbm", "geglu": "hbm", "split_f32": "hbm"}
+KERNEL = {"split_f32": "split_rows_kernel (strict mode: fp32 -> split fp16 pair image of a matrix operand)", "linear_fp8": "gemm_dma_kernel<f8, CONV=false> (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 x e4m3)", "quantize_fp8": "quant_fp8_kernel",
           "linear": "gemm_dma_kernel / gemm8p_kernel <bf16, CONV=false>",
           "linear_xattn": "gemm_dma_kernel<bf16, 128, 64, ..., XA=true> (query projection + text-context attention in its epilogue)", "conv2d": "conv_halo_kernel / gemm_dma_kernel<bf16, CONV=true>",
           "attention_self": "attn32i_kernel<7, true> / attn32i_kernel<4, true>", "attention_cross": "attn16v2_kernel<4, 1>",
@@ -53,6 +53,11 @@ def parse_args():
                                                              "timed mode is 'step', the other 16-bit type, strict fp32)")
     ap.add_argument("--fp8", action="store_true", help="transformer-block projections on the fp8 matrix pipe (BASELINE config #5 mode; "
                                                        "a separate line with dtype fp8, never the headline)")
+    ap.add_argument("--model", choices=["base", "refiner"], default="base",
+                    help="SDXL-base (the headline, BASELINE configs #2-#4) or the SDXL-refiner UNet (config #5; parity unpinned: the reference has no refiner)")
+    ap.add_argument("--img2img", type=float, default=None, metavar="STRENGTH",
+                    help="img2img start (the refiner's use): the trajectory starts at schedule entry n - int(n * STRENGTH) from init latent + noise; "
+                         "the timed steps are denoise steps from there (step graph, wrapping round the schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-census", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a same-device rehearsal)")
@@ -110,12 +115,17 @@ def self_launch(args, cmd=None) -> int:
     return 0
 
 
-def build_model(dev, dtype, rank, world):
+def model_spec(name):
+    from stabletriton_amd.unet import SDXL_BASE, SDXL_REFINER
+    return SDXL_REFINER if name == "refiner" else SDXL_BASE
+
+
+def build_model(dev, dtype, rank, world, spec):
     import torch
     from stabletriton_amd import parallel, synth
-    from stabletriton_amd.unet import SDXL_BASE, UNet2DConditionModel
+    from stabletriton_amd.unet import UNet2DConditionModel
     with torch.device("meta"):
-        model = UNet2DConditionModel(SDXL_BASE)
+        model = UNet2DConditionModel(spec)
     model = model.to_empty(device=dev).to(dtype).eval().requires_grad_(False)
     t0 = time.time()
     if rank == 0:
@@ -205,7 +215,7 @@ def committed_profile(name):
     return out, traffic, mfma_busy
 
 
-def roofline_of(name, f, boundary_ms):
+def roofline_of(name, f, boundary_ms, committed=True):
     """`boundary_ms`: what one launch costs in the replayed graph on top of its kernel-only time - the dependent-launch
     boundary in front of every kernel, which rocprofv3 attributes to the kernel (its trace shows back-to-back kernels with
     no gaps) and an event-bracketed launch does not see: (graph step time - census kernel-only time) / launches."""
@@ -216,7 +226,7 @@ def roofline_of(name, f, boundary_ms):
         ach, peak, unit = f["flops"] / sec / 1e12, (PEAK_FP8_TFLOPS if name == "linear_fp8" else PEAK_BF16_TFLOPS), "TFLOP/s"
     else:
         ach, peak, unit = f["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s"
-    prof, traffic, mfma_busy = committed_profile(name)
+    prof, traffic, mfma_busy = committed_profile(name) if committed else ({}, None, None)
     r = {"kernel": KERNEL[name], "op": name, "bound": BOUND[name], "achieved": round(ach, 2), "peak": peak, "unit": unit,
          "frac": round(ach / peak, 4), "traffic": traffic, "launches_per_step": f["launches"],
          "avg_launch_us": round(ms * 1e3 / f["launches"], 2), "ms_per_step": round(ms, 3),
@@ -247,48 +257,82 @@ def extras(args, model, gm, loop, mode, dtype, dev, n_sched, cond, x):
       loop_graph_it_per_s   - one replay of the 50-step loop hipGraph (north_star's form) when the timed run was step mode
                               (the driver's --steps 20 --warmup 5 is not a whole number of loops);
       other16_it_per_s      - the other 16-bit type (fp16 <-> bf16), same protocol;
-      strict_fp32_it_per_s  - the fp32 storage / exact-fp32-MFMA mode, the one that meets north_star's 1e-3 abs gate."""
+      strict_fp32_it_per_s  - the strict mode (fp32 storage, matrix operands as split fp16 pairs on the 16-bit MFMA, fp32
+                              accumulation / softmax / statistics): the one that meets north_star's 1e-3 abs gate; `strict` holds its
+                              step time and its own per-family roofline.
+    A leg that fails is recorded under `extras_error`; the headline line is printed regardless."""
     import torch
     from stabletriton_amd import synth
     from stabletriton_amd.optimization import optimize_model
     from stabletriton_amd.pipeline import DenoiseLoop
     from stabletriton_amd.scheduler import euler_discrete_tables
-    from stabletriton_amd.unet import SDXL_BASE, UNet2DConditionModel
+    from stabletriton_amd.unet import UNet2DConditionModel
+    spec = model_spec(args.model)
     out = {}
 
     def make(g, dt, md):
-        lp = DenoiseLoop(g, args.batch, args.latent, dt, dev, euler_discrete_tables(n_sched), mode=md)
+        lp = DenoiseLoop(g, args.batch, args.latent, dt, dev, euler_discrete_tables(n_sched), cross_dim=spec.cross_dim, pooled_dim=spec.pooled_dim,
+                         mode=md, n_time_ids=spec.n_time_ids)
         lp.set_conditioning(*(c.to(dt) for c in cond))
         lp.set_noise(x["latent"])
         return lp
 
-    with torch.no_grad():
-        if mode == "step" and not args.fp8:
-            lp = make(gm, dtype, "loop")
-            ms = _time_loop(lp, n_sched, n_sched, dev)
-            out["loop_graph_it_per_s"] = round(args.batch * 1e3 / ms, 3)
-            del lp
-        if not args.fp8:
-            other = torch.float16 if dtype == torch.bfloat16 else torch.bfloat16
-            with torch.device("meta"):
-                m2 = UNet2DConditionModel(SDXL_BASE)
-            m2 = m2.to_empty(device=dev).to(other).eval().requires_grad_(False)
-            m2.load_state_dict({k: v.to(other) for k, v in model.state_dict().items()})
-            lp = make(optimize_model(m2, cuda_graph=False), other, "step")
-            ms = _time_loop(lp, 20, 5, dev)
-            out["other16_it_per_s"] = {"dtype": "fp16" if other == torch.float16 else "bf16", "value": round(args.batch * 1e3 / ms, 3),
-                                       "finite": bool(torch.isfinite(lp.latent).all())}
-            del lp, m2
-            torch.cuda.empty_cache()
-            with torch.device("meta"):
-                m3 = UNet2DConditionModel(SDXL_BASE)
-            m3 = m3.to_empty(device=dev).float().eval().requires_grad_(False)
-            synth.fill_module_(m3, 0)
-            lp = make(optimize_model(m3, cuda_graph=False), torch.float32, "step")
-            ms = _time_loop(lp, 5, 2, dev)
-            out["strict_fp32_it_per_s"] = round(args.batch * 1e3 / ms, 3)
-            del lp, m3
-            torch.cuda.empty_cache()
+    def leg(name, fn):
+        """a side measurement must never cost the headline line: a failure (an OOM on a shared card, a broken side path) is recorded"""
+        try:
+            with torch.no_grad():
+                fn()
+        except Exception as e:          # noqa: BLE001
+            out.setdefault("extras_error", {})[name] = f"{type(e).__name__}: {e}"[:300]
+        torch.cuda.empty_cache()
+
+    def loop_graph():
+        lp = make(gm, dtype, "loop")
+        ms = _time_loop(lp, n_sched, n_sched, dev)
+        out["loop_graph_it_per_s"] = round(args.batch * 1e3 / ms, 3)
+
+    def other16():
+        other = torch.float16 if dtype == torch.bfloat16 else torch.bfloat16
+        with torch.device("meta"):
+            m2 = UNet2DConditionModel(spec)
+        m2 = m2.to_empty(device=dev).to(other).eval().requires_grad_(False)
+        m2.load_state_dict({k: v.to(other) for k, v in model.state_dict().items()})
+        lp = make(optimize_model(m2, cuda_graph=False), other, "step")
+        ms = _time_loop(lp, 20, 5, dev)
+        out["other16_it_per_s"] = {"dtype": "fp16" if other == torch.float16 else "bf16", "value": round(args.batch * 1e3 / ms, 3),
+                                   "finite": bool(torch.isfinite(lp.latent).all())}
+
+    def strict():
+        with torch.device("meta"):
+            m3 = UNet2DConditionModel(spec)
+        m3 = m3.to_empty(device=dev).float().eval().requires_grad_(False)
+        synth.fill_module_(m3, 0)
+        lp = make(optimize_model(m3, cuda_graph=False), torch.float32, "step")
+        ms = _time_loop(lp, 20, 5, dev)
+        out["strict_fp32_it_per_s"] = round(args.batch * 1e3 / ms, 3)
+        rec = {"ms_per_step": round(ms, 3), "finite": bool(torch.isfinite(lp.latent).all()),
+               "arithmetic": "fp32 storage; Linear / conv / attention operands as split fp16 pairs (x ~ hi + lo * 2^-11), three "
+                             "v_mfma_f32_16x16x32_f16 per product, fp32 accumulation, fp32 softmax and statistics"}
+        if not args.no_census:          # the strict step's own families against the 16-bit MFMA peak (algorithmic flops: the 3x of the split is overhead)
+            fam, census_ms, _, _ = census(lp)
+            n_launch = sum(f["launches"] for f in fam.values())
+            boundary = max(ms - census_ms, 0.0) / n_launch
+            roofs = {k: roofline_of(k, v, boundary, committed=False) for k, v in fam.items()}
+            names = {"linear": "gemm_dma_kernel<fsp, CONV=false> (split fp32 operands: 3 x v_mfma_f32_16x16x32_f16 per 32 k)",
+                     "conv2d": "gemm_dma_kernel<fsp, CONV=true> (implicit GEMM on split operands)",
+                     "attention_self": "attn_split_kernel<4>", "attention_cross": "attn_split_kernel<4>"}
+            for k, r in roofs.items():
+                r["kernel"] = names.get(k, r["kernel"])
+            rec["roofline"] = roofs[max(fam, key=lambda k: fam[k]["ms"])]
+            rec["kernels"] = [{k: r[k] for k in ("op", "bound", "achieved", "unit", "frac", "launches_per_step", "ms_per_step", "kernel_only_ms")}
+                              for r in sorted(roofs.values(), key=lambda r: -r["ms_per_step"])]
+        out["strict"] = rec
+
+    if mode == "step" and not args.fp8:
+        leg("loop_graph", loop_graph)
+    if not args.fp8 and dtype != torch.float32:
+        leg("other16", other16)
+        leg("strict", strict)
     return out
 
 
@@ -327,13 +371,13 @@ def host_cores():
     return max(1, use), f"{phys or '?'} physical / {logical} logical cores" + (f", cgroup quota {quota}" if quota else "")
 
 
-def cpu_baseline(model, latent_hw):
+def cpu_baseline(model, latent_hw, spec):
     """Oracle (CPU restatement of the reference eager path, fp32) on the host cores: 1 warm-up + 2 timed steps, median."""
     import torch
     from oracle import unet_oracle as orc          # checker/baseline only, never on the product path
     from stabletriton_amd import synth
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    x = synth.denoise_inputs(1, latent_hw, 1234)
+    x = synth.denoise_inputs(1, latent_hw, 1234, cross_dim=spec.cross_dim, pooled_dim=spec.pooled_dim, n_time_ids=spec.n_time_ids)
     cores, desc = host_cores()
     before = torch.get_num_threads()
     torch.set_num_threads(cores)
@@ -413,7 +457,8 @@ def main():
         raise SystemExit("--fp8 runs on a bf16 model")
     n_sched = 50
 
-    model, t_fill, t_bcast, n_bcast = build_model(dev, dtype, rank, world)
+    spec = model_spec(args.model)
+    model, t_fill, t_bcast, n_bcast = build_model(dev, dtype, rank, world, spec)
     ranks_seen = world
     if world > 1:
         ones = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
@@ -423,12 +468,21 @@ def main():
     gm = optimize_model(model, cuda_graph=False, fp8=args.fp8)
     mode = args.mode
     if mode == "auto":
-        mode = "loop" if (args.steps % n_sched == 0 and args.warmup % n_sched == 0) else "step"
-    loop = DenoiseLoop(gm, args.batch, args.latent, dtype, dev, euler_discrete_tables(n_sched), mode=mode)
-    x = synth.denoise_inputs(args.batch, args.latent, 1234 + rank, device=dev)
+        mode = "loop" if (args.steps % n_sched == 0 and args.warmup % n_sched == 0 and args.img2img is None) else "step"
+    if args.img2img is not None and mode == "loop":
+        raise SystemExit("--img2img starts mid-schedule: use --mode step (or auto)")
+    loop = DenoiseLoop(gm, args.batch, args.latent, dtype, dev, euler_discrete_tables(n_sched), cross_dim=spec.cross_dim,
+                       pooled_dim=spec.pooled_dim, mode=mode, n_time_ids=spec.n_time_ids)
+    x = synth.denoise_inputs(args.batch, args.latent, 1234 + rank, device=dev, cross_dim=spec.cross_dim, pooled_dim=spec.pooled_dim,
+                             n_time_ids=spec.n_time_ids)
     cond = (x["encoder_hidden_states"].to(dtype), x["text_embeds"].to(dtype), x["time_ids"].to(dtype))
     loop.set_conditioning(*cond)
-    loop.set_noise(x["latent"])
+    steps_per_image = n_sched
+    if args.img2img is None:
+        loop.set_noise(x["latent"])
+    else:
+        init = synth.normal("img2img.init", tuple(x["latent"].shape), 78 + rank, dev) * 0.8
+        steps_per_image = loop.set_image(init, x["latent"], args.img2img)
 
     with torch.no_grad():
         # per-prompt setup (text K/V projections + the 50-row time table), amortised over a trajectory: timed on its own
@@ -456,18 +510,21 @@ def main():
 
         ms_per_step = elapsed / args.steps * 1e3
         result = {
-            "metric": "denoise it/s, SDXL UNet 1024x1024 50-step, bs=1 per GPU",
+            "metric": "denoise it/s, SDXL UNet 1024x1024 50-step, bs=1 per GPU" if args.model == "base" and args.img2img is None else
+                      f"denoise it/s, SDXL-{args.model} UNet {args.latent * 8}x{args.latent * 8}" + (" img2img" if args.img2img is not None else "") + f", bs={args.batch} per GPU",
             "value": round(world * args.batch * args.steps / elapsed, 3),
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp8" if args.fp8 else args.dtype, "data": "synthetic",
-            "config": {"workload": f"SDXL-base UNet, latent {args.latent}x{args.latent} (1024x1024 px), bs={args.batch}/GPU, "
-                                   f"{n_sched}-step Euler-discrete loop, hipGraph mode={mode}, no CFG"
+            "config": {"workload": f"SDXL-{args.model} UNet, latent {args.latent}x{args.latent} ({args.latent * 8}x{args.latent * 8} px), bs={args.batch}/GPU, "
+                                   + (f"{n_sched}-step Euler-discrete loop" if args.img2img is None else
+                                      f"img2img strength {args.img2img} ({steps_per_image} of {n_sched} Euler-discrete steps per image)")
+                                   + f", hipGraph mode={mode}, no CFG"
                                    + (", transformer projections e4m3 x e4m3 (everything else bf16)" if args.fp8 else ""),
                        "parallelism": f"prompt-parallel x{world}", "weights": "synthetic seed 0",
                        "weight_broadcasts": n_bcast},
             "finite": finite, "capture_s": round(t_capture, 2), "weights_s": round(t_fill, 2),
-            "prompt_setup_ms": round(prompt_setup_ms, 2),
+            "prompt_setup_ms": round(prompt_setup_ms, 2), "steps_per_image": steps_per_image,
             "it_per_s_incl_prompt_setup": round(world * args.batch * n_sched / (n_sched * ms_per_step * 1e-3 + prompt_setup_ms * 1e-3), 3),
         }
         if world > 1:
@@ -492,9 +549,12 @@ def main():
                                     "launches_per_step": n_launch, "boundary_us_per_launch": round(boundary_ms * 1e3, 3),
                                     "torch_glue_ms": round(glue_ms, 3), "event_record_us": round(marker_ms * 1e3, 2)}
             if not args.no_extras:
-                result.update(extras(args, model, gm, loop, mode, dtype, dev, n_sched, cond, x))
+                try:
+                    result.update(extras(args, model, gm, loop, mode, dtype, dev, n_sched, cond, x))
+                except Exception as e:          # noqa: BLE001  (never lose the measured headline to a side measurement)
+                    result["extras_error"] = {"extras": f"{type(e).__name__}: {e}"[:300]}
             if not args.no_cpu_baseline:
-                result["cpu_baseline"] = cpu_baseline(model, args.latent)
+                result["cpu_baseline"] = cpu_baseline(model, args.latent, spec)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -244,8 +244,8 @@ int st_linear_fp8(const void* xq, const float* row_scale, const void* Wq, const 
  * st_linear_fp8x: y[M,N] = epilogue((xq Wq^T) * a_scale[m * a_scale_stride] * w_scale[n]) - a_scale_stride 0: one scale for the
  *   whole activation tensor (the scale[i] above), 1: per row (st_quantize_fp8's row_scale).  With ln_c / ln_d / ln_stats the
  *   LayerNorm in front of the projection is folded exactly as in st_ln_linear (xq is then the e4m3 copy of the UN-normalised
- *   input, c[n] = sum_k of the dequantised folded weights).  `y` may be NULL when only the e4m3 copy q8 of the output is
- *   wanted (the GEGLU projection feeding the feed-forward output projection).  row_stats as in st_linear. */
+ *   input, c[n] = sum_k of the dequantised folded weights).  `y` may be NULL, with ST_EPI_GEGLU only, when just the e4m3 copy q8 of the
+ *   output is wanted (the GEGLU projection feeding the feed-forward output projection).  row_stats as in st_linear. */
 int st_linear_emit8(const void* x, const void* W, const void* bias, const void* residual,
                     const void* rowbias, void* y, int M, int N, int K,
                     long lda, long ldc, long ldr, int rows_per_batch,

@@ -171,7 +171,8 @@ extern "C" int st_linear_fp8x(const void* xq, const float* a_scale, int a_scale_
     ST_REQUIRE(!(epilogue & ST_EPI_ROWBIAS), "linear_fp8x: the row-bias epilogue is not supported");
     ST_REQUIRE(((uintptr_t)xq | (uintptr_t)Wq | (uintptr_t)y | (uintptr_t)w_scale) % 16 == 0, "linear_fp8x: pointers must be 16-byte aligned");
     ST_REQUIRE(!ln_c || (ln_d && ln_stats && ln_chunks > 0 && !(epilogue & ~ST_EPI_GEGLU)), "linear_fp8x: folded LayerNorm takes c, d, the row statistics and only the GEGLU flag (bias lives in d)");
-    ST_REQUIRE(y || (epilogue & ST_EPI_GEGLU) || ln_c, "linear_fp8x: an output without y is the GEGLU / folded-LayerNorm form");
+    // (only the staged epilogue - every GEGLU tile takes it - honours a missing y; the fragment epilogue of the small tiles stores through it)
+    ST_REQUIRE(y || (epilogue & ST_EPI_GEGLU), "linear_fp8x: an output without y (only the e4m3 copy) is the GEGLU form");
     GemmArgs a = {};
     a.A = xq; a.W = Wq; a.bias = bias; a.residual = residual; a.C = y;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.epi = epilogue;

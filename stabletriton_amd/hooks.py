@@ -42,30 +42,37 @@ class _HoistedUNet(nn.Module):
         self.compute_dtype = compute_dtype
         self.cuda_graph = cuda_graph
         self._ctx: Dict[tuple, tuple] = {}        # ehs shape -> static context tensors (read by the captured graphs)
-        # the tensor the cached context was built from, HELD (not its address: the caching allocator hands the next
-        # prompt's tensor the address of a freed one, with _version 0 again) and the version it had then
-        self._ctx_src: Optional[torch.Tensor] = None
-        self._ctx_version = -1
-        self._ctx_copy: Optional[torch.Tensor] = None    # private copy of its contents, to recognise the same prompt in a new tensor
+        # per shape: the tensor the cached context was built from, HELD (not its address: the caching allocator hands the
+        # next prompt's tensor the address of a freed one, with _version 0 again), the version it had then, and a private
+        # copy of its contents, to recognise the same prompt in a new tensor object.  Per shape: a caller that alternates
+        # two context shapes (cond / uncond batches of different lengths) keeps both.
+        self._ctx_src: Dict[tuple, torch.Tensor] = {}
+        self._ctx_version: Dict[tuple, int] = {}
+        self._ctx_copy: Dict[tuple, torch.Tensor] = {}
         self._steps: Dict[tuple, object] = {}     # ehs shape -> (graphed) step function
+        self._new_prompt = False                  # set when a context was (re)projected: the fp8 plan measures its scales again
 
     def refresh_weights(self) -> int:
         """Re-derive fused / folded weight buffers after an in-place weight update (also done at every new prompt).
-        The hoisted text-context K/V were projected with the old weights: the next call recomputes them."""
-        self._ctx_src = None
+        The hoisted text-context K/V were projected with the old weights: the next call recomputes them (and, with the fp8
+        plan, measures the activation scales again)."""
+        self._ctx_src.clear()
+        self._ctx_copy.clear()
         return self.compiled.exec_context.refresh_derived(full=True)
 
     def _context_for(self, ehs: torch.Tensor) -> tuple:
         """Static K/V context buffers for this prompt.  Fast path: the very tensor object the cache was built from, at the
         version it had then.  A different object of the same shape (ComfyUI re-concatenates cond | uncond on every call) is
         compared BY CONTENT with the kept copy (one device compare + host sync, ~1 % of a step) and adopted when equal;
-        anything else re-projects the context (one pass of 140 small GEMMs)."""
+        anything else re-projects the context (one pass of 140 small GEMMs).  Under a stream capture of the caller's own
+        the compare (a host sync) is skipped and the call counts as a new prompt."""
         shape = tuple(ehs.shape)
-        if ehs is self._ctx_src and ehs._version == self._ctx_version and shape in self._ctx:
+        if ehs is self._ctx_src.get(shape) and ehs._version == self._ctx_version.get(shape) and shape in self._ctx:
             return self._ctx[shape]
-        fresh = self._ctx_src is not None and shape in self._ctx and self._ctx_copy is not None \
-            and self._ctx_copy.shape == ehs.shape and self._ctx_copy.dtype == ehs.dtype and self._ctx_copy.device == ehs.device
-        if not (fresh and torch.equal(ehs, self._ctx_copy)):
+        copy = self._ctx_copy.get(shape)
+        same = (copy is not None and shape in self._ctx and copy.dtype == ehs.dtype and copy.device == ehs.device
+                and not torch.cuda.is_current_stream_capturing() and torch.equal(ehs, copy))
+        if not same:
             self.compiled.exec_context.refresh_derived(full=True)
             with torch.no_grad():
                 new = self.compiled.precompute_context(ehs.to(self.compute_dtype))
@@ -75,8 +82,9 @@ class _HoistedUNet(nn.Module):
             else:
                 for dst, src in zip(old, new):
                     dst.copy_(src)
-            self._ctx_copy = ehs.detach().clone()
-        self._ctx_src, self._ctx_version = ehs, ehs._version      # held: its address cannot be recycled under the cache
+            self._ctx_copy[shape] = ehs.detach().clone()
+            self._new_prompt = True
+        self._ctx_src[shape], self._ctx_version[shape] = ehs, ehs._version      # held: its address cannot be recycled under the cache
         return self._ctx[shape]
 
     def _step_fn(self, shape: tuple):
@@ -101,8 +109,14 @@ class _HoistedUNet(nn.Module):
         timesteps = timesteps.to(device=dev, dtype=torch.float32)
         if timesteps.dim() > 1 or (timesteps.dim() == 1 and timesteps.numel() not in (1, sample.shape[0])):
             raise ValueError(f"timesteps of shape {tuple(timesteps.shape)} do not match batch {sample.shape[0]}")
+        x = sample.to(self.compute_dtype)
+        if self._new_prompt:
+            self._new_prompt = False
+            from .optimization import recalibrate_fp8
+            ctx = self._ctx[tuple(ehs.shape)]
+            recalibrate_fp8(self.compiled, lambda: self.compiled.forward_with_context(x, timesteps, ctx, cond))
         with torch.no_grad():
-            out = self._step_fn(tuple(ehs.shape))(sample.to(self.compute_dtype), timesteps, cond)
+            out = self._step_fn(tuple(ehs.shape))(x, timesteps, cond)
         return out.to(io_dtype)
 
 

@@ -177,6 +177,16 @@ class Fp8Scales:
             i = self.sites[key] = len(self.sites)
         return i
 
+    def reset(self) -> None:
+        """Forget what earlier evaluations measured: the scales go back to their initial value and the next evaluation
+        measures again (optimization.recalibrate_fp8).  Called where the activation ranges may have nothing in common with
+        the last ones seen: a new trajectory (the last step of one and the first of the next sit at opposite ends of the
+        sigma schedule), a new prompt, new weights.  In place: captured graphs keep the addresses."""
+        self.scale.fill_(1.0 / 16)
+        self.inv_scale.fill_(16.0)
+        self.amax.zero_()
+        self.calibrated = False
+
     def update(self) -> None:
         if self.sites:
             _C.check(_C.load().st_fp8_update_scales(self.scale.data_ptr(), self.inv_scale.data_ptr(), self.amax.data_ptr(),

@@ -124,6 +124,27 @@ def _run_step(gm: fx.GraphModule, core):
         return core()
 
 
+FP8_CALIBRATION_PASSES = 2      # measuring evaluations after a reset: the first runs under the initial scale (values beyond 28 clip,
+                                # so what it records downstream of a clipped tensor is too small), the second under scales from the first
+
+
+def recalibrate_fp8(gm, run_once) -> bool:
+    """Start the delayed scales of `gm`'s fp8 plan over and measure them on the evaluation `run_once()` performs (eagerly,
+    outside any capture; its result is discarded): after this the scales are a function of that evaluation's inputs alone,
+    so two identical trajectories give identical results whatever ran before.  Returns False when there is nothing to do."""
+    ectx = getattr(gm, "exec_context", None)
+    if ectx is None or not getattr(gm, "fp8_plan", False) or ectx.fp8 is None:
+        return False
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("fp8 plan: the scales cannot be re-measured inside a graph capture")
+    ectx.fp8.reset()
+    with torch.no_grad():
+        for _ in range(FP8_CALIBRATION_PASSES):
+            ectx.fp8.calibrated = False            # _run_step: one measuring pass, the scale update, one pass under the new scales
+            run_once()
+    return True
+
+
 def _install_context_split(gm: fx.GraphModule) -> bool:
     """Hoist the text-context projections (step-invariant) out of the per-step graph.
 

@@ -93,6 +93,7 @@ class DenoiseLoop:
         self.latent.copy_(latent_unit.to(self.device, torch.float32) * self.tables.init_noise_sigma)
         self.x_in.copy_(self.latent * float(self.tables.in_scale()[0]))
         self.step.zero_()
+        self._recalibrate(0)
 
     def set_image(self, init_latent: torch.Tensor, noise_unit: torch.Tensor, strength: float) -> int:
         """img2img start (the refiner's use, BASELINE config #5; restated diffusers img2img: `get_timesteps` +
@@ -109,7 +110,17 @@ class DenoiseLoop:
         self.latent.copy_(lat)
         self.x_in.copy_(self.latent * float(self.tables.in_scale()[t_start]))
         self.step.fill_(t_start)
+        self._recalibrate(t_start)
         return n - t_start
+
+    def _recalibrate(self, i: int) -> None:
+        """fp8 plan only: a trajectory starts from scales measured on its own first evaluation (not on the last step of
+        whatever ran before), so the same inputs always give the same outputs."""
+        if self.ctx is None and self._split:
+            return                                   # no prompt yet: the first evaluation after compile measures by itself
+        from .optimization import recalibrate_fp8
+        row = tuple(tbl[i] for tbl in self.time_tables) if (self._tsplit and self.time_tables is not None) else None
+        recalibrate_fp8(self.unet, lambda: self._unet(self.timesteps[i], row))
 
     # ---- one step ------------------------------------------------------------------------
     def _cond(self) -> Dict[str, torch.Tensor]:
@@ -162,6 +173,9 @@ class DenoiseLoop:
                 self._captured_steps = self.n_steps
         self.graph = g
         self.latent.copy_(keep[0]); self.x_in.copy_(keep[1]); self.step.copy_(keep[2])
+        # (fp8 plan: the warm-up evaluation above measured the scales its own way; start them over exactly as set_noise /
+        #  set_image do, so the first trajectory after a capture equals every later one)
+        self._recalibrate(int(keep[2].item()) % self.n_steps)
 
     def run_steps(self, k: int) -> None:
         """Advance exactly k denoise steps from the current state (asynchronous)."""

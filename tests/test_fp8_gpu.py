@@ -235,3 +235,29 @@ def test_fp8_feed_forward_pair_keeps_e4m3_between_the_two_gemms(gpu):
         s = st2.buf.double().sum(1)
         assert torch.allclose(s[:, 0], y.double().sum(1), rtol=1e-4, atol=1e-2)
         assert torch.equal(y8.q, (y.float() * float(ctx.fp8.inv_scale[y8.index])).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8))
+
+
+def test_fp8_trajectories_do_not_depend_on_what_ran_before(gpu):
+    """Delayed scales are state: without a reset the first step of a trajectory would quantise with the maxima of the previous
+    trajectory's LAST step (the other end of the sigma schedule).  DenoiseLoop.set_noise restarts them from measuring passes on
+    the trajectory's own first evaluation, so identical inputs give identical outputs whatever ran in between."""
+    from stabletriton_amd import synth
+    from stabletriton_amd.optimization import optimize_model
+    from stabletriton_amd.pipeline import DenoiseLoop
+    from stabletriton_amd.scheduler import euler_discrete_tables
+    from stabletriton_amd.unet import TINY, UNet2DConditionModel
+    m = UNet2DConditionModel(TINY).eval().requires_grad_(False).to(gpu, torch.bfloat16)
+    synth.fill_module_(m, 0)
+    gm = optimize_model(m, cuda_graph=False, fp8=True)
+    x = synth.denoise_inputs(1, 16, 1234, cross_dim=TINY.cross_dim, pooled_dim=TINY.pooled_dim)
+    xg = {k: v.to(gpu, torch.bfloat16) for k, v in x.items()}
+    loop = DenoiseLoop(gm, 1, 16, torch.bfloat16, gpu, euler_discrete_tables(8), cross_dim=TINY.cross_dim, pooled_dim=TINY.pooled_dim, mode="step")
+    loop.set_conditioning(xg["encoder_hidden_states"], xg["text_embeds"], xg["time_ids"])
+    with torch.no_grad():
+        first = loop.denoise(x["latent"])
+        again = loop.denoise(x["latent"])                        # straight after a whole trajectory (scales of its last step)
+        other = loop.denoise(x["latent"] * 3.0 + 1.0)            # a trajectory with other ranges in between
+        third = loop.denoise(x["latent"])
+    assert gm.exec_context.fp8 is not None and gm.exec_context.fp8.sites, "the tiny model has no fp8 sites: the test checks nothing"
+    assert torch.isfinite(first).all() and not torch.equal(first, other)
+    assert torch.equal(first, again) and torch.equal(first, third)

@@ -187,7 +187,7 @@ def test_context_cache_is_keyed_on_the_prompt_not_its_address(gpu):
     first = ehs_a.to(gpu)
     addr = first.data_ptr()
     out_a = unet(xg["latent"], t, encoder_hidden_states=first, added_cond_kwargs=cond)[0].clone()
-    unet._ctx_src = None                                   # what the pre-fix cache amounted to: nothing keeps `first` alive ...
+    unet._ctx_src.clear()                                  # what the pre-fix cache amounted to: nothing keeps `first` alive ...
     del first
     second = ehs_b.to(gpu)                                 # ... so the allocator recycles its block for the next prompt
     reused = second.data_ptr() == addr
@@ -197,11 +197,33 @@ def test_context_cache_is_keyed_on_the_prompt_not_its_address(gpu):
     print(f"second prompt at {'the same' if reused else 'another'} address: max abs err vs oracle {err:.2e}")
     assert err <= ABS_TOL_STRICT and not torch.equal(out_a, out_b)
     # the adapter now holds `second`: a third tensor cannot take its address while the cache points at it
-    assert unet._ctx_src is second
+    assert unet._ctx_src[tuple(second.shape)] is second
     # same contents in a NEW tensor object (ComfyUI's per-call torch.cat): recognised, nothing re-projected
     before = tuple(c.data_ptr() for c in unet._ctx[tuple(second.shape)])
     out_c = unet(xg["latent"], t, encoder_hidden_states=second.clone(), added_cond_kwargs=cond)[0]
     assert torch.equal(out_b, out_c) and before == tuple(c.data_ptr() for c in unet._ctx[tuple(second.shape)])
+
+
+def test_context_cache_keeps_one_entry_per_shape(gpu):
+    """A caller that alternates two context shapes (cond / uncond of different lengths) re-projects neither."""
+    m = _tiny(torch.float32, gpu)
+    unet = hooks.compile_unet_from_state_dict(m.state_dict(), TINY, torch.float32, gpu)
+    x = synth.denoise_inputs(1, 16, 1234, cross_dim=TINY.cross_dim, pooled_dim=TINY.pooled_dim)
+    xg = {k: v.to(gpu) for k, v in x.items()}
+    cond = {"text_embeds": xg["text_embeds"], "time_ids": xg["time_ids"]}
+    t = torch.tensor(300.0)
+    long_, short = xg["encoder_hidden_states"], xg["encoder_hidden_states"][:, :40].contiguous()
+    outs = {}
+    for name, e in (("long", long_), ("short", short)):
+        outs[name] = unet(xg["latent"], t, encoder_hidden_states=e, added_cond_kwargs=cond)[0].clone()
+    calls = []
+    inner = unet.compiled.precompute_context
+    unet.compiled.precompute_context = lambda e: (calls.append(tuple(e.shape)), inner(e))[1]
+    for _ in range(3):
+        for name, e in (("long", long_.clone()), ("short", short.clone())):        # new tensor objects, same contents
+            assert torch.equal(unet(xg["latent"], t, encoder_hidden_states=e, added_cond_kwargs=cond)[0], outs[name])
+    assert calls == [], calls
+    assert not torch.equal(outs["long"], outs["short"])
 
 
 # ------------------------------------------------------------------------------------------------ ComfyUI

@@ -104,7 +104,12 @@ def _linear_fp8x(a):
     return "linear_fp8", 2.0 * M * rows * K, float(M * K + rows * K + out_bytes), f"M={M} N={N} K={K} fp8x epi={epi}" + (" ln" if a[17] else "") + (" +e4m3 copy" if a[23] else "")
 
 
-DECODERS = {"st_linear": _linear, "st_linear_emit8": _linear_emit8, "st_linear_fp8x": _linear_fp8x, "st_ln_linear": _ln_linear, "st_ln_linear_xattn": _ln_linear_xattn, "st_attention": _attention,
+def _split_f32(a):
+    rows, K = a[2], a[3]
+    return "split_f32", 0.0, 8.0 * rows * K, f"rows={rows} K={K}"
+
+
+DECODERS = {"st_split_f32": _split_f32, "st_linear": _linear, "st_linear_emit8": _linear_emit8, "st_linear_fp8x": _linear_fp8x, "st_ln_linear": _ln_linear, "st_ln_linear_xattn": _ln_linear_xattn, "st_attention": _attention,
             "st_conv2d": _conv2d, "st_group_norm": _group_norm, "st_group_norm_from_stats": _group_norm_from_stats,
             "st_group_norm_from_stats_cat": _group_norm_from_stats_cat, "st_conv1x1_cat": _conv1x1_cat,
             "st_layer_norm": _layer_norm, "st_geglu": _geglu, "st_quantize_fp8": _quantize_fp8,
