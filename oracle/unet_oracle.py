@@ -24,6 +24,38 @@ import torch.nn.functional as F
 
 SD = Dict[str, torch.Tensor]
 
+# ---- storage emulation (tests only): what 16-bit STORAGE alone costs --------------------------------------------------
+# `with storage(torch.bfloat16):` rounds the result of every operator below (and, through `rounded_state_dict`, every weight)
+# to that type and back to fp32, the arithmetic inside an operator staying fp32: the deviation of such a run from the fp32
+# run is the error that 16-bit tensors at operator boundaries cause by themselves, whatever the kernels do.  The bf16 / fp16
+# gates of tests/test_unet_gpu.py are a small factor of THAT (oracle/make_rounded_golden.py records it), not of a measurement
+# of the kernels under test.  The compiled graph rounds in fewer places (LayerNorm, GEGLU and the residual adds live inside
+# GEMM epilogues), so the emulation is an upper-side estimate of the storage error, not a model of the kernels.
+_STORAGE = None
+
+
+class storage:
+    def __init__(self, dtype: Optional[torch.dtype]):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _STORAGE
+        self.prev, _STORAGE = _STORAGE, self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        global _STORAGE
+        _STORAGE = self.prev
+        return False
+
+
+def _r(x: torch.Tensor) -> torch.Tensor:
+    return x if _STORAGE is None else x.to(_STORAGE).float()
+
+
+def rounded_state_dict(sd: SD, dtype: torch.dtype) -> SD:
+    return {k: v.to(dtype).float() for k, v in sd.items()}
+
 
 def _has(sd: SD, key: str) -> bool:
     return key in sd
@@ -37,20 +69,20 @@ def _count(sd: SD, fmt: str) -> int:
 
 
 def linear(sd: SD, p: str, x):
-    return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
+    return _r(F.linear(x, sd[p + ".weight"], sd.get(p + ".bias")))
 
 
 def conv(sd: SD, p: str, x, stride=1, padding=1):
-    return F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride=stride, padding=padding)
+    return _r(F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride=stride, padding=padding))
 
 
 def group_norm(sd: SD, p: str, x, eps: float, groups: int = 32):
-    return F.group_norm(x, groups, sd[p + ".weight"], sd[p + ".bias"], eps)
+    return _r(F.group_norm(x, groups, sd[p + ".weight"], sd[p + ".bias"], eps))
 
 
 def layer_norm(sd: SD, p: str, x):
     w = sd[p + ".weight"]
-    return F.layer_norm(x, w.shape, w, sd[p + ".bias"], 1e-5)
+    return _r(F.layer_norm(x, w.shape, w, sd[p + ".bias"], 1e-5))
 
 
 def timestep_features(t: torch.Tensor, dim: int) -> torch.Tensor:
@@ -64,19 +96,19 @@ def timestep_features(t: torch.Tensor, dim: int) -> torch.Tensor:
 
 def timestep_mlp(sd: SD, p: str, x):
     """unet_pt.py:46-51."""
-    return linear(sd, p + ".linear_2", F.silu(linear(sd, p + ".linear_1", x)))
+    return linear(sd, p + ".linear_2", _r(F.silu(linear(sd, p + ".linear_1", x))))
 
 
 def resnet_block(sd: SD, p: str, x, temb, groups: int = 32):
     """unet_pt.py:74-95."""
-    h = F.silu(group_norm(sd, p + ".norm1", x, 1e-5, groups))
+    h = _r(F.silu(group_norm(sd, p + ".norm1", x, 1e-5, groups)))
     h = conv(sd, p + ".conv1", h)
-    h = h + linear(sd, p + ".time_emb_proj", F.silu(temb))[:, :, None, None]
-    h = F.silu(group_norm(sd, p + ".norm2", h, 1e-5, groups))
+    h = _r(h + linear(sd, p + ".time_emb_proj", _r(F.silu(temb)))[:, :, None, None])
+    h = _r(F.silu(group_norm(sd, p + ".norm2", h, 1e-5, groups)))
     h = conv(sd, p + ".conv2", h)
     if _has(sd, p + ".conv_shortcut.weight"):
         x = conv(sd, p + ".conv_shortcut", x, padding=0)
-    return x + h
+    return _r(x + h)
 
 
 def attention_core(q, k, v, heads: int):
@@ -88,7 +120,7 @@ def attention_core(q, k, v, heads: int):
     v = v.view(b, v.shape[1], heads, d).transpose(1, 2)
     s = torch.matmul(q, k.transpose(-2, -1)) * (d ** -0.5)
     o = torch.matmul(torch.softmax(s, dim=-1), v)
-    return o.transpose(1, 2).contiguous().view(b, t, c)
+    return _r(o.transpose(1, 2).contiguous().view(b, t, c))
 
 
 def attention(sd: SD, p: str, x, context=None, head_dim: int = 64):
@@ -104,15 +136,15 @@ def attention(sd: SD, p: str, x, context=None, head_dim: int = 64):
 def geglu(x_proj):
     """unet_pt.py:155-158: exact-erf GELU on the second half."""
     a, g = x_proj.chunk(2, dim=-1)
-    return a * F.gelu(g)
+    return _r(a * F.gelu(g))
 
 
 def transformer_layer(sd: SD, p: str, x, context, head_dim: int = 64):
     """unet_pt.py:189-210."""
-    x = attention(sd, p + ".attn1", layer_norm(sd, p + ".norm1", x), None, head_dim) + x
-    x = attention(sd, p + ".attn2", layer_norm(sd, p + ".norm2", x), context, head_dim) + x
+    x = _r(attention(sd, p + ".attn1", layer_norm(sd, p + ".norm1", x), None, head_dim) + x)
+    x = _r(attention(sd, p + ".attn2", layer_norm(sd, p + ".norm2", x), context, head_dim) + x)
     h = geglu(linear(sd, p + ".ff.net.0.proj", layer_norm(sd, p + ".norm3", x)))
-    return linear(sd, p + ".ff.net.2", h) + x
+    return _r(linear(sd, p + ".ff.net.2", h) + x)
 
 
 def spatial_transformer(sd: SD, p: str, x, context, groups: int = 32, head_dim: int = 64):
@@ -125,7 +157,7 @@ def spatial_transformer(sd: SD, p: str, x, context, groups: int = 32, head_dim: 
         y = transformer_layer(sd, f"{p}.transformer_blocks.{i}", y, context, head_dim)
     y = linear(sd, p + ".proj_out", y)
     y = y.reshape(b, h, w, c).permute(0, 3, 1, 2).contiguous()
-    return y + x
+    return _r(y + x)
 
 
 def unet_forward(sd: SD, sample, timestep, encoder_hidden_states, text_embeds, time_ids,
@@ -141,7 +173,7 @@ def unet_forward(sd: SD, sample, timestep, encoder_hidden_states, text_embeds, t
     emb = timestep_mlp(sd, "time_embedding", timestep_features(t, time_proj_dim).to(sample.dtype))
     tid = timestep_features(time_ids.flatten(), add_time_proj_dim).reshape(b, -1)
     add = torch.cat([text_embeds, tid], dim=-1).to(emb.dtype)
-    emb = emb + timestep_mlp(sd, "add_embedding", add)
+    emb = _r(emb + timestep_mlp(sd, "add_embedding", add))
 
     x = conv(sd, "conv_in", sample)
     skips: List[torch.Tensor] = [x]
@@ -172,7 +204,7 @@ def unet_forward(sd: SD, sample, timestep, encoder_hidden_states, text_embeds, t
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")     # unet_pt.py:264-266
             x = conv(sd, p + ".upsamplers.0.conv", x)
 
-    x = F.silu(group_norm(sd, "conv_norm_out", x, 1e-5, groups))       # unet_pt.py:538-540
+    x = _r(F.silu(group_norm(sd, "conv_norm_out", x, 1e-5, groups)))   # unet_pt.py:538-540
     return conv(sd, "conv_out", x)
 
 

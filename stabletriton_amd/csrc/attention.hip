@@ -14,7 +14,6 @@
 //     ds_read_b64_tr_b16 on the row-major V image; K and V images are XOR-swizzled per 16-byte chunk on the DMA source
 //     side so the fragment reads are conflict-free; keys beyond S are zero-filled and masked.
 // fp32 ("strict" parity mode): attention_f32.hip.
-#define ST_ATTENTION_TU 1
 #include "attention_core.h"
 
 template <typename E, int NW, int TAG>
@@ -44,7 +43,7 @@ template <typename E, int NW, bool LD>
 __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const E* __restrict__ Q, const E* __restrict__ K,
                                                       const E* __restrict__ V, E* __restrict__ O,
                                                       int T, int S, long ldq, long ldk, long ldv, long ldo, float scale_log2e,
-                                                      int H, unsigned long long* probe) {
+                                                      int H) {
     typedef typename V16<E>::x8 E8;
     typedef typename V16<E>::x4 E4;
     constexpr int TILE_B = ATT_KV * 128;
@@ -52,9 +51,6 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
     constexpr int RB = 6;                             // ring buffers
     constexpr int PIECES = 16 / NW;
     extern __shared__ __attribute__((aligned(16))) char lds[];      // the ring, then a 1-KiB dump for the dummy DMAs
-#ifdef ST_PROBE
-    unsigned long long pv = 0, pvw = 0, pm = 0, pmw = 0;
-#endif
 
     const int t_ = threadIdx.x, lane = t_ & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t_ >> 6);
@@ -261,7 +257,6 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
 
     int vslot = 0, kslot = 2;                         // ring slots of tile kt (V^T) and tile kt+2 (K)
     auto trip = [&](f32x16& s0, f32x16& s1, f32x16& n0, f32x16& n1, int kt) {
-        AP_STAMP(t1)
         const char* vb = lds + vslot * BUF_B + TILE_B;
         const char* kb = lds + kslot * BUF_B;
         float mch[4];                                  // four maximum chains over the next tile's scores
@@ -276,7 +271,6 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
             vf[g >> 1][g & 1] = v_frag<E>(vb, ((g & 1) ? v_base1 : v_base0) + (g >> 1) * 2048, ((g & 1) ? v_base1 : v_base0) + (g >> 1) * 2048 + 1024);
             __builtin_amdgcn_sched_barrier(0);
         }
-        AP_STAMP(tq)
         // ---- PV phase: gap p carries MFMA p; gaps 0-7 the other sixteen exponentials, gaps 2-11 the maximum of the next
         //      tile's scores, gaps 4-11 the K fragments of tile kt+2 ----
 #pragma unroll
@@ -323,7 +317,6 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
         float mx = att_max3(mch[0], mch[1], att_max3(mch[2], mch[3], mch[3]));
         vslot = vslot == RB - 1 ? 0 : vslot + 1;
         kslot = kslot == RB - 1 ? 0 : kslot + 1;
-        AP_STAMP(t2)
         if (kt + 1 < nkt) {
             if ((kt + 2) * ATT_KV > S) { mask_tail(n0, n1, kt + 1); mx = max32(n0, n1); }
             if (__any(mx > ATT_LAG)) {
@@ -339,24 +332,15 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        AP_STAMP(t3)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");   // own pieces of tile kt+3 have landed; tile kt+4's may fly
         dma_next();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        AP_STAMP(t4)
-        AP_ADD(pv, tq, t1) AP_ADD(pvw, t2, tq) AP_ADD(pm, t3, t2) AP_ADD(pmw, t4, t3)
     };
     for (int kt = 0; kt < nkt; kt += 2) {
         trip(sa0, sa1, sb0, sb1, kt);
         if (kt + 1 < nkt) trip(sb0, sb1, sa0, sa1, kt + 1);
     }
-#ifdef ST_PROBE
-    if (probe && lane == 0 && q0 == wave * 32 && head == 0 && b == 0) {
-        unsigned long long* o = probe + wave * 8;
-        o[0] = pv; o[1] = pvw; o[2] = pm; o[3] = pmw; o[4] = nkt; o[5] = 0; o[6] = 0; o[7] = 0;
-    }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -415,7 +399,7 @@ static int attention16_launch(const void* q, const void* k, const void* v, void*
     ensure_dynamic_lds(kfn, RING, &lds_ok[nw - 1]);
     ST_REQUIRE((long)cdiv(T, 32 * nw) * H * B < (1L << 31), "attention: too many blocks");
     hipLaunchKernelGGL(kfn, dim3(cdiv(T, 32 * nw) * H * B), dim3(threads), RING, st, (const E*)q, (const E*)k, (const E*)v,
-                       (E*)out, T, S, ldq, ldk, ldv, ldo, c, H, ATT_PROBE_ARG);
+                       (E*)out, T, S, ldq, ldk, ldv, ldo, c, H);
     return st_check_launch("attention");
 }
 

@@ -14,31 +14,6 @@ static inline int att_dev_env_int(const char* name, int dflt) {      // develope
 #endif
 }
 
-#ifdef ST_PROBE
-static unsigned long long* g_att_probe = nullptr;
-#ifdef ST_ATTENTION_TU
-extern "C" void st_debug_set_att_probe(void* p) { g_att_probe = (unsigned long long*)p; }
-#endif
-__device__ __forceinline__ unsigned long long att_now() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-#define AP_STAMP(v) unsigned long long v = att_now();
-#define AP_ADD(a, t1, t0) a += (t1) - (t0);
-#else
-#define AP_STAMP(v)
-#define AP_ADD(a, t1, t0)
-#endif
-
-#ifdef ST_PROBE
-#define ATT_PROBE_ARG g_att_probe
-#else
-#define ATT_PROBE_ARG nullptr
-#endif
-
 static constexpr int ATT_D = 64;
 static constexpr int ATT_KV = 64;          // keys per tile
 

@@ -1,0 +1,684 @@
+// GEMM-shaped operators: the epilogues (bias, SiLU, GEGLU, residual, row bias, folded LayerNorm, fp8 scales, e4m3 copy,
+// LayerNorm / GroupNorm partials) in their two forms - fragment layout (small dense tiles) and staged through LDS (wide tiles,
+// GEGLU, convs) - with one instance per feature set of the denoise step.  Internal to csrc/.
+#pragma once
+#include "gemm_args.h"
+
+// ---- shared epilogue ---------------------------------------------------------------------------
+// One output row m, 4 consecutive columns n..n+3: v = accumulators (value half), g = gate half (GEGLU).
+// epilogue_compute4 does every load and all the arithmetic and leaves the final values in v;
+// epilogue_put4 stores them.  The tile kernels run compute over ALL their tiles before the first
+// store: on gfx950 vmcnt counts stores too, so a load issued after a store waits for that store's
+// write acknowledgement (a microsecond under load) -- interleaved load/store tiles serialise on it.
+template <typename T, bool GEGLU>
+__device__ __forceinline__ void epilogue_compute4(const GemmArgs& p, int m, int n, float (&v)[4], const float (&g_in)[4],
+                                                  float ln_mean = 0.f, float ln_rstd = 0.f) {
+    const T* __restrict__ bias = (const T*)p.bias;
+    const T* __restrict__ Rp = (const T*)p.residual;
+    const T* __restrict__ RBp = (const T*)p.rowbias;
+    const bool full = (n + 3 < p.N);
+    float g[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = g_in[e];
+    if (p.col_scale) {                                 // fp8 operands: dequantisation scales
+        const float rs = p.row_scale[(size_t)m * p.rs_stride];
+        for (int e = 0; e < 4 && n + e < p.N; ++e) { v[e] *= rs * p.col_scale[n + e]; if (GEGLU) g[e] *= rs * p.col_scale[p.N + n + e]; }
+    }
+    if (p.ln_c) {                                      // folded LayerNorm: rank-1 correction per row / column
+        if (full) {
+            float c4[4], d4[4];
+            Out4<float>::load(p.ln_c + n, c4); Out4<float>::load(p.ln_d + n, d4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ln_fold(v[e], ln_mean, ln_rstd, c4[e], d4[e]);
+            if (GEGLU) {
+                Out4<float>::load(p.ln_c + p.N + n, c4); Out4<float>::load(p.ln_d + p.N + n, d4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = ln_fold(g[e], ln_mean, ln_rstd, c4[e], d4[e]);
+            }
+        } else {
+            for (int e = 0; e < 4 && n + e < p.N; ++e) {
+                v[e] = ln_fold(v[e], ln_mean, ln_rstd, p.ln_c[n + e], p.ln_d[n + e]);
+                if (GEGLU) g[e] = ln_fold(g[e], ln_mean, ln_rstd, p.ln_c[p.N + n + e], p.ln_d[p.N + n + e]);
+            }
+        }
+    }
+    if (p.epi & ST_EPI_BIAS) {
+        if (full) { float b4[4]; Out4<T>::load(bias + n, b4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += b4[e];
+        } else {
+            for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(bias[n + e]);
+        }
+    }
+    if (GEGLU) {
+        if (p.epi & ST_EPI_BIAS) {
+            if (full) { float b4[4]; Out4<T>::load(bias + p.N + n, b4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] += b4[e];
+            } else {
+                for (int e = 0; e < 4 && n + e < p.N; ++e) g[e] += Elem<T>::to_f(bias[p.N + n + e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_for<T>(g[e]);
+    }
+    if (p.epi & ST_EPI_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+    }
+    if (p.epi & ST_EPI_ROWBIAS) {
+        const T* rb = RBp + (size_t)(m / p.rows_per_batch) * p.N + n;
+        if (full) { float b4[4]; Out4<T>::load(rb, b4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += b4[e];
+        } else {
+            for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(rb[e]);
+        }
+    }
+    if (p.epi & ST_EPI_RESIDUAL) {
+        const T* rr = Rp + (size_t)m * p.ldr + n;
+        if (full) { float b4[4]; Out4<T>::load(rr, b4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += b4[e];
+        } else {
+            for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += Elem<T>::to_f(rr[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (n + e < p.N) ? Elem<T>::to_f(Elem<T>::from_f(v[e])) : 0.f;   // what will be stored
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue_put4(const GemmArgs& p, int m, int n, const float (&v)[4]) {
+    T* dst = (T*)p.C + (size_t)m * p.ldc + n;
+    if (n + 3 < p.N) Out4<T>::store(dst, v);
+    else for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = Elem<T>::from_f(v[e]);
+}
+
+template <typename T, bool GEGLU>
+__device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n, float (&v)[4], const float (&g_in)[4],
+                                                float ln_mean = 0.f, float ln_rstd = 0.f) {
+    epilogue_compute4<T, GEGLU>(p, m, n, v, g_in, ln_mean, ln_rstd);
+    epilogue_put4<T>(p, m, n, v);
+}
+
+// The feature set of an epilogue as bits (see staged_epilogue_impl): MODE >= 0 = exactly that set, tile inside the matrix.
+enum { EPI_F_BIAS = 1, EPI_F_RES = 2, EPI_F_RB = 4, EPI_F_LN = 8, EPI_F_SILU = 16, EPI_F_SCALE = 32, EPI_F_ROWS = 64, EPI_F_COLS = 128,
+       EPI_F_Q8 = 256, EPI_F_NOC = 512 };
+
+// lane (r16, q) holds rows m = .. + r16, columns n = .. + 4q .. 4q+3 of every 16x16 tile.
+template <typename T, int TM, int TN, int WTM, int WTN, bool GEGLU, int WGM_ = 0, int WGN_ = 0, bool ALIGNED_N = false, int MODE = -1>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                              int r16, int q, int split = 0, const float* row_mean = nullptr,
+                                              const float* row_rstd = nullptr, char* lds_scratch = nullptr, int tile_n = 0) {
+    constexpr bool FAST = MODE >= 0;
+    float rs1[TM], rs2[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { rs1[i] = 0.f; rs2[i] = 0.f; }
+    constexpr int TNO = GEGLU ? TN / 2 : TN;
+    constexpr int WTNO = GEGLU ? WTN / 2 : WTN;
+    const bool has_q8 = FAST ? bool(MODE & EPI_F_Q8) : (p.q8_out != nullptr);
+    const bool emit_rows = FAST ? bool(MODE & EPI_F_ROWS) : (p.row_stats != nullptr);
+    const bool emit_cols = FAST ? bool(MODE & EPI_F_COLS) : (p.col_stats != nullptr && (p.N & 3) == 0);
+    if (!FAST && !ALIGNED_N && (p.N & 3) != 0) {
+        // ragged N: per-tile loads, arithmetic and element stores
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + r16;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TNO; ++j) {
+                const int n = n0 + wn * WTNO + j * 16 + 4 * q;
+                if (n >= p.N) continue;
+                float v[4], g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = acc[i][j][e]; if (GEGLU) g[e] = acc[i][j + (GEGLU ? TN / 2 : 0)][e]; }
+                epilogue_store4<T, GEGLU>(p, m, n, v, g, row_mean ? row_mean[i] : 0.f, row_rstd ? row_rstd[i] : 0.f);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { rs1[i] += v[e]; rs2[i] = fmaf(v[e], v[e], rs2[i]); }
+            }
+        }
+    } else {
+        // Three passes: every load (unconditional, clamped addresses, so they all go out back to back
+        // and cost ONE round trip), then the arithmetic, then nothing but stores.  On gfx950 vmcnt
+        // counts stores too, so a load behind a store would also wait for that store's acknowledgement.
+        typedef typename Raw4<T>::type R4;
+        const bool has_bias = FAST ? bool(MODE & EPI_F_BIAS) : bool(p.epi & ST_EPI_BIAS), has_res = FAST ? bool(MODE & EPI_F_RES) : bool(p.epi & ST_EPI_RESIDUAL);
+        const bool has_rb = FAST ? bool(MODE & EPI_F_RB) : bool(p.epi & ST_EPI_ROWBIAS), has_ln = FAST ? bool(MODE & EPI_F_LN) : (p.ln_c != nullptr);
+        const bool do_silu = FAST ? bool(MODE & EPI_F_SILU) : bool(p.epi & ST_EPI_SILU), has_scale = FAST ? bool(MODE & EPI_F_SCALE) : (p.col_scale != nullptr);
+        int ncol[TNO], mrow[TM];
+        bool nok[TNO], mok[TM];
+#pragma unroll
+        for (int j = 0; j < TNO; ++j) { const int n = n0 + wn * WTNO + j * 16 + 4 * q; nok[j] = FAST || n < p.N; ncol[j] = nok[j] ? n : 0; }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { const int m = m0 + wm * WTM + i * 16 + r16; mok[i] = FAST || m < p.M; mrow[i] = mok[i] ? m : 0; }
+        const T* __restrict__ bias = (const T*)p.bias;
+        unsigned int touch_next = 0;                       // destination of the next-weights touches (kept live to the end)
+        // wide wave tiles take the load + arithmetic passes in column chunks of JC tiles (registers)
+        constexpr int JC = TM >= 8 ? 1 : (TNO <= 5 ? TNO : 5);      // (tall wave tiles: one column of tiles per pass)
+        auto chunk = [&](auto jc) {
+            constexpr int J0 = decltype(jc)::value;
+            constexpr int NJ = (J0 + JC <= TNO) ? JC : TNO - J0;
+            R4 braw[NJ] = {}, graw[NJ] = {};
+            f32x4 cv[NJ] = {}, dv[NJ] = {}, cg[NJ] = {}, dg[NJ] = {};
+            R4 rres[TM][NJ] = {}, rrb[TM][NJ] = {};
+            f32x4 csc[NJ] = {}, gsc[NJ] = {};
+            float rsc[TM] = {};
+            if (has_scale) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    csc[j] = *reinterpret_cast<const f32x4*>(p.col_scale + ncol[J0 + j]);
+                    if (GEGLU) gsc[j] = *reinterpret_cast<const f32x4*>(p.col_scale + p.N + ncol[J0 + j]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) rsc[i] = p.row_scale[(size_t)mrow[i] * p.rs_stride];
+            }
+            if (has_bias) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { braw[j] = ld_raw4<T>(bias + ncol[J0 + j]); if (GEGLU) graw[j] = ld_raw4<T>(bias + p.N + ncol[J0 + j]); }
+            }
+            if (has_ln) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int n = ncol[J0 + j];
+                    cv[j] = *reinterpret_cast<const f32x4*>(p.ln_c + n); dv[j] = *reinterpret_cast<const f32x4*>(p.ln_d + n);
+                    if (GEGLU) { cg[j] = *reinterpret_cast<const f32x4*>(p.ln_c + p.N + n); dg[j] = *reinterpret_cast<const f32x4*>(p.ln_d + p.N + n); }
+                }
+            }
+            if (has_rb) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) rrb[i][j] = ld_raw4<T>((const T*)p.rowbias + (size_t)(mrow[i] / p.rows_per_batch) * p.N + ncol[J0 + j]);
+            }
+            if (has_res) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) rres[i][j] = ld_raw4<T>((const T*)p.residual + (size_t)mrow[i] * p.ldr + ncol[J0 + j]);
+            }
+            if constexpr (J0 == 0) {
+                // the next launch's weights: issued AFTER this pass's loads (so the arithmetic below does not wait for
+                // them), in flight while the arithmetic and the stores run; the wave's exit waits for them
+                touch_next_weights(p, touch_next);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float mean = row_mean ? row_mean[i] : 0.f, rstd = row_rstd ? row_rstd[i] : 0.f;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    float v[4], g[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = acc[i][J0 + j][e]; g[e] = GEGLU ? acc[i][J0 + j + (GEGLU ? TN / 2 : 0)][e] : 0.f; }
+                    if (has_scale) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] *= rsc[i] * csc[j][e]; if (GEGLU) g[e] *= rsc[i] * gsc[j][e]; }
+                    }
+                    if (has_ln) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = ln_fold(v[e], mean, rstd, cv[j][e], dv[j][e]);
+                            if (GEGLU) g[e] = ln_fold(g[e], mean, rstd, cg[j][e], dg[j][e]);
+                        }
+                    }
+                    if (has_bias) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += Elem<T>::to_f(braw[j][e]); if (GEGLU) g[e] += Elem<T>::to_f(graw[j][e]); }
+                    }
+                    if (GEGLU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= gelu_for<T>(g[e]);
+                    }
+                    if (do_silu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                    }
+                    if (has_rb) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f(rrb[i][j][e]);
+                    }
+                    if (has_res) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += Elem<T>::to_f(rres[i][j][e]);
+                    }
+                    const bool live = mok[i] && nok[J0 + j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = live ? Elem<T>::to_f(Elem<T>::from_f(v[e])) : 0.f;      // what is stored
+                        rs1[i] += v[e]; rs2[i] = fmaf(v[e], v[e], rs2[i]); acc[i][J0 + j][e] = v[e];
+                    }
+                }
+            }
+        };
+        chunk(std::integral_constant<int, 0>{});
+        if constexpr (JC < TNO) chunk(std::integral_constant<int, JC>{});
+        if constexpr (2 * JC < TNO) chunk(std::integral_constant<int, 2 * JC>{});
+        if constexpr (3 * JC < TNO) chunk(std::integral_constant<int, 3 * JC>{});
+        static_assert(4 * JC >= TNO, "epilogue chunking covers at most four chunks");
+        const float q8_inv = has_q8 ? *p.q8_inv_scale : 0.f;
+        float q8_max = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TNO; ++j)
+                if (mok[i] && nok[j]) {
+                    const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    Out4<T>::store((T*)p.C + (size_t)mrow[i] * p.ldc + ncol[j], v);
+                    if (has_q8) {            // e4m3 copy of the stored values (4 bytes per lane)
+                        q8_max = fmaxf(fmaxf(q8_max, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                        *reinterpret_cast<unsigned int*>((unsigned char*)p.q8_out + (size_t)mrow[i] * p.q8_ld + ncol[j]) =
+                            pack4_fp8(clamp_fp8(v[0] * q8_inv), clamp_fp8(v[1] * q8_inv), clamp_fp8(v[2] * q8_inv), clamp_fp8(v[3] * q8_inv));
+                    }
+                }
+        if (has_q8) publish_amax(p.q8_amax, q8_max, blockIdx.x * 8 + (threadIdx.x >> 6));
+        retire_touches(touch_next);
+    }
+    if constexpr (WGN_ > 0) {
+        // LayerNorm partials of the rows this block just stored (consumed by the next st_ln_linear):
+        // lane sums -> the four q lanes -> the WGN waves of this tile row (through LDS) -> one float2
+        // per (row, N tile).  Fixed order throughout: bit-reproducible.
+        if (emit_rows) {
+            float2* sm = reinterpret_cast<float2*>(lds_scratch);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float a1 = rs1[i], a2 = rs2[i];
+                a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
+                a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+                if (q == 0) sm[(wm * WTM + i * 16 + r16) * WGN_ + wn] = make_float2(a1, a2);
+            }
+            __syncthreads();
+            for (int row = threadIdx.x; row < WGM_ * WTM; row += WGM_ * WGN_ * 64) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WGN_; ++w) { const float2 t = sm[row * WGN_ + w]; a1 += t.x; a2 += t.y; }
+                if (m0 + row < p.M)
+                    reinterpret_cast<float2*>(p.row_stats)[(size_t)(m0 + row) * p.stats_chunks + tile_n] = make_float2(a1, a2);
+            }
+        }
+        // GroupNorm partials: per output column of this tile, (sum, sum of squares) over the tile's rows of the values just
+        // stored (acc holds them, zero for rows / columns outside the problem).  In-lane over the row tiles, a fixed
+        // butterfly over the sixteen row lanes, then the WGM waves of the column through LDS: bit-reproducible.
+        if (emit_cols) {
+            constexpr int TNO_ = GEGLU ? TN / 2 : TN;
+            constexpr int WTNO_ = GEGLU ? WTN / 2 : WTN;
+            float2* cm = reinterpret_cast<float2*>(lds_scratch + WGM_ * WTM * WGN_ * 8);      // behind the row-statistics area
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TNO_; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) { const float v = acc[i][j][e]; c1 += v; c2 = fmaf(v, v, c2); }
+                    c1 = row16_sum(c1); c2 = row16_sum(c2);
+                    if (r16 == 0) cm[wm * (WGN_ * WTNO_) + wn * WTNO_ + j * 16 + 4 * q + e] = make_float2(c1, c2);
+                }
+            __syncthreads();
+            const int tile_m = m0 / (WGM_ * WTM);
+            for (int col = threadIdx.x; col < WGN_ * WTNO_; col += WGM_ * WGN_ * 64) {
+                float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WGM_; ++w) { const float2 t = cm[w * (WGN_ * WTNO_) + col]; c1 += t.x; c2 += t.y; }
+                if (n0 + col < p.N) reinterpret_cast<float2*>(p.col_stats)[(size_t)tile_m * p.N + n0 + col] = make_float2(c1, c2);
+            }
+        }
+    }
+}
+
+
+// =============================================================================
+// Staged epilogue (the LDS-DMA kernels, the 256 x 256 kernel, the halo conv).  After the K loop the LDS ring is free:
+// the block parks its fp32 accumulators there as a row-major tile, and every thread then owns ONE 16-byte output vector
+// (8 bf16 / f16 or 4 fp32 columns of one row) per pass:
+//   * stores, residual and row-bias loads are full 16-byte accesses, 128..512 contiguous bytes per row (the fragment
+//     layout gave 8 bytes per lane in 32-byte row segments);
+//   * per-column operands (bias, LayerNorm c / d, fp8 column scales) are loaded once per thread (its columns never change);
+//   * the loads of a chunk go out BEFORE the accumulators are parked, so their latency runs under the LDS staging;
+//   * a thread holds ~40 live registers instead of every epilogue operand of a whole wave tile (the 256-wide tiles and the
+//     halo conv spilled 38..116 VGPRs there);
+//   * GEGLU needs no value / gate pairing inside a wave any more: W rows are staged [values | gates] and the two halves of an
+//     accumulator row meet in LDS, so every tile shape can carry it.
+// Tiles that do not fit the ring at once go through it in row chunks (also bounding the loads in flight per thread).
+// Statistics for the consumers (LayerNorm row partials, GroupNorm column partials) are reduced through LDS in a fixed order:
+// bit-reproducible.  Arithmetic order per element is the one of epilogue_compute4.
+// =============================================================================
+template <typename TO> struct EpiVec;           // 16 bytes of outputs / residual / bias
+template <> struct EpiVec<bf16> { typedef bf16x8 type; static constexpr int N = 8; };
+template <> struct EpiVec<f16> { typedef f16x8 type; static constexpr int N = 8; };
+template <> struct EpiVec<float> { typedef f32x4 type; static constexpr int N = 4; };
+
+struct ColsPlain {              // accumulator n-tile j of wave column wn -> first tile column
+    int wn, wtn;
+    __device__ __forceinline__ int operator()(int j) const { return wn * wtn + j * 16; }
+};
+
+template <int BM, int BN, int NT, int VEC, bool GEGLU, int LDS_BYTES>
+struct EpiGeom {
+    static constexpr int BNO = GEGLU ? BN / 2 : BN;              // output columns of the tile
+    static_assert(BNO % VEC == 0, "tile width must be a whole number of 16-byte vectors");
+    static constexpr int VPR = BNO / VEC;                        // vectors (threads) per row
+    static constexpr int RPI = NT / VPR;                         // rows per pass of the block
+    static constexpr int LDW = BN + 4;                           // floats per staged row (+16 B: the 16 row lanes of a fragment hit different banks)
+    static constexpr int ROW_BYTES = LDW * 4 + VPR * 8;          // + one (sum, sum of squares) partial per vector (row statistics)
+    // passes per chunk (bounds the residual / row-bias vectors in flight; the 256 x 256 tile still holds up to 96 accumulator
+    // registers of later chunks while it works on one: two passes keep it from spilling)
+    static constexpr int MAX_IT = (BM * BN >= 256 * 256) ? 2 : 4;      // (four passes on the 256 x 256 tiles: no faster, and the GEGLU ones spill)
+    static constexpr int ch0 = (LDS_BYTES / ROW_BYTES) / 16 * 16;
+    static constexpr int ch1 = ch0 < MAX_IT * RPI ? ch0 : (MAX_IT * RPI) / 16 * 16;
+    static constexpr int ch2 = ch1 < BM ? ch1 : BM;
+    static constexpr int NCH = (BM + ch2 - 1) / ch2;
+    static constexpr int CH = ((BM + NCH - 1) / NCH + 15) / 16 * 16;      // rows per chunk (balanced, multiple of 16)
+    static constexpr int IT = (CH + RPI - 1) / RPI;
+    static_assert(ch2 >= 16 && CH * ROW_BYTES <= LDS_BYTES, "staged epilogue: the ring cannot hold sixteen rows of the tile");
+    static_assert(RPI * BNO * 8 <= LDS_BYTES, "staged epilogue: column-statistics scratch");
+};
+
+// What the epilogue of a launch has to do, as bits: MODE >= 0 instantiates staged_epilogue_impl for exactly that set with the
+// tile known to lie inside the matrix and every pointer / stride 16-byte aligned (no per-element tests, no wide / narrow
+// branches, no code for the absent features); MODE = -1 is the general instance that reads the set from the arguments.
+// Why: with run-time flags the bias-only epilogue of a 256 x 256 tile took 24,000 cycles, the bare accumulators -> LDS ->
+// 16-byte stores round trip 9,400 (tools/gemm_probe.py): twelve microseconds of a 48-us launch went into testing flags.
+
+template <typename TO, int BM, int BN, int WGM, int WGN, int TM, int TN, bool GEGLU, int LDS_BYTES, bool STATS, int MODE, typename ColMap>
+__device__ __forceinline__ void staged_epilogue_impl(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int tile_n, int wm, int r16, int q,
+                                                     ColMap colmap, char* lds, const float2* lnrows) {
+    constexpr bool FAST = MODE >= 0;
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int VEC = EpiVec<TO>::N;
+    typedef typename EpiVec<TO>::type OV;
+    typedef EpiGeom<BM, BN, NT, VEC, GEGLU, LDS_BYTES> G;
+    constexpr int BNO = G::BNO, VPR = G::VPR, RPI = G::RPI, LDW = G::LDW, CH = G::CH, NCH = G::NCH, IT = G::IT;
+    constexpr int WTM = BM / WGM;
+    const int t = threadIdx.x;
+    const bool worker = t < RPI * VPR;
+    const int rloc = t / VPR, v = t - rloc * VPR;
+    const int n = n0 + v * VEC;                                   // first output column of this thread
+    const bool has_bias = FAST ? bool(MODE & EPI_F_BIAS) : bool(p.epi & ST_EPI_BIAS), has_res = FAST ? bool(MODE & EPI_F_RES) : bool(p.epi & ST_EPI_RESIDUAL);
+    const bool has_rb = FAST ? bool(MODE & EPI_F_RB) : bool(p.epi & ST_EPI_ROWBIAS), has_ln = FAST ? bool(MODE & EPI_F_LN) : (p.ln_c != nullptr);
+    const bool do_silu = FAST ? bool(MODE & EPI_F_SILU) : bool(p.epi & ST_EPI_SILU), has_scale = FAST ? bool(MODE & EPI_F_SCALE) : (p.col_scale != nullptr);
+    const bool has_q8 = FAST ? bool(MODE & EPI_F_Q8) : (p.q8_out != nullptr), has_c = FAST ? !(MODE & EPI_F_NOC) : (p.C != nullptr);
+    const bool col_full = FAST || n + VEC <= p.N;                 // all VEC columns exist
+    const bool col_any = worker && (FAST || n < p.N);
+    const bool wide = col_full && (p.ldc % VEC == 0) && ((uintptr_t)p.C & 15) == 0;             // 16-byte stores
+    const bool wide_res = col_full && (p.ldr % VEC == 0) && ((uintptr_t)p.residual & 15) == 0;
+    const bool wide_rb = col_full && (p.N % VEC == 0) && ((uintptr_t)p.rowbias & 15) == 0;
+    float* tile = reinterpret_cast<float*>(lds);
+    float2* rstat = reinterpret_cast<float2*>(lds + (size_t)CH * LDW * 4);
+    const bool emit_rows = FAST ? bool(MODE & EPI_F_ROWS) : (STATS && p.row_stats != nullptr);
+    const bool emit_cols = FAST ? bool(MODE & EPI_F_COLS) : (STATS && p.col_stats != nullptr && (p.N & 3) == 0);
+
+    // ---- per-column operands: once per thread ------------------------------------------------------
+    // (kept as loaded - raw vectors - and converted where they are used: a conversion placed here would make the compiler
+    //  wait for the loads in front of the first barrier instead of letting them fly under the staging)
+    OV bia = OV{}, big = OV{};
+    float lc[VEC], ld[VEC], lcg[VEC], ldg[VEC], cs[VEC], csg[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { lc[e] = ld[e] = lcg[e] = ldg[e] = 0.f; cs[e] = csg[e] = 1.f; }
+    if (col_any) {
+        const TO* __restrict__ bias = (const TO*)p.bias;
+        // whole vectors whenever the columns exist and the arrays keep 16-byte alignment (N % VEC == 0 covers the gate half too)
+        const bool vec_cols = FAST || (col_full && (p.N % VEC == 0) && (!has_bias || ((uintptr_t)bias & 15) == 0) &&
+                                       (!has_ln || (((uintptr_t)p.ln_c | (uintptr_t)p.ln_d) & 15) == 0) && (!has_scale || ((uintptr_t)p.col_scale & 15) == 0));
+        auto ldf = [&](const float* a, float (&dst)[VEC]) {       // VEC floats
+#pragma unroll
+            for (int e4 = 0; e4 < VEC; e4 += 4) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(a + e4);
+                dst[e4] = x[0]; dst[e4 + 1] = x[1]; dst[e4 + 2] = x[2]; dst[e4 + 3] = x[3];
+            }
+        };
+        if (vec_cols) {
+            if (has_bias) {
+                bia = *reinterpret_cast<const OV*>(bias + n);
+                if (GEGLU) big = *reinterpret_cast<const OV*>(bias + p.N + n);
+            }
+            if (has_ln) { ldf(p.ln_c + n, lc); ldf(p.ln_d + n, ld); if (GEGLU) { ldf(p.ln_c + p.N + n, lcg); ldf(p.ln_d + p.N + n, ldg); } }
+            if (has_scale) { ldf(p.col_scale + n, cs); if (GEGLU) ldf(p.col_scale + p.N + n, csg); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int ne = (n + e < p.N) ? n + e : p.N - 1;       // clamped: every load unconditional
+                if (has_bias) { bia[e] = bias[ne]; if (GEGLU) big[e] = bias[p.N + ne]; }
+                if (has_ln) { lc[e] = p.ln_c[ne]; ld[e] = p.ln_d[ne]; if (GEGLU) { lcg[e] = p.ln_c[p.N + ne]; ldg[e] = p.ln_d[p.N + ne]; } }
+                if (has_scale) { cs[e] = p.col_scale[ne]; if (GEGLU) csg[e] = p.col_scale[p.N + ne]; }
+            }
+        }
+    }
+    const float q8_inv = has_q8 ? *p.q8_inv_scale : 0.f;           // e4m3 copy for an fp8 consumer (see GemmArgs::q8_out)
+    float q8_max = 0.f;
+    float c1[VEC], c2[VEC];                                       // GroupNorm partials of this thread's columns over its rows
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { c1[e] = 0.f; c2[e] = 0.f; }
+    unsigned int touch_next = 0;
+
+    // (this barrier costs 0.6 % of a batch-1 step - measured by leaving it out - and stays: nothing else orders the other
+    //  waves' last fragment reads and tail DMAs against the tile that is about to overwrite the ring)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the last fragment reads of the K loop have returned ...
+    __builtin_amdgcn_s_barrier();                                 // ... in every wave: the ring may be overwritten
+    // (unrolled over the chunks: static parking conditions; a rolled general instance measured 20 % slower and spilled)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int row_lo = c * CH;                                // first tile row of this chunk
+        // -- loads of the chunk (16 bytes per row each), in flight while the accumulators are parked
+        OV res[IT], rbv[IT];
+        bool rok[IT];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int row = row_lo + rloc + k * RPI;
+            const int m = m0 + row;
+            rok[k] = (rloc + k * RPI < CH) && row < BM && (FAST ? worker : (col_any && m < p.M));
+            const int mc = rok[k] ? m : m0;                       // clamped
+            res[k] = OV{}; rbv[k] = OV{};
+            if (has_res) {
+                const TO* rr = (const TO*)p.residual + (size_t)mc * p.ldr + (col_any ? n : n0);
+                if (FAST || wide_res) res[k] = *reinterpret_cast<const OV*>(rr);
+                else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) res[k][e] = rr[(n + e < p.N) ? e : 0];
+                }
+            }
+            if (has_rb) {
+                const TO* rb = (const TO*)p.rowbias + (size_t)(mc / p.rows_per_batch) * p.N + (col_any ? n : n0);
+                if (FAST || wide_rb) rbv[k] = *reinterpret_cast<const OV*>(rb);
+                else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) rbv[k][e] = rb[(n + e < p.N) ? e : 0];
+                }
+            }
+        }
+        if (c == 0) touch_next_weights(p, touch_next);            // the next launch's weights: fire and forget until the exit
+        // -- park this chunk's accumulators (wave-uniform test: a 16-row accumulator tile lies in exactly one chunk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm * WTM + i * 16;
+            if (row >= row_lo && row < row_lo + CH) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    *reinterpret_cast<f32x4*>(tile + (size_t)(row - row_lo + r16) * LDW + colmap(j) + 4 * q) = acc[i][j];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // -- one 16-byte output vector per thread and pass
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int rl = rloc + k * RPI;                        // row inside the chunk
+            float val[VEC];
+            if (rok[k]) {
+                const int row = row_lo + rl, m = m0 + row;
+                const float* src = tile + (size_t)rl * LDW + v * VEC;
+                float g[VEC];
+#pragma unroll
+                for (int e4 = 0; e4 < VEC; e4 += 4) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(src + e4);
+                    val[e4] = a[0]; val[e4 + 1] = a[1]; val[e4 + 2] = a[2]; val[e4 + 3] = a[3];
+                    if (GEGLU) {
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(src + BNO + e4);
+                        g[e4] = b[0]; g[e4 + 1] = b[1]; g[e4 + 2] = b[2]; g[e4 + 3] = b[3];
+                    }
+                }
+                if (has_scale) {
+                    const float rs = p.row_scale[(size_t)m * p.rs_stride];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { val[e] *= rs * cs[e]; if (GEGLU) g[e] *= rs * csg[e]; }
+                }
+                if (has_ln) {
+                    const float2 st = lnrows[row];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        val[e] = ln_fold(val[e], st.x, st.y, lc[e], ld[e]);
+                        if (GEGLU) g[e] = ln_fold(g[e], st.x, st.y, lcg[e], ldg[e]);
+                    }
+                }
+                if (has_bias) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { val[e] += Elem<TO>::to_f(bia[e]); if (GEGLU) g[e] += Elem<TO>::to_f(big[e]); }
+                }
+                if (GEGLU) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) val[e] *= gelu_for<TO>(g[e]);
+                }
+                if (do_silu) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) val[e] = silu_f(val[e]);
+                }
+                if (has_rb) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) val[e] += Elem<TO>::to_f(rbv[k][e]);
+                }
+                if (has_res) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) val[e] += Elem<TO>::to_f(res[k][e]);
+                }
+                OV out;
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) out[e] = Elem<TO>::from_f(val[e]);
+                if (emit_rows || emit_cols) {                     // (block-uniform: five VALU instructions per element that most launches skip)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float w = (FAST || n + e < p.N) ? Elem<TO>::to_f(out[e]) : 0.f;      // what is stored
+                        s1 += w; s2 = fmaf(w, w, s2);
+                        c1[e] += w; c2[e] = fmaf(w, w, c2[e]);
+                    }
+                }
+                if (has_c) {
+                    TO* dst = (TO*)p.C + (size_t)m * p.ldc + n;
+                    if (FAST || wide) *reinterpret_cast<OV*>(dst) = out;
+                    else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) if (n + e < p.N) dst[e] = out[e];
+                    }
+                }
+                if constexpr (VEC == 8) {
+                    if (has_q8 && col_full) {
+                        float a = 0.f;
+                        unsigned int w2[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const float x0 = Elem<TO>::to_f(out[4 * h]), x1 = Elem<TO>::to_f(out[4 * h + 1]), x2 = Elem<TO>::to_f(out[4 * h + 2]),
+                                        x3 = Elem<TO>::to_f(out[4 * h + 3]);
+                            a = fmaxf(fmaxf(a, fmaxf(fabsf(x0), fabsf(x1))), fmaxf(fabsf(x2), fabsf(x3)));
+                            w2[h] = pack4_fp8(clamp_fp8(x0 * q8_inv), clamp_fp8(x1 * q8_inv), clamp_fp8(x2 * q8_inv), clamp_fp8(x3 * q8_inv));
+                        }
+                        q8_max = fmaxf(q8_max, a);
+                        *reinterpret_cast<u32x2*>((unsigned char*)p.q8_out + (size_t)m * p.q8_ld + n) = u32x2{w2[0], w2[1]};
+                    }
+                }
+                if (emit_rows) rstat[rl * VPR + v] = make_float2(s1, s2);
+            } else if (emit_rows && worker && rl < CH) {
+                rstat[rl * VPR + v] = make_float2(0.f, 0.f);
+            }
+        }
+        if (emit_rows) {
+            // LayerNorm partials of the rows just stored: one float2 per (row, N tile), the row's vectors added in order
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (int rl = t; rl < CH; rl += NT) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < VPR; ++w) { const float2 x = rstat[rl * VPR + w]; a1 += x.x; a2 += x.y; }
+                const int row = row_lo + rl;
+                if (row < BM && m0 + row < p.M)
+                    reinterpret_cast<float2*>(p.row_stats)[(size_t)(m0 + row) * p.stats_chunks + tile_n] = make_float2(a1, a2);
+            }
+        }
+        if (c + 1 < NCH || emit_cols) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this chunk's LDS reads are done before the next one is parked
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (emit_cols) {
+        // GroupNorm partials: per output column (sum, sum of squares) over the tile's rows - the RPI row slots through LDS,
+        // added in slot order
+        float2* cstat = reinterpret_cast<float2*>(lds);
+        if (worker) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) cstat[rloc * BNO + v * VEC + e] = make_float2(c1[e], c2[e]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int tile_m = m0 / BM;
+        for (int col = t; col < BNO; col += NT) {
+            float a1 = 0.f, a2 = 0.f;
+            for (int w = 0; w < RPI; ++w) { const float2 x = cstat[w * BNO + col]; a1 += x.x; a2 += x.y; }
+            if (n0 + col < p.N) reinterpret_cast<float2*>(p.col_stats)[(size_t)tile_m * p.N + n0 + col] = make_float2(a1, a2);
+        }
+    }
+    if (has_q8) publish_amax(p.q8_amax, q8_max, blockIdx.x * (NT / 64) + (threadIdx.x >> 6));
+    retire_touches(touch_next);
+}
+
+// The dispatcher: the feature set of the launch (block-uniform), and whether this tile qualifies for a specialised instance.
+// Listed are the sets the big launches of the denoise step use; anything else (and every ragged or unaligned tile) takes the
+// general instance.  SCALED: e4m3 operands (row / column scales in the epilogue).
+template <typename TO, int BM, int BN, int WGM, int WGN, int TM, int TN, bool GEGLU, int LDS_BYTES, bool STATS, bool SCALED = false, typename ColMap>
+__device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int tile_n, int wm, int r16, int q,
+                                                ColMap colmap, char* lds, const float2* lnrows) {
+    constexpr int VEC = EpiVec<TO>::N;
+    constexpr int BNO = GEGLU ? BN / 2 : BN;
+    const bool has_res = p.epi & ST_EPI_RESIDUAL, has_rb = p.epi & ST_EPI_ROWBIAS;
+    const bool aligned = (m0 + BM <= p.M) && (n0 + BNO <= p.N) && (p.N % VEC == 0) &&
+                         (p.C == nullptr || ((p.ldc % VEC == 0) && ((uintptr_t)p.C & 15) == 0)) &&
+                         (!has_res || ((p.ldr % VEC == 0) && ((uintptr_t)p.residual & 15) == 0)) && (!has_rb || ((uintptr_t)p.rowbias & 15) == 0) &&
+                         ((((uintptr_t)p.bias | (uintptr_t)p.ln_c | (uintptr_t)p.ln_d | (uintptr_t)p.col_scale) & 15) == 0) &&
+                         (p.q8_out == nullptr || VEC == 8);
+    if (aligned) {
+        const int flags = ((p.epi & ST_EPI_BIAS) ? EPI_F_BIAS : 0) | (has_res ? EPI_F_RES : 0) | (has_rb ? EPI_F_RB : 0) | (p.ln_c ? EPI_F_LN : 0) |
+                          ((p.epi & ST_EPI_SILU) ? EPI_F_SILU : 0) | (p.col_scale ? EPI_F_SCALE : 0) | ((STATS && p.row_stats) ? EPI_F_ROWS : 0) |
+                          ((STATS && p.col_stats && (p.N & 3) == 0) ? EPI_F_COLS : 0) | (p.q8_out ? EPI_F_Q8 : 0) | (p.C ? 0 : EPI_F_NOC);
+#define ST_EPI_CASE(M)                                                                                                                          \
+    case (M):                                                                                                                                   \
+        staged_epilogue_impl<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, LDS_BYTES, STATS, (M)>(p, acc, m0, n0, tile_n, wm, r16, q, colmap, lds, lnrows); \
+        return;
+        // (a folded LayerNorm carries the projection's bias in its d vector: no BIAS bit)
+        if constexpr (!STATS && !SCALED) {
+            switch (flags) { ST_EPI_CASE(EPI_F_LN) ST_EPI_CASE(EPI_F_LN | EPI_F_BIAS) default: break; }
+        } else if constexpr (!STATS && SCALED) {
+            switch (flags) {
+                ST_EPI_CASE(EPI_F_LN | EPI_F_SCALE)
+                ST_EPI_CASE(EPI_F_LN | EPI_F_SCALE | EPI_F_Q8 | EPI_F_NOC)
+                default: break;
+            }
+        } else if constexpr (STATS && !SCALED) {
+            switch (flags) {
+                ST_EPI_CASE(EPI_F_BIAS)
+                ST_EPI_CASE(EPI_F_BIAS | EPI_F_RES)
+                ST_EPI_CASE(EPI_F_BIAS | EPI_F_ROWS)
+                ST_EPI_CASE(EPI_F_BIAS | EPI_F_RES | EPI_F_ROWS)
+                ST_EPI_CASE(EPI_F_BIAS | EPI_F_RES | EPI_F_ROWS | EPI_F_Q8)
+                ST_EPI_CASE(EPI_F_BIAS | EPI_F_COLS)
+                ST_EPI_CASE(EPI_F_BIAS | EPI_F_RB | EPI_F_COLS)
+                ST_EPI_CASE(EPI_F_BIAS | EPI_F_RES | EPI_F_COLS)
+                default: break;
+            }
+        } else {
+            switch (flags) {
+                ST_EPI_CASE(EPI_F_BIAS | EPI_F_SCALE | EPI_F_RES | EPI_F_ROWS)
+                ST_EPI_CASE(EPI_F_BIAS | EPI_F_SCALE | EPI_F_RES | EPI_F_ROWS | EPI_F_Q8)
+                default: break;
+            }
+        }
+#undef ST_EPI_CASE
+    }
+    staged_epilogue_impl<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, LDS_BYTES, STATS, -1>(p, acc, m0, n0, tile_n, wm, r16, q, colmap, lds, lnrows);
+}

@@ -1,0 +1,300 @@
+// GEMM-shaped operators: the eight-phase 256-row kernel (large Linear problems; 16-bit and e4m3 operands) and its launchers.
+// Internal to csrc/.
+#pragma once
+#include "gemm_dma.h"
+
+// =============================================================================
+// gemm8p: 256-row tiles for the large Linear problems (the projections at batch >= 2, the GEGLU projection at any
+// batch).  A 128 x 128 tile needs (128+128)*128 B of LDS fill per 0.21 us of MFMA work - more than the ~130 GB/s one
+// CU pulls from its L2 - a 256-row tile about half of that.  Two shapes of the same kernel:
+//     256 x 256: 8 waves = 2 (rows) x 4 (columns), wave tile 128 x 64;
+//     256 x 160: 8 waves = 4 x 2, wave tile 64 x 80 - SDXL's widths are 5 * 2^k: 1024 x 10240 (the GEGLU projection at
+//                batch 1) is 160 tiles of 256 x 256 but 256 of 256 x 160, one per CU.
+//   * A K tile is four phases, one quadrant of the wave tile each: (A0,B0) (A0,B1) (A1,B1) (A1,B0), Ah = the two halves of
+//     the wave's rows, B0 / B1 = its first ceil(TN/2) / last floor(TN/2) accumulator columns.  A phase reads only the
+//     fragments it is the first to use (A0+B0, B1, A1, nothing).
+//   * The two halves of the block's waves run half a phase apart (waves 4-7 pass one extra barrier first): while one
+//     half multiplies, the other reads fragments and issues DMAs, on the same SIMDs - a software ping-pong with two raw
+//     barriers per phase and no wave ever doing both at once.
+//   * LDS: two K tiles, each as four regions (A0, A1, B0, B1: the rows all eight waves read in the same phase), filled by
+//     LDS-DMA one region per phase (two 1-KiB pieces per wave; a region with fewer than sixteen pieces fills up with dummy
+//     pieces so that every wave counts the same vmcnt), swizzled on the source side as in gemm_dma_kernel.  A region is
+//     refilled two phases after its last read and waited for (counted vmcnt, never 0) one phase before its first read,
+//     which leaves four regions in flight at all times.
+// Staged epilogue (GEGLU: tile columns [values | gates]), LayerNorm folding, statistics, next-weights touches and the
+// XCD-aware tile order are the ones of gemm_dma_kernel.  No K split.
+// =============================================================================
+template <typename T, bool GEGLU, bool LNF, int BN = 256, int WGM = 2, int WGN = 4>
+__global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
+    static_assert(sizeof(T) <= 2, "16-bit elements (bf16 / f16) or e4m3 bytes");
+    constexpr int BM = 256, NW = 8;
+    constexpr int KB = 128 / (int)sizeof(T);           // elements per 128-byte row of a K tile: 64, or 128 e4m3
+    constexpr int EV = 16 / (int)sizeof(T);            // elements per 16-byte chunk
+    typedef typename OutT<T>::type TO;                // element type of C, bias, residual (e4m3 operands: bf16)
+    static_assert(WGM * WGN == NW && BM % (32 * WGM) == 0 && BN % (16 * WGN) == 0 && (!GEGLU || BN % 32 == 0), "wave layout");
+    constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 16, TN = WTN / 16;
+    constexpr int TMH = TM / 2, TN0 = (TN + 1) / 2, TN1 = TN - TN0;          // accumulator tiles per A half / in B0 / in B1
+    constexpr int RA = WGM * TMH * 16, RB0 = WGN * TN0 * 16, RB1 = WGN * TN1 * 16;      // rows of the regions
+    static_assert(RA == 128 && RB0 <= 128 && RB1 <= 128 && RB0 % 8 == 0 && RB1 % 8 == 0, "a region is at most sixteen 8-row pieces");
+    constexpr int HA = RA * 128, HB0 = RB0 * 128, HB1 = RB1 * 128;            // bytes
+    constexpr int TILE_B = 2 * HA + HB0 + HB1;                                // A0 A1 B0 B1
+    constexpr int BNO = GEGLU ? BN / 2 : BN;
+    typedef typename Mma<T>::Frag Frag;
+    // what one ds_read_b128 delivers: a whole MFMA operand of 32 k (16-bit), or half of the 128-k operand of the e4m3 instruction
+    typedef typename std::conditional<sizeof(T) == 1, u32x4, Frag>::type Half;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* const lnrows = lds + 2 * TILE_B;            // LayerNorm (mean, rstd) per row
+    char* const dump = lnrows + BM * 8;               // target of the dummy DMAs
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    const int tiles_m = p.M / BM;
+    const int nblk = gridDim.x - p.helper_blocks, bid = blockIdx.x;
+    if (bid >= nblk) {                               // helper block on an otherwise idle CU: the next launch's weights
+        unsigned int sink = 0;
+        touch_next_weights(p, sink, true);
+        retire_touches(sink);
+        return;
+    }
+    const TileId tid = tile_of_block(p, bid, nblk);
+    const int tile_m = tid.tile_m, tile_n = tid.tile_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BNO;
+    const T* __restrict__ Ap = (const T*)p.A;
+    const T* __restrict__ Wp = (const T*)p.W;
+    const T* zeros = reinterpret_cast<const T*>(g_zero16);
+
+    // ---- per-lane DMA sources: piece e (0, 1) of this wave inside a region covers region rows idx = (2*wave+e)*8 + lr.
+    //      A region row idx = wave row (idx / (TMH*16)), row inside that wave's half (idx % (TMH*16)); B likewise with the
+    //      wave column.  Tile column c -> row of W: c (plain), or value row c / gate row N + c - BN/2 (GEGLU).
+    const int lr = lane >> 3;
+    const int lc = (lane & 7) ^ lr;                  // logical 16-byte chunk this lane fetches (source-side swizzle)
+    const T* a_src[2];
+    const T* b0_src[2];
+    const T* b1_src[2];
+    auto w_row = [&](int c) { return GEGLU ? (c < BN / 2 ? (size_t)(n0 + c) : (size_t)p.N + n0 + (c - BN / 2)) : (size_t)(n0 + c); };
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int idx = (2 * wave + e) * 8 + lr;
+        a_src[e] = Ap + (size_t)(m0 + (idx / (TMH * 16)) * WTM + (idx % (TMH * 16))) * p.lda + lc * EV;      // half h adds TMH*16 rows
+        const int i0 = idx < RB0 ? idx : 0, i1 = idx < RB1 ? idx : 0;
+        b0_src[e] = Wp + w_row((i0 / (TN0 * 16)) * WTN + (i0 % (TN0 * 16))) * p.K + lc * EV;
+        b1_src[e] = Wp + w_row((i1 / (TN1 * 16)) * WTN + TN0 * 16 + (i1 % (TN1 * 16))) * p.K + lc * EV;
+    }
+    const size_t a_half = (size_t)(TMH * 16) * p.lda;
+    const int nk = p.K / KB;
+
+    // region r of a K tile: 0 = A0, 1 = A1, 2 = B0, 3 = B1.  Always two DMAs per wave: pieces beyond the region's rows and
+    // `kt >= nk` are dummies (a zero line into the dump area).
+    auto issue_half = [&](int kt, int region) {
+        const int roff = region == 0 ? 0 : region == 1 ? HA : region == 2 ? 2 * HA : 2 * HA + HB0;
+        const int rrows = region < 2 ? RA : region == 2 ? RB0 : RB1;
+        const unsigned dst = lds_addr_of(lds) + (kt & 1) * TILE_B + roff + (2 * wave) * 1024;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool live = kt < nk && (2 * wave + e) * 8 < rrows;
+            const T* src = region < 2 ? a_src[e] + (region & 1) * a_half : region == 2 ? b0_src[e] : b1_src[e];
+            src = live ? src + (size_t)kt * KB : zeros;
+            dma16_at<0>(src, live ? dst + e * 1024 : lds_addr_of(lds) + 2 * TILE_B + BM * 8);        // (= dump)
+        }
+    };
+
+    // touch the epilogue's operands now (they are first read after the K loop, where a miss would be exposed)
+    unsigned int touch_sink = 0;
+    {
+        auto touch_at = [&](const char* a) {
+            a = (const char*)((uintptr_t)a & ~(uintptr_t)3);
+            asm volatile("global_load_dword %0, %1, off" : "+v"(touch_sink) : "v"(a) : "memory");
+        };
+        auto touch = [&](const void* base, long byte_off, int nbytes) {
+            for (int o = t * 128; o < nbytes; o += 512 * 128) touch_at((const char*)base + byte_off + o);
+        };
+        if (p.epi & ST_EPI_BIAS) {
+            touch(p.bias, (long)n0 * 2, BNO * 2);
+            if (GEGLU) touch(p.bias, ((long)p.N + n0) * 2, BNO * 2);
+        }
+        if (LNF) {
+            touch(p.ln_c, (long)n0 * 4, BNO * 4); touch(p.ln_d, (long)n0 * 4, BNO * 4);
+            if (GEGLU) { touch(p.ln_c, ((long)p.N + n0) * 4, BNO * 4); touch(p.ln_d, ((long)p.N + n0) * 4, BNO * 4); }
+        }
+        if (p.epi & ST_EPI_RESIDUAL) {
+            constexpr int lines = (BNO * 2 + 127) / 128;
+            for (int o = t; o < BM * lines; o += 512) {
+                const int r = o / lines, l = o - r * lines;
+                touch_at((const char*)p.residual + ((size_t)(m0 + r) * p.ldr + n0) * 2 + l * 128);
+            }
+        }
+    }
+    // LayerNorm-folded GEMM: row statistics from the producer's partials (two threads per row)
+    LnRowSum<2> ln_sum;
+    if constexpr (LNF) {
+        const float2* st2 = reinterpret_cast<const float2*>(p.ln_stats);
+        const int row = t >> 1, part = t & 1;
+        ln_sum.load(st2 + (size_t)(m0 + row) * p.ln_chunks, p.ln_chunks, part);
+    }
+    // prologue: K tile 0 whole and A0, B0 of K tile 1 (the loop issues B1(1), A1(1), A0(2), B0(2), B1(2), ...)
+    issue_half(0, 0); issue_half(0, 2); issue_half(0, 3); issue_half(0, 1); issue_half(1, 0); issue_half(1, 2);
+    if constexpr (LNF) {
+        const float2* st2 = reinterpret_cast<const float2*>(p.ln_stats);
+        const int row = t >> 1, part = t & 1;
+        float a1, a2;
+        ln_sum.finish(st2 + (size_t)(m0 + row) * p.ln_chunks, p.ln_chunks, part, a1, a2);
+        const float mean = a1 / (float)p.K;
+        const float rstd = rsqrtf(fmaxf(a2 / (float)p.K - mean * mean, 0.f) + p.ln_eps);
+        if (part == 0) reinterpret_cast<float2*>(lnrows)[row] = make_float2(mean, rstd);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    wait_vmcnt<8>();                                 // A0(0), B0(0) have landed (and every load older than the DMAs)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::"v"(touch_sink));
+    if (wave >= 4) __builtin_amdgcn_s_barrier();     // the second half of the waves runs one barrier (half a phase) behind the first
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int r16 = lane & 15, q = lane >> 4;
+    // fragment addresses: region row = w * (tiles * 16) + frag * 16 + r16, chunk 4*kk + q, swizzled by row & 7 = r16 & 7
+    int a_off[2], b0_off[2], b1_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int sw = ((4 * kk + q) ^ (r16 & 7)) << 4;
+        a_off[kk] = (wm * TMH * 16 + r16) * 128 + sw;
+        b0_off[kk] = 2 * HA + (wn * TN0 * 16 + r16) * 128 + sw;
+        b1_off[kk] = 2 * HA + HB0 + (wn * TN1 * 16 + r16) * 128 + sw;
+    }
+    // A half in use, B0 (kept for the fourth phase), B1.  16-bit: [..][kk] = the operand of k step kk; e4m3: [..][0] is the whole
+    // 128-k operand, assembled from the two 16-byte reads (chunks q and q + 4) where they land
+    constexpr int NKK = sizeof(T) == 1 ? 1 : 2;
+    Frag fa[TMH][NKK], fb0[TN0][NKK], fb1[TN1][NKK];
+    auto read_op = [&](const char* base, const int (&off)[2], Frag (&dst)[NKK]) {
+        if constexpr (sizeof(T) == 1) {
+            const Half lo = *reinterpret_cast<const Half*>(base + off[0]), hi = *reinterpret_cast<const Half*>(base + off[1]);
+            dst[0] = Frag{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) dst[kk] = *reinterpret_cast<const Frag*>(base + off[kk]);
+        }
+    };
+    auto read_a = [&](const char* tile, int h) {
+#pragma unroll
+        for (int i = 0; i < TMH; ++i) read_op(tile + h * HA + i * 2048, a_off, fa[i]);
+    };
+    auto read_b0 = [&](const char* tile) {
+#pragma unroll
+        for (int j = 0; j < TN0; ++j) read_op(tile + j * 2048, b0_off, fb0[j]);
+    };
+    auto read_b1 = [&](const char* tile) {
+#pragma unroll
+        for (int j = 0; j < TN1; ++j) read_op(tile + j * 2048, b1_off, fb1[j]);
+    };
+    auto quadrant = [&](auto mh_, auto nh_) {
+        constexpr int mh = decltype(mh_)::value, nh = decltype(nh_)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+            for (int i = 0; i < TMH; ++i) {
+                if constexpr (nh == 0) {
+#pragma unroll
+                    for (int j = 0; j < TN0; ++j) Mma<T>::run(acc[mh * TMH + i][j], fb0[j][kk], fa[i][kk]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TN1; ++j) Mma<T>::run(acc[mh * TMH + i][TN0 + j], fb1[j][kk], fa[i][kk]);
+                }
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // one phase: [fragment reads] [one region of DMA] [counted wait] barrier [MFMAs of one quadrant] barrier
+    // after the issue of phase ph the eight DMAs of phases ph-3 .. ph may stay in flight: the region issued in
+    // phase ph-4 has landed for this wave, and for everybody once both halves of the waves have passed their next barrier
+#define ST_PHASE_SYNC()                                   \
+    __builtin_amdgcn_sched_barrier(0);                    \
+    wait_vmcnt<8>();                                      \
+    __builtin_amdgcn_s_barrier();                         \
+    __builtin_amdgcn_sched_barrier(0)
+#define ST_PHASE_END()                                    \
+    __builtin_amdgcn_sched_barrier(0);                    \
+    __builtin_amdgcn_s_barrier();                         \
+    __builtin_amdgcn_sched_barrier(0)
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* tile = lds + (kt & 1) * TILE_B;
+        // phase 0: (A0, B0); refill B1 of tile kt+1 (last read in phase 1 of tile kt-1)
+        read_a(tile, 0); read_b0(tile);
+        issue_half(kt + 1, 3);
+        ST_PHASE_SYNC();
+        quadrant(I0{}, I0{});
+        ST_PHASE_END();
+        // phase 1: (A0, B1); refill A1 of tile kt+1 (last read in phase 2 of tile kt-1)
+        read_b1(tile);
+        issue_half(kt + 1, 1);
+        ST_PHASE_SYNC();
+        quadrant(I0{}, I1{});
+        ST_PHASE_END();
+        // phase 2: (A1, B1); refill A0 of tile kt+2 (last read in phase 0 of this tile)
+        read_a(tile, 1);
+        issue_half(kt + 2, 0);
+        ST_PHASE_SYNC();
+        quadrant(I1{}, I1{});
+        ST_PHASE_END();
+        // phase 3: (A1, B0) from registers; refill B0 of tile kt+2 (last read in phase 0 of this tile)
+        issue_half(kt + 2, 2);
+        ST_PHASE_SYNC();
+        quadrant(I1{}, I0{});
+        ST_PHASE_END();
+    }
+#undef ST_PHASE_SYNC
+#undef ST_PHASE_END
+    if (wave < 4) __builtin_amdgcn_s_barrier();      // barrier counts of the two halves are equal again
+    wait_vmcnt<0>();                                  // no LDS-DMA may outlive the workgroup's LDS allocation
+    __builtin_amdgcn_s_barrier();
+    staged_epilogue<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, 2 * TILE_B, !LNF, sizeof(T) == 1>(p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds,
+                                                                        reinterpret_cast<const float2*>(lnrows));
+}
+
+// the two shapes of gemm8p: 256 (2 x 4 waves) and 160 columns (4 x 2 waves)
+static inline bool gemm8p_applies(const GemmArgs& a, int bn, int kb = 64) {
+    const long n_rows = (a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N;
+    return a.M % 256 == 0 && n_rows % bn == 0 && a.K % kb == 0 && a.K >= 2 * kb && a.N % 8 == 0 &&
+           !(a.epi & ST_EPI_ROWBIAS) && (!a.row_stats || !(a.epi & ST_EPI_GEGLU));
+}
+
+template <typename T, bool GEGLU, bool LNF, int BN, int WGM, int WGN>
+static void gemm8p_go(const GemmArgs& a, hipStream_t st) {
+    constexpr size_t lds = 2 * (size_t)(2 * 128 * 128 + BN * 128) + 256 * 8 + 1024;
+    auto kfn = gemm8p_kernel<T, GEGLU, LNF, BN, WGM, WGN>;
+    static unsigned long long lds_ok = 0;
+    ensure_dynamic_lds(kfn, lds, &lds_ok);
+    GemmArgs b = a;
+    const int tiles_m = a.M / 256, tiles_n = (int)(((a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N) / BN);
+    {   // XCD partition of the tile order: bytes from beyond L2 ~ A * (8 / panels) + W * panels
+        const double abytes = (double)a.M * a.K, wbytes = (double)tiles_n * BN * a.K;
+        int best_p = 1;
+        double best = 1e300;
+        for (int pm = 1; pm <= 8 && pm <= tiles_m; pm *= 2) {
+            const double c = abytes * (8.0 / pm) + wbytes * pm;
+            if (c < best) { best = c; best_p = pm; }
+        }
+        b.panel_h = cdiv(tiles_m, best_p);
+    }
+    const int main_blocks = tiles_m * tiles_n;
+    b.splitk = 1;
+    fill_tile_map(b, tiles_m, tiles_n, 0);
+    b.helper_blocks = (b.next_w && main_blocks <= 208) ? (256 - main_blocks > 96 ? 96 : 256 - main_blocks) : 0;
+    b.stats_chunks = tiles_n;
+    if (a.stats_chunks_out) *a.stats_chunks_out = a.row_stats ? b.stats_chunks : 0;
+    if (!colstats_ok(a, 256, LNF)) b.col_stats = nullptr;
+    fill_next_per(b, main_blocks + b.helper_blocks);
+    hipLaunchKernelGGL(kfn, dim3(main_blocks + b.helper_blocks), dim3(512), lds, st, b);
+}
+
+template <typename T, int BN, int WGM, int WGN>
+static void gemm8p_launch(const GemmArgs& a, hipStream_t st) {
+    const bool geglu = a.epi & ST_EPI_GEGLU;
+    if (a.ln_c) { if (geglu) gemm8p_go<T, true, true, BN, WGM, WGN>(a, st); else gemm8p_go<T, false, true, BN, WGM, WGN>(a, st); }
+    else { if (geglu) gemm8p_go<T, true, false, BN, WGM, WGN>(a, st); else gemm8p_go<T, false, false, BN, WGM, WGN>(a, st); }
+}

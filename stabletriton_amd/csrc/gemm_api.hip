@@ -7,10 +7,6 @@
 int g_dbg_cfg = -1, g_dbg_fusek = -1;
 extern "C" void st_debug_force_gemm(int cfg, int fusek) { g_dbg_cfg = cfg; g_dbg_fusek = fusek; }
 #endif
-#ifdef ST_PROBE
-static unsigned long long* g_probe = nullptr;
-extern "C" void st_debug_set_probe(void* p) { g_probe = (unsigned long long*)p; }
-#endif
 
 static int run_dense(const GemmArgs& a, int dtype, hipStream_t st) {
     switch (dtype) {
@@ -50,9 +46,6 @@ static int linear_impl(const void* x, const void* W, const void* bias, const voi
     ST_REQUIRE(!row_stats || !(epilogue & ST_EPI_GEGLU), "linear: row_stats with GEGLU is not supported");
     a.row_stats = row_stats; a.stats_capacity = row_stats_capacity; a.stats_chunks_out = row_stats_chunks;
     a.col_stats = col_stats; a.col_tiles_cap = col_stats_tiles; a.col_rows_out = col_stats_rows;
-#ifdef ST_PROBE
-    a.probe = g_probe;
-#endif
     take_hint(a, next_weights, next_weights_bytes);
     if (int e = check_epilogue("linear", a)) return e;
     if (q8) {

@@ -111,7 +111,9 @@ def test_diffusers_callsite_sdxl_fp16_pipeline(gpu, sdxl_bf16):
     print(f"F3-cfg fp16 pipeline / bf16 kernels: final latent rms err {rms:.2e} = {100 * rms / ref_rms:.2f} % of rms {ref_rms:.2f}, "
           f"max abs {float((out - ref).abs().max()):.2e}")
     assert torch.isfinite(out).all()
-    assert rms <= 0.045 * ref_rms          # measured 2.9 % (fp16 latent state, guidance x9): 1.5x headroom
+    # bound: twice what the storage alone costs in this protocol (oracle/make_rounded_golden.py f3_cfg: the oracle with an fp16
+    # latent state, fp16 tensors at the UNet boundary and every UNet tensor rounded to bf16; guidance multiplies it by 9)
+    assert rms <= 2.0 * float(golden("f3_cfg50_latent64_rounded")["bf16_rms"])
 
 
 def test_diffusers_callsite_sdxl_fp16_module(gpu, sdxl_fp16_pair):
@@ -130,7 +132,7 @@ def test_diffusers_callsite_sdxl_fp16_module(gpu, sdxl_fp16_pair):
     print(f"F3-cfg fp16 pipeline / fp16 kernels: final latent rms err {rms:.2e} = {100 * rms / ref_rms:.2f} % of rms {ref_rms:.2f}, "
           f"max abs {float((out - ref).abs().max()):.2e}")
     assert torch.isfinite(out).all()
-    assert rms <= 0.25 * 0.045 * ref_rms
+    assert rms <= 2.0 * float(golden("f3_cfg50_latent64_rounded")["fp16_rms"])       # (the same with fp16 UNet storage)
 
 
 def test_diffusers_hook_rejects_unsupported(gpu):

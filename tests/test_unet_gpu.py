@@ -21,7 +21,18 @@ from tests.util import golden, rel_err
 
 pytestmark = pytest.mark.gpu
 ABS_TOL_STRICT = 1e-3          # north_star: 1e-3 abs on the final latent
-BF16_F3_MAX_ABS = {64: 0.51, 128: 0.49}    # bf16 50-step final latent, worst element of |latent| <= 56: 1.5 x the measured 0.341 / 0.324
+# bf16 / fp16 runs are bounded by what 16-bit STORAGE costs by itself: oracle/make_rounded_golden.py ran the (reference-pinned)
+# oracle on the same inputs with every weight and every operator result rounded to the type and fp32 arithmetic inside the
+# operators, and recorded its deviation from the reference's fp32 output (tests/golden/*_rounded.npz: F1 bf16 max abs 6.2e-2 /
+# rms 1.8e-2, fp16 8.3e-3 / 2.2e-3; F3 latent 64 bf16 0.36 / 8.8e-2).  The HIP path's own deviation may be at most
+# STORAGE_FACTOR times that: two realisations of the same rounding noise differ, a kernel that adds error of its own shows.
+STORAGE_FACTOR = 2.0
+
+
+def storage_bound(name, dt):
+    """(max abs, rms) deviation from the reference that `dt` storage alone causes on fixture `name`, times STORAGE_FACTOR"""
+    g = golden(name + "_rounded")
+    return STORAGE_FACTOR * float(g[dt + "_max_abs"]), STORAGE_FACTOR * float(g[dt + "_rms"])
 F2_STRIDE = 31                 # oracle/make_golden.py subsample rule
 
 
@@ -196,8 +207,8 @@ def test_sdxl_f1_step_bf16(gpu, sdxl_bf16):
     err = float((out - ref).abs().max())
     print(f"F1 bf16: max abs err {err:.2e}, rms err {float((out - ref).pow(2).mean().sqrt()):.2e} "
           f"(|ref| max {float(ref.abs().max()):.2f}, rms {float(ref.pow(2).mean().sqrt()):.2f})")
-    # bf16 storage: ~2 decimal digits through ~600 dependent ops; bounds = 1.5x the measured 6.5e-2 / 1.8e-2
-    assert err <= 0.1 and float((out - ref).pow(2).mean().sqrt()) <= 0.027
+    mx, rms_b = storage_bound("f1_unet_step_latent64", "bf16")
+    assert err <= mx and float((out - ref).pow(2).mean().sqrt()) <= rms_b
 
 
 def test_sdxl_f1_step_fp16(gpu, sdxl_fp16):
@@ -208,7 +219,8 @@ def test_sdxl_f1_step_fp16(gpu, sdxl_fp16):
     err, rms = float((out - ref).abs().max()), float((out - ref).pow(2).mean().sqrt())
     print(f"F1 fp16: max abs err {err:.2e}, rms err {rms:.2e} (|ref| max {float(ref.abs().max()):.2f}, rms {float(ref.pow(2).mean().sqrt()):.2f})")
     assert torch.isfinite(out).all()
-    assert err <= 0.025 and rms <= 0.00675
+    mx, rms_b = storage_bound("f1_unet_step_latent64", "fp16")
+    assert err <= mx and rms <= rms_b
 
 
 def _sdxl_loop(gm, dtype, dev, hw, mode="loop"):
@@ -239,8 +251,8 @@ def test_sdxl_f3_euler50_bf16(gpu, sdxl_bf16, hw):
     print(f"F3 latent{hw} bf16: final latent max abs err {err:.2e}, rms {rms:.2e} "
           f"(|ref| max {float(ref.abs().max()):.2f}, rms {float(ref.pow(2).mean().sqrt()):.2f})")
     assert torch.isfinite(out).all()
-    assert rms <= 0.0075 * float(ref.pow(2).mean().sqrt())    # bf16 mode: reported; bound = 1.5x the measured 0.5 % of the latent rms
-    assert err <= BF16_F3_MAX_ABS[hw]                          # and the worst element (|latent| max ~50): 1.5x the measured value
+    mx, rms_b = storage_bound(f"f3_euler50_latent{hw}", "bf16")
+    assert rms <= rms_b and err <= mx
 
 
 @pytest.mark.parametrize("hw", [64, 128])
@@ -252,8 +264,8 @@ def test_sdxl_f3_euler50_fp16(gpu, sdxl_fp16, hw):
     print(f"F3 latent{hw} fp16: final latent max abs err {err:.2e}, rms {rms:.2e} "
           f"(|ref| max {float(ref.abs().max()):.2f}, rms {float(ref.pow(2).mean().sqrt()):.2f})")
     assert torch.isfinite(out).all()
-    assert rms <= 0.25 * 0.0075 * float(ref.pow(2).mean().sqrt())      # a quarter of the bf16 bound
-    assert err <= 0.25 * BF16_F3_MAX_ABS[hw]
+    mx, rms_b = storage_bound(f"f3_euler50_latent{hw}", "fp16")
+    assert rms <= rms_b and err <= mx
 
 
 # ---------------------------------------------------------------------------------- BASELINE config #3: batch > 1 on SDXL-base
@@ -282,7 +294,8 @@ def test_sdxl_f1_b4_step_bf16(gpu, sdxl_bf16):
     out = _sdxl_step_b4(sdxl_bf16, torch.bfloat16, gpu, torch.tensor(float(g["timestep"])))
     err, rms = float((out - ref).abs().max()), float((out - ref).pow(2).mean().sqrt())
     print(f"F1-b4 bf16: max abs err {err:.2e}, rms err {rms:.2e} (|ref| max {float(ref.abs().max()):.2f}, rms {float(ref.pow(2).mean().sqrt()):.2f})")
-    assert err <= 0.1 and rms <= 0.03                 # measured 6.5e-2 / 1.8e-2 at bs=1: ~1.5x headroom
+    mx, rms_b = storage_bound("f1_unet_step_latent64", "bf16")       # (the rows of a batch are independent: the bs=1 storage error, per row)
+    assert err <= mx and rms <= rms_b
 
 
 def _sdxl_loop_batch(gm, dtype, dev, hw, batch, mode, steps=None):
@@ -311,7 +324,7 @@ def test_sdxl_f3_b2_euler50_bf16(gpu, sdxl_bf16):
     out = _sdxl_loop_batch(sdxl_bf16, torch.bfloat16, gpu, 64, 2, "loop")
     rms, ref_rms = float((out - ref).pow(2).mean().sqrt()), float(ref.pow(2).mean().sqrt())
     print(f"F3-b2 latent64 bf16: final latent rms err {rms:.2e} = {100 * rms / ref_rms:.2f} % of {ref_rms:.2f}")
-    assert torch.isfinite(out).all() and rms <= 0.015 * ref_rms          # measured 0.5 % at bs=1: tightened from 5 %
+    assert torch.isfinite(out).all() and rms <= storage_bound("f3_euler50_latent64", "bf16")[1]      # (per row: the bs=1 storage error)
 
 
 @pytest.mark.parametrize("hw", [64, 128])

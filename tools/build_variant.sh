@@ -7,7 +7,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/tools/_variants/$name
 mkdir -p "$out/obj"
 objs=()
-for f in "$root"/stabletriton_amd/csrc/*.hip; do
+for f in "$root"/stabletriton_amd/csrc/*.hip "$root"/tools/dev_kernels/*.hip; do
   o=$out/obj/$(basename "${f%.hip}").o
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form "$@" -c "$f" -o "$o" &
   objs+=("$o")

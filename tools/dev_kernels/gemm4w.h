@@ -1,5 +1,5 @@
 // =============================================================================
-// gemm4w: 256 x 256 tiles on FOUR waves - one per SIMD, wave tile 128 x 128 (included by gemm_core.h).
+// gemm4w: 256 x 256 tiles on FOUR waves - one per SIMD, wave tile 128 x 128 (a developer kernel: included by csrc/dispatch.h in -DST_DEV_CONFIGS builds only).
 //
 // Why: the eight-phase kernel (gemm8p, wave tiles of 128 x 64) moves 192 KB of fragments out of LDS and 64 KB of DMA
 // into it per K tile: 256 KB at the LDS's 128 B/clk = 2048 cycles, exactly the tile's MFMA time - it is paced by LDS
@@ -231,13 +231,6 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const GemmArgs p) {
     }
 #undef ST4W_SYNC
     wait_vmcnt<0>();                                  // no LDS-DMA may outlive the workgroup's LDS allocation
-#ifdef ST_4W_NOEPI      // timing experiment: K loop only
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
-    return;
-#endif
     staged_epilogue<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, 2 * TILE_B, !LNF, sizeof(T) == 1>(p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, 128}, lds,
                                                                         reinterpret_cast<const float2*>(lnrows));
 }
