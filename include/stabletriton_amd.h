@@ -51,7 +51,7 @@ int         st_abi_version(void);          /* bumps on any signature or contract
                                               producer; 9: st_ln_linear_xattn; 10: ST_F16 accepted by every entry point
                                               that takes a dtype, st_ln_linear_xattn takes a dtype; 11: fp8 plan with
                                               delayed per-tensor scaling - st_linear_emit8, st_linear_fp8x, st_fp8_update_scales; 12: readers of a channel
-                                              concatenation that is never written - st_group_norm_from_stats_cat, st_conv1x1_cat; 13: ST_F32S split fp32 matrix operands, st_split_f32) */
+                                              concatenation that is never written - st_group_norm_from_stats_cat, st_conv1x1_cat; 13: ST_F32S split fp32 matrix operands, st_split_f32, st_arm_split_output) */
 const char* st_last_error(void);           /* host string, thread-local     */
 
 /* GroupNorm (+SiLU).  Replaces reference group_norm_wrapper
@@ -267,6 +267,13 @@ int st_fp8_update_scales(float* scale, float* inv_scale, unsigned int* amax_part
  * hi[k] = f16(x[k]), bytes [64, 128) lo[k] = f16((x[k] - hi[k]) * 2048).  K % 32 == 0.  No reference counterpart: the
  * reference's strict path is torch eager fp32 (optimizers/unet_pt.py:469-542). */
 int st_split_f32(const float* x, void* xs, long rows, int K, long ldx, void* stream);
+/* Split image from the PRODUCER: arms the next launch on the calling thread - one of st_linear, st_ln_linear, st_conv2d,
+ * st_conv1x1_cat, st_group_norm, st_group_norm_from_stats[_cat], st_attention with fp32 outputs (ST_F32 / ST_F32S) - to
+ * write, beside its output y of (rows, cols) values (cols % 32 == 0; rows = M, pixels or (batch, token)), the split image
+ * of y to ys (rows * cols * 4 bytes), which a following GEMM-shaped launch takes as its ST_F32S operand: no st_split_f32
+ * launch, no second read of y.  That launch disarms it.  An armed launch that cannot emit (16-bit element type, other
+ * shape) is rejected.  Thread-local, like st_last_error(). */
+int st_arm_split_output(void* ys, long rows, int cols);
 
 /* The reference's own timestep operator, elementwise (optimizers/replace_timesteps.py:33-40 ->
  * kernels/timestep.py:13-45): x is fp32 of shape (..., half), n elements in all;

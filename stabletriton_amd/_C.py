@@ -47,6 +47,7 @@ SIGNATURES = {
     "st_linear_fp8x": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _i, _p, _p, _f, _p, _i, _p, _p, _l, _p, _p, _p, _z, _p, _z, _p]),
     "st_fp8_update_scales": (_i, [_p, _p, _p, _i, _f, _p]),
     "st_split_f32": (_i, [_p, _p, _l, _i, _l, _p]),
+    "st_arm_split_output": (_i, [_p, _l, _i]),
 }
 
 _lib = None

@@ -361,7 +361,7 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
 
 // fp32 ("strict" parity mode): attention_f32.hip - split operands on the 16-bit matrix pipe, fp32 softmax
 int attention_f32_launch(const float* q, const float* k, const float* v, float* out, int B, int T, int S, int H,
-                         long ldq, long ldk, long ldv, long ldo, float scale, hipStream_t st);
+                         long ldq, long ldk, long ldv, long ldo, float scale, void* out_split, hipStream_t st);
 
 template <typename E>
 static int attention16_launch(const void* q, const void* k, const void* v, void* out, int B, int T, int S, int H,
@@ -413,8 +413,10 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
     ST_REQUIRE(ldq % vec == 0 && ldk % vec == 0 && ldv % vec == 0 && ldo % 4 == 0, "attention: strides must keep 16-byte alignment");
     ST_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 == 0, "attention: pointers must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    void* out_split = nullptr;
+    if (int e = st_take_split_arm("attention", (long)B * T, H * D, dtype == ST_F32, &out_split)) return e;
     if (dtype == ST_BF16) return attention16_launch<bf16>(q, k, v, out, B, T, S, H, ldq, ldk, ldv, ldo, scale, st);
     if (dtype == ST_F16) return attention16_launch<f16>(q, k, v, out, B, T, S, H, ldq, ldk, ldv, ldo, scale, st);
-    if (dtype == ST_F32) return attention_f32_launch((const float*)q, (const float*)k, (const float*)v, (float*)out, B, T, S, H, ldq, ldk, ldv, ldo, scale, st);
+    if (dtype == ST_F32) return attention_f32_launch((const float*)q, (const float*)k, (const float*)v, (float*)out, B, T, S, H, ldq, ldk, ldv, ldo, scale, out_split, st);
     return st_fail("attention: unsupported dtype %d", dtype);
 }

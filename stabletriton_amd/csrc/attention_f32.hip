@@ -29,7 +29,9 @@ constexpr int SP_BUF = 4 * SP_PLANE;              // K hi, K lo, V hi, V lo
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                              const float* __restrict__ V, float* __restrict__ O, int T, int S,
-                                                             long ldq, long ldk, long ldv, long ldo, float scale_log2e) {
+                                                             long ldq, long ldk, long ldv, long ldo, float scale_log2e, char* __restrict__ Os, int Cs) {
+    // Os != nullptr: also the split image of the output, rows = (batch, token), Cs = H * 64 values per row (the consumer is the
+    // output projection: st_arm_split_output)
     constexpr int NT = NW * 64;
     constexpr int TASKS = 2 * ATT_KV * 8 / NT;     // (row, 8-value chunk) pieces of a K + V tile per thread
     static_assert(2 * ATT_KV * 8 % NT == 0 && TASKS % 2 == 0, "the K and the V pieces divide over the threads");
@@ -196,6 +198,10 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const float* __rest
 #pragma unroll
             for (int e = 0; e < 4; ++e) a_[e] = __builtin_fmaf(oc[db][e], 1.0f / ST_SPLIT_SCALE, om[db][e]) * inv;
             *reinterpret_cast<f32x4*>(orow + 16 * db + 4 * g) = a_;
+            if (Os) {
+                const float v4[4] = {a_[0], a_[1], a_[2], a_[3]};
+                split_store4(Os + ((size_t)b * T + q0 + c16) * Cs * 4, head * ATT_D + 16 * db + 4 * g, v4);
+            }
         }
     }
 }
@@ -204,11 +210,11 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const float* __rest
 
 // (entry: st_attention with dtype ST_F32, attention.hip)
 int attention_f32_launch(const float* q, const float* k, const float* v, float* out, int B, int T, int S, int H,
-                         long ldq, long ldk, long ldv, long ldo, float scale, hipStream_t st) {
+                         long ldq, long ldk, long ldv, long ldo, float scale, void* out_split, hipStream_t st) {
     const float c = scale * 1.4426950408889634f;
     constexpr size_t LDS = 2 * SP_BUF;
     // 64 query rows per block: the 1024-token level at batch 1 is 320 blocks, two per CU (LDS 64 KiB each)
     auto kfn = attn_split_kernel<4>;
-    hipLaunchKernelGGL(kfn, dim3(cdiv(T, 64), H, B), dim3(256), LDS, st, q, k, v, out, T, S, ldq, ldk, ldv, ldo, c);
+    hipLaunchKernelGGL(kfn, dim3(cdiv(T, 64), H, B), dim3(256), LDS, st, q, k, v, out, T, S, ldq, ldk, ldv, ldo, c, (char*)out_split, H * ATT_D);
     return st_check_launch("attention");
 }

@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 // ---- host-side error plumbing -------------------------------------------------
 int st_fail(const char* fmt, ...);      // records message, returns non-zero
 int st_check_launch(const char* what);  // hipGetLastError -> status
+int st_take_split_arm(const char* who, long rows, int cols, bool can_emit, void** out);      // runtime.hip: the image armed by st_arm_split_output
 
 #define ST_REQUIRE(cond, ...) do { if (!(cond)) return st_fail(__VA_ARGS__); } while (0)
 

@@ -104,7 +104,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n,
 
 // The feature set of an epilogue as bits (see staged_epilogue_impl): MODE >= 0 = exactly that set, tile inside the matrix.
 enum { EPI_F_BIAS = 1, EPI_F_RES = 2, EPI_F_RB = 4, EPI_F_LN = 8, EPI_F_SILU = 16, EPI_F_SCALE = 32, EPI_F_ROWS = 64, EPI_F_COLS = 128,
-       EPI_F_Q8 = 256, EPI_F_NOC = 512 };
+       EPI_F_Q8 = 256, EPI_F_NOC = 512, EPI_F_SP = 1024 };      // SP: the split image of the output (fp32 epilogues, strict mode)
 
 // lane (r16, q) holds rows m = .. + r16, columns n = .. + 4q .. 4q+3 of every 16x16 tile.
 template <typename T, int TM, int TN, int WTM, int WTN, bool GEGLU, int WGM_ = 0, int WGN_ = 0, bool ALIGNED_N = false, int MODE = -1>
@@ -264,6 +264,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                 if (mok[i] && nok[j]) {
                     const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                     Out4<T>::store((T*)p.C + (size_t)mrow[i] * p.ldc + ncol[j], v);
+                    if constexpr (std::is_same<T, float>::value) {      // strict mode: the split image for a GEMM-shaped consumer
+                        if (FAST ? bool(MODE & EPI_F_SP) : (p.sp_out != nullptr)) split_store4((char*)p.sp_out + (size_t)mrow[i] * p.N * 4, ncol[j], v);
+                    }
                     if (has_q8) {            // e4m3 copy of the stored values (4 bytes per lane)
                         q8_max = fmaxf(fmaxf(q8_max, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                         *reinterpret_cast<unsigned int*>((unsigned char*)p.q8_out + (size_t)mrow[i] * p.q8_ld + ncol[j]) =
@@ -569,6 +572,12 @@ __device__ __forceinline__ void staged_epilogue_impl(const GemmArgs& p, f32x4 (&
                         for (int e = 0; e < VEC; ++e) if (n + e < p.N) dst[e] = out[e];
                     }
                 }
+                if constexpr (std::is_same<TO, float>::value) {      // strict mode: the split image of the stored values (N % 32 == 0: whole vectors)
+                    if (FAST ? bool(MODE & EPI_F_SP) : (p.sp_out != nullptr)) {
+                        const float v4[4] = {out[0], out[1], out[2], out[3]};
+                        split_store4((char*)p.sp_out + (size_t)m * p.N * 4, n, v4);
+                    }
+                }
                 if constexpr (VEC == 8) {
                     if (has_q8 && col_full) {
                         float a = 0.f;
@@ -645,11 +654,23 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
     if (aligned) {
         const int flags = ((p.epi & ST_EPI_BIAS) ? EPI_F_BIAS : 0) | (has_res ? EPI_F_RES : 0) | (has_rb ? EPI_F_RB : 0) | (p.ln_c ? EPI_F_LN : 0) |
                           ((p.epi & ST_EPI_SILU) ? EPI_F_SILU : 0) | (p.col_scale ? EPI_F_SCALE : 0) | ((STATS && p.row_stats) ? EPI_F_ROWS : 0) |
-                          ((STATS && p.col_stats && (p.N & 3) == 0) ? EPI_F_COLS : 0) | (p.q8_out ? EPI_F_Q8 : 0) | (p.C ? 0 : EPI_F_NOC);
+                          ((STATS && p.col_stats && (p.N & 3) == 0) ? EPI_F_COLS : 0) | (p.q8_out ? EPI_F_Q8 : 0) | (p.C ? 0 : EPI_F_NOC) |
+                          (p.sp_out ? EPI_F_SP : 0);
 #define ST_EPI_CASE(M)                                                                                                                          \
     case (M):                                                                                                                                   \
         staged_epilogue_impl<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, LDS_BYTES, STATS, (M)>(p, acc, m0, n0, tile_n, wm, r16, q, colmap, lds, lnrows); \
         return;
+        if constexpr (std::is_same<TO, float>::value) {      // the strict mode's producers that also leave the split image of their output
+            if constexpr (!STATS && !SCALED) {
+                switch (flags) { ST_EPI_CASE(EPI_F_LN | EPI_F_SP) default: break; }
+            } else if constexpr (STATS && !SCALED) {
+                switch (flags) {
+                    ST_EPI_CASE(EPI_F_BIAS | EPI_F_ROWS | EPI_F_SP)
+                    ST_EPI_CASE(EPI_F_BIAS | EPI_F_RES | EPI_F_ROWS | EPI_F_SP)
+                    default: break;
+                }
+            }
+        }
         // (a folded LayerNorm carries the projection's bias in its d vector: no BIAS bit)
         if constexpr (!STATS && !SCALED) {
             switch (flags) { ST_EPI_CASE(EPI_F_LN) ST_EPI_CASE(EPI_F_LN | EPI_F_BIAS) default: break; }

@@ -52,6 +52,7 @@ static int linear_impl(const void* x, const void* W, const void* bias, const voi
         ST_REQUIRE(st_dtype_is16(dtype), "linear: the e4m3 copy is emitted by the 16-bit kernels");
         if (int e = check_q8("linear", a, q8, ldq8, q8_inv_scale, q8_amax)) return e;
     }
+    if (int e = st_take_split_arm("linear", M, N, !st_dtype_is16(dtype) && N % 32 == 0, &a.sp_out)) return e;
     return run_dense(a, dtype, (hipStream_t)stream);
 }
 
@@ -95,6 +96,7 @@ extern "C" int st_ln_linear(const void* x, const float* row_stats, int row_stats
     a.A = x; a.W = Wg; a.C = y; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.epi = epilogue;
     a.ln_c = c; a.ln_d = d; a.ln_eps = eps; a.splitk = 1; a.ln_stats = row_stats; a.ln_chunks = row_stats_chunks;
     take_hint(a, next_weights, next_weights_bytes);
+    if (int e = st_take_split_arm("ln_linear", M, N, !st_dtype_is16(dtype) && N % 32 == 0, &a.sp_out)) return e;
     return run_dense(a, dtype, (hipStream_t)stream);
 }
 
@@ -121,6 +123,7 @@ extern "C" int st_ln_linear_xattn(const void* x, const float* row_stats, int row
     a.ln_c = c; a.ln_d = d; a.ln_eps = eps; a.splitk = 1; a.ln_stats = row_stats; a.ln_chunks = row_stats_chunks;
     a.xa_k = k; a.xa_v = v; a.xa_ldk = ldk; a.xa_ldv = ldv; a.xa_S = S; a.xa_T = rows_per_batch; a.xa_scale_log2e = scale * 1.4426950408889634f;
     take_hint(a, next_weights, next_weights_bytes);
+    { void* none; if (int e = st_take_split_arm("ln_linear_xattn", M, N, false, &none)) return e; }
     return dtype == ST_BF16 ? gemm_xattn_bf16(a, (hipStream_t)stream) : gemm_xattn_f16(a, (hipStream_t)stream);
 }
 
@@ -209,6 +212,7 @@ extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const v
     a.col_stats = col_stats; a.col_tiles_cap = col_stats_tiles; a.col_rows_out = col_stats_rows;
     take_hint(a, next_weights, next_weights_bytes);
     if (int e = check_epilogue("conv2d", a)) return e;
+    if (int e = st_take_split_arm("conv2d", a.M, Cout, !st_dtype_is16(dtype) && Cout % 32 == 0 && Cin % 32 == 0, &a.sp_out)) return e;
     hipStream_t st = (hipStream_t)stream;
     const int kb = st_dtype_is16(dtype) ? 64 : 32;
     if (Cin % kb == 0) {
@@ -250,6 +254,7 @@ extern "C" int st_conv1x1_cat(const void* x0, int C0, const void* x1, int C1, co
     a.col_stats = col_stats; a.col_tiles_cap = col_stats_tiles; a.col_rows_out = col_stats_rows;
     take_hint(a, next_weights, next_weights_bytes);
     if (int e = check_epilogue("conv1x1_cat", a)) return e;
+    if (int e = st_take_split_arm("conv1x1_cat", a.M, Cout, !st_dtype_is16(dtype) && Cout % 32 == 0, &a.sp_out)) return e;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ST_BF16) return gemm_conv_bf16(a, 1, 0, st);
     if (dtype == ST_F16) return gemm_conv_f16(a, 1, 0, st);

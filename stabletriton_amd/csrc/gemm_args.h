@@ -4,6 +4,7 @@
 #pragma once
 #include "common.h"
 #include "attention_core.h"
+#include "split.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -50,6 +51,9 @@ struct GemmArgs {
     // e4m3 copy of the output for an fp8 consumer (delayed per-tensor scaling, fp8.hip): q8[m][n] = e4m3(value * *q8_inv_scale),
     // the launch's max |value| goes to the q8_amax partial slots; C may then be NULL (only the copy is wanted)
     void* q8_out; long q8_ld; const float* q8_inv_scale; unsigned int* q8_amax;
+    // split image of the output (strict mode, csrc/split.h): (M, N) values as fp16 pairs for a GEMM-shaped consumer, N % 32 == 0;
+    // written beside C by the fp32 epilogues (st_arm_split_output)
+    void* sp_out;
     const void* next_w; size_t next_bytes;   // weights of the NEXT launch (host hint): touched during this epilogue
     int helper_blocks;           // > 0: that many extra blocks at the end of the grid (idle CUs) do the touching instead
     // st_ln_linear_xattn: the tile is the query block of ONE head; its epilogue runs the text-context attention on it

@@ -589,7 +589,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
             mean[i] = v.x; rstd[i] = v.y;
         }
         // (specialised instances for the feature sets of the step, as in staged_epilogue)
-        const bool inside = (m0 + BM <= p.M) && (n0 + BNO <= p.N) && (p.N & 3) == 0 && p.C != nullptr && !p.q8_out;
+        const bool inside = (m0 + BM <= p.M) && (n0 + BNO <= p.N) && (p.N & 3) == 0 && p.C != nullptr && !p.q8_out && !p.sp_out;
         const int flags = inside ? (((p.epi & ST_EPI_BIAS) ? EPI_F_BIAS : 0) | (p.epi & (ST_EPI_RESIDUAL | ST_EPI_ROWBIAS | ST_EPI_SILU) ? 1024 : 0) |
                                     (p.col_scale ? EPI_F_SCALE : 0) | EPI_F_LN) : -1;
         if (!is_fp8<T>() && flags == EPI_F_LN) gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, 0, 0, false, EPI_F_LN>(p, acc, m0, n0, wm, wn, r16, q, split, mean, rstd);
@@ -602,12 +602,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         const bool inside = (m0 + BM <= p.M) && (n0 + BNO <= p.N) && (p.N & 3) == 0 && p.C != nullptr;
         const int flags = inside ? (((p.epi & ST_EPI_BIAS) ? EPI_F_BIAS : 0) | ((p.epi & ST_EPI_RESIDUAL) ? EPI_F_RES : 0) | ((p.epi & ST_EPI_ROWBIAS) ? EPI_F_RB : 0) |
                                     ((p.epi & ST_EPI_SILU) ? EPI_F_SILU : 0) | (p.col_scale ? EPI_F_SCALE : 0) | (p.ln_c ? EPI_F_LN : 0) | (p.row_stats ? EPI_F_ROWS : 0) |
-                                    ((p.col_stats && (p.N & 3) == 0) ? EPI_F_COLS : 0) | (p.q8_out ? EPI_F_Q8 : 0)) : -1;
+                                    ((p.col_stats && (p.N & 3) == 0) ? EPI_F_COLS : 0) | (p.q8_out ? EPI_F_Q8 : 0) | (p.sp_out ? EPI_F_SP : 0)) : -1;
 #define ST_FRAG_CASE(M)                                                                                                                        \
     case (M):                                                                                                                                  \
         gemm_epilogue<TO, TM, TN, WTM, WTN, GEGLU, WGM, WGN, false, (M)>(p, acc, m0, n0, wm, wn, r16, q, split, nullptr, nullptr, lds, tile_n); \
         break;
-        if constexpr (!is_fp8<T>()) {
+        bool done = false;
+        if constexpr (std::is_same<TO, float>::value) {      // (strict mode producers with the split image; anything else below)
+            done = true;
+            switch (flags) {
+                ST_FRAG_CASE(EPI_F_BIAS | EPI_F_ROWS | EPI_F_SP)
+                ST_FRAG_CASE(EPI_F_BIAS | EPI_F_RES | EPI_F_ROWS | EPI_F_SP)
+                default: done = false;
+            }
+        }
+        if (done) {
+        } else if constexpr (!is_fp8<T>()) {
             switch (flags) {
                 ST_FRAG_CASE(EPI_F_BIAS)
                 ST_FRAG_CASE(EPI_F_BIAS | EPI_F_RES)

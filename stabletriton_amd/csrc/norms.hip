@@ -2,6 +2,8 @@
 // 16-byte loads per lane, fp32 statistics, wave64 shuffles + LDS for the
 // cross-wave step.  (Rows G and E of SURVEY.md section 8a, LayerNorm is 8f-1.)
 #include "common.h"
+#include "split.h"
+#include <type_traits>
 
 // =============================================================================
 // GroupNorm
@@ -147,7 +149,8 @@ template <typename T, bool SILU>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_nhwc(const T* __restrict__ x, const T* __restrict__ gamma,
                                                             const T* __restrict__ beta, const float2* __restrict__ stats,
                                                             T* __restrict__ y, int C, int HW, int G, int VC, int RP, int P,
-                                                            const T* __restrict__ x1 = nullptr, int C0 = 0) {
+                                                            const T* __restrict__ x1 = nullptr, int C0 = 0, char* __restrict__ ys = nullptr) {
+    // ys != nullptr (fp32 only, C % 32 == 0): also the split image of y, rows = pixels (st_arm_split_output)
     // x1 != nullptr: the input is the channel concatenation [x | x1] that was never materialised - channels [0, C0) of a pixel
     // from x (pixel stride C0), the rest from x1 (pixel stride C - C0); a thread's channel vector lies in one of them
     constexpr int VEC = Elem<T>::VEC;
@@ -177,6 +180,12 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_nhwc(const T* __restrict_
             o.set(i, f);
         }
         store16(y + base + (size_t)p * C, o);
+        if constexpr (std::is_same<T, float>::value) {
+            if (ys) {
+                const float v4[4] = {o.get(0), o.get(1), o.get(2), o.get(3)};
+                split_store4(ys + ((size_t)n * HW + p) * C * 4, col * VEC, v4);
+            }
+        }
     }
 }
 
@@ -203,7 +212,7 @@ static size_t gn_ws_bytes(int N, int G) {
 
 template <typename T>
 static int gn_launch(const void* x, const void* gamma, const void* beta, void* y, int N, int C, int HW, int G,
-                     float eps, int silu, int layout, void* ws, hipStream_t st) {
+                     float eps, int silu, int layout, void* ws, hipStream_t st, char* ys = nullptr) {
     float4* part = (float4*)ws;
     float2* stats = (float2*)((char*)ws + (size_t)N * GN_MAX_BLOCKS * G * sizeof(float4));
     int NB;
@@ -218,10 +227,10 @@ static int gn_launch(const void* x, const void* gamma, const void* beta, void* y
         hipLaunchKernelGGL(gn_finalize, dim3(cdiv(N * G, 4)), dim3(256), 0, st, part, stats, NB, G, N * G, eps);
         if (silu)
             hipLaunchKernelGGL((gn_apply_nhwc<T, true>), dim3(NB, N), dim3(GN_THREADS), 0, st, (const T*)x, (const T*)gamma,
-                               (const T*)beta, stats, (T*)y, C, HW, G, g.VC, g.RP, g.P);
+                               (const T*)beta, stats, (T*)y, C, HW, G, g.VC, g.RP, g.P, (const T*)nullptr, 0, ys);
         else
             hipLaunchKernelGGL((gn_apply_nhwc<T, false>), dim3(NB, N), dim3(GN_THREADS), 0, st, (const T*)x, (const T*)gamma,
-                               (const T*)beta, stats, (T*)y, C, HW, G, g.VC, g.RP, g.P);
+                               (const T*)beta, stats, (T*)y, C, HW, G, g.VC, g.RP, g.P, (const T*)nullptr, 0, ys);
     } else {
         const long total = (long)(C / G) * HW;
         NB = (int)((total + 8191) / 8192);
@@ -256,9 +265,11 @@ extern "C" int st_group_norm(const void* x, const void* gamma, const void* beta,
     ST_REQUIRE(groups <= 1024 && N * C <= 65535 && N <= 65535, "group_norm: shape exceeds launch limits");
     ST_REQUIRE(layout == ST_NCHW || layout == ST_NHWC, "group_norm: bad layout %d", layout);
     hipStream_t st = (hipStream_t)stream;
+    void* ys = nullptr;
+    if (int e = st_take_split_arm("group_norm", (long)N * HW, C, dtype == ST_F32 && layout == ST_NHWC && C % 32 == 0, &ys)) return e;
     if (dtype == ST_BF16) return gn_launch<bf16>(x, gamma, beta, y, N, C, HW, groups, eps, silu, layout, workspace, st);
     if (dtype == ST_F16) return gn_launch<f16>(x, gamma, beta, y, N, C, HW, groups, eps, silu, layout, workspace, st);
-    if (dtype == ST_F32) return gn_launch<float>(x, gamma, beta, y, N, C, HW, groups, eps, silu, layout, workspace, st);
+    if (dtype == ST_F32) return gn_launch<float>(x, gamma, beta, y, N, C, HW, groups, eps, silu, layout, workspace, st, (char*)ys);
     return st_fail("group_norm: unsupported dtype %d", dtype);
 }
 
@@ -308,7 +319,8 @@ __global__ __launch_bounds__(256) void gn_cols_finalize(GnSource s0, GnSource s1
 
 template <typename T>
 static int gn_from_stats_launch(const void* x, const void* gamma, const void* beta, void* y, int N, int C, int HW, int G, float eps,
-                                int silu, GnSource s0, GnSource s1, void* ws, hipStream_t st, const void* x1 = nullptr, int C0 = 0) {
+                                int silu, GnSource s0, GnSource s1, void* ws, hipStream_t st, const void* x1 = nullptr, int C0 = 0,
+                                char* ys = nullptr) {
     ST_REQUIRE(C % Elem<T>::VEC == 0, "group_norm_from_stats: C=%d must be a multiple of %d", C, Elem<T>::VEC);
     GnGeom g = gn_geom<T>(C, HW);
     ST_REQUIRE(g.VC <= GN_THREADS, "group_norm_from_stats: C=%d too wide", C);
@@ -317,10 +329,10 @@ static int gn_from_stats_launch(const void* x, const void* gamma, const void* be
                        (double)(C / G) * (double)HW, eps);
     if (silu)
         hipLaunchKernelGGL((gn_apply_nhwc<T, true>), dim3(g.NB, N), dim3(GN_THREADS), 0, st, (const T*)x, (const T*)gamma,
-                           (const T*)beta, stats, (T*)y, C, HW, G, g.VC, g.RP, g.P, (const T*)x1, C0);
+                           (const T*)beta, stats, (T*)y, C, HW, G, g.VC, g.RP, g.P, (const T*)x1, C0, ys);
     else
         hipLaunchKernelGGL((gn_apply_nhwc<T, false>), dim3(g.NB, N), dim3(GN_THREADS), 0, st, (const T*)x, (const T*)gamma,
-                           (const T*)beta, stats, (T*)y, C, HW, G, g.VC, g.RP, g.P, (const T*)x1, C0);
+                           (const T*)beta, stats, (T*)y, C, HW, G, g.VC, g.RP, g.P, (const T*)x1, C0, ys);
     return st_check_launch("group_norm_from_stats");
 }
 
@@ -336,9 +348,11 @@ extern "C" int st_group_norm_from_stats(const void* x, const void* gamma, const 
     GnSource s0 = {(const float2*)stats0, C0, HW / rows0};
     GnSource s1 = {(const float2*)stats1, C1, stats1 ? HW / rows1 : 0};
     hipStream_t st = (hipStream_t)stream;
+    void* ys = nullptr;
+    if (int e = st_take_split_arm("group_norm_from_stats", (long)N * HW, C, dtype == ST_F32 && C % 32 == 0, &ys)) return e;
     if (dtype == ST_BF16) return gn_from_stats_launch<bf16>(x, gamma, beta, y, N, C, HW, groups, eps, silu, s0, s1, workspace, st);
     if (dtype == ST_F16) return gn_from_stats_launch<f16>(x, gamma, beta, y, N, C, HW, groups, eps, silu, s0, s1, workspace, st);
-    if (dtype == ST_F32) return gn_from_stats_launch<float>(x, gamma, beta, y, N, C, HW, groups, eps, silu, s0, s1, workspace, st);
+    if (dtype == ST_F32) return gn_from_stats_launch<float>(x, gamma, beta, y, N, C, HW, groups, eps, silu, s0, s1, workspace, st, nullptr, 0, (char*)ys);
     return st_fail("group_norm_from_stats: unsupported dtype %d", dtype);
 }
 
@@ -358,9 +372,11 @@ extern "C" int st_group_norm_from_stats_cat(const void* x0, const void* x1, cons
     GnSource s0 = {(const float2*)stats0, C0, HW / rows0};
     GnSource s1 = {(const float2*)stats1, C1, HW / rows1};
     hipStream_t st = (hipStream_t)stream;
+    void* ys = nullptr;
+    if (int e = st_take_split_arm("group_norm_from_stats_cat", (long)N * HW, C, dtype == ST_F32 && C % 32 == 0, &ys)) return e;
     if (dtype == ST_BF16) return gn_from_stats_launch<bf16>(x0, gamma, beta, y, N, C, HW, groups, eps, silu, s0, s1, workspace, st, x1, C0);
     if (dtype == ST_F16) return gn_from_stats_launch<f16>(x0, gamma, beta, y, N, C, HW, groups, eps, silu, s0, s1, workspace, st, x1, C0);
-    if (dtype == ST_F32) return gn_from_stats_launch<float>(x0, gamma, beta, y, N, C, HW, groups, eps, silu, s0, s1, workspace, st, x1, C0);
+    if (dtype == ST_F32) return gn_from_stats_launch<float>(x0, gamma, beta, y, N, C, HW, groups, eps, silu, s0, s1, workspace, st, x1, C0, (char*)ys);
     return st_fail("group_norm_from_stats_cat: unsupported dtype %d", dtype);
 }
 

@@ -4,6 +4,29 @@
 
 static thread_local char g_err[512] = "";
 
+// ---- split image of the NEXT launch's output (strict mode; header: st_arm_split_output) -------------------------------
+static thread_local struct { void* p; long rows; int cols; } g_split_arm = {nullptr, 0, 0};
+
+extern "C" int st_arm_split_output(void* ys, long rows, int cols) {
+    ST_REQUIRE(ys && rows > 0 && cols > 0 && cols % 32 == 0 && (uintptr_t)ys % 16 == 0, "arm_split_output: (rows, cols) image with cols %% 32 == 0 expected");
+    g_split_arm = {ys, rows, cols};
+    return 0;
+}
+
+// Called by every entry point that can emit: returns the armed image for an output of (rows, cols) fp32 values and disarms
+// it; a launch that is armed but cannot emit (other element type, other shape) fails, so an armed image is never left
+// unwritten without the caller hearing of it.
+int st_take_split_arm(const char* who, long rows, int cols, bool can_emit, void** out) {
+    *out = nullptr;
+    if (!g_split_arm.p) return 0;
+    const auto arm = g_split_arm;
+    g_split_arm = {nullptr, 0, 0};
+    ST_REQUIRE(can_emit, "%s: a split output image was armed, but this launch cannot emit one (fp32 outputs only)", who);
+    ST_REQUIRE(arm.rows == rows && arm.cols == cols, "%s: the armed split image is (%ld, %d), the output is (%ld, %d)", who, arm.rows, arm.cols, rows, cols);
+    *out = arm.p;
+    return 0;
+}
+
 int st_fail(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);

@@ -29,5 +29,15 @@ __device__ __forceinline__ void split8(const float (&x)[8], f16x8& hi, f16x8& lo
     }
 }
 
+// four consecutive values of a row (k % 4 == 0) -> 8 bytes of hi halves at split_off(k) of the row's image, 8 bytes of lo halves 64 further
+__device__ __forceinline__ void split_store4(char* row_image, int k, const float (&v)[4]) {
+    f16x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f16 h, l; split_f32(v[i], h, l); hi[i] = h; lo[i] = l; }
+    char* dst = row_image + (size_t)(k >> 5) * 128 + (size_t)(k & 31) * 2;
+    *reinterpret_cast<f16x4*>(dst) = hi;
+    *reinterpret_cast<f16x4*>(dst + 64) = lo;
+}
+
 // byte offset of value k of a row inside the row's split image: hi half; the lo half sits 64 bytes further
 __device__ __forceinline__ size_t split_off(int k) { return (size_t)(k >> 5) * 128 + (size_t)(k & 31) * 2; }

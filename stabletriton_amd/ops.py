@@ -307,6 +307,44 @@ def split_usable(dtype: torch.dtype, K: int) -> bool:
     return STRICT_SPLIT and dtype == torch.float32 and K % SPLIT_K == 0
 
 
+# Split images written by PRODUCERS (st_arm_split_output): an operator whose fp32 output usually feeds a GEMM-shaped consumer
+# (GroupNorm(+SiLU) -> conv / proj_in, attention -> to_out, the GEGLU projection -> ff.net.2, a GEMM that emits LayerNorm
+# partials -> the LayerNorm-folded projection) leaves the image beside its output and notes it here; the consumer finds it by
+# the output's memory (address, rows, row length) and skips its own st_split_f32 launch.  An entry HOLDS the output tensor,
+# so its memory cannot be handed to another tensor while the note exists, and the list keeps only the last few outputs
+# (consumers follow their producers within a handful of launches): a miss costs one launch, never a wrong operand.
+_RECENT_SPLITS = 6
+EMIT_SPLIT = True             # False: every consumer splits its own input (tests compare)
+
+
+def _arm_split(out: torch.Tensor, rows: int, cols: int):
+    """Arm the next launch to write the split image of `out` (rows x cols fp32, dense rows); returns the image tensor or None."""
+    if not (EMIT_SPLIT and split_usable(out.dtype, cols)):
+        return None
+    img = torch.empty((rows, cols), dtype=torch.float32, device=out.device)
+    _C.check(_C.load().st_arm_split_output(img.data_ptr(), rows, cols), "arm_split_output")
+    return img
+
+
+def _note_split(out: torch.Tensor, img: Optional[torch.Tensor], rows: int, cols: int) -> None:
+    if img is None:
+        return
+    ctx = current_context(out.device)
+    lst = ctx.__dict__.setdefault("recent_splits", [])
+    lst.append((out, out.data_ptr(), rows, cols, img))
+    del lst[:-_RECENT_SPLITS]
+
+
+def _split_of(x: torch.Tensor, rows: int, cols: int, ld: int) -> torch.Tensor:
+    """The split image of the (rows, cols) fp32 matrix at x's address (row stride ld): a producer's, if one was noted, else made now."""
+    if ld == cols:
+        for ent in reversed(current_context(x.device).__dict__.get("recent_splits", ())):
+            if ent[1] == x.data_ptr() and ent[2] == rows and ent[3] == cols:
+                return ent[4]
+    x2 = x if (x.dim() == 2 and x.shape[1] == cols) else x.as_strided((rows, cols), (ld, 1))
+    return split_rows(x2).s
+
+
 @torch.no_grad()
 def _split_weight(owner: torch.Tensor, as_rows=None, want_rowsum: bool = False):
     """Split image of a weight, kept by the current execution context and re-derived in place when `owner` changes.
@@ -357,9 +395,11 @@ def group_norm(x: torch.Tensor, num_groups: int, weight: torch.Tensor, bias: tor
     # scratch for the partial statistics: allocated per call from torch's caching allocator (stream-ordered; under
     # graph capture it belongs to the graph's private pool, so replays never alias a buffer somebody else owns)
     ws = torch.empty(lib.st_group_norm_workspace_bytes(N, Cc, HW, num_groups), dtype=torch.uint8, device=x.device)
+    img = _arm_split(y, N * HW, Cc) if layout == _C.ST_NHWC else None      # strict mode: the conv / proj_in behind it reads the split image
     _C.check(lib.st_group_norm(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups,
                                float(eps), int(bool(silu)), layout, _C.dtype_code(x.dtype), ws.data_ptr(),
                                _C.stream_ptr()), "group_norm")
+    _note_split(y, img, N * HW, Cc)
     return y
 
 
@@ -400,11 +440,13 @@ def group_norm_from_stats(x: torch.Tensor, sources, num_groups: int, weight: tor
     ws = torch.empty(lib.st_group_norm_workspace_bytes(N, Cc, HW, num_groups), dtype=torch.uint8, device=x.device)
     s0 = sources[0]
     s1 = sources[1] if len(sources) == 2 else None
+    img = _arm_split(y, N * HW, Cc)
     _C.check(lib.st_group_norm_from_stats(x.data_ptr(), w.data_ptr(),
                     b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups, float(eps), int(bool(silu)), _C.dtype_code(x.dtype),
                     s0.buf.data_ptr(), s0.channels, s0.rows, None if s1 is None else s1.buf.data_ptr(),
                     0 if s1 is None else s1.channels, 0 if s1 is None else s1.rows, ws.data_ptr(), _C.stream_ptr()),
              "group_norm_from_stats")
+    _note_split(y, img, N * HW, Cc)
     return y
 
 
@@ -431,10 +473,12 @@ def group_norm_from_stats_cat(x0: torch.Tensor, x1: torch.Tensor, sources, num_g
     b = bias if bias.dtype == x0.dtype else bias.to(x0.dtype)
     ws = torch.empty(lib.st_group_norm_workspace_bytes(N, Cc, HW, num_groups), dtype=torch.uint8, device=x0.device)
     s0, s1 = sources
+    img = _arm_split(y, N * HW, Cc)
     _C.check(lib.st_group_norm_from_stats_cat(x0.data_ptr(), x1.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups,
                                               float(eps), int(bool(silu)), _C.dtype_code(x0.dtype), s0.buf.data_ptr(), s0.channels, s0.rows,
                                               s1.buf.data_ptr(), s1.channels, s1.rows, ws.data_ptr(), _C.stream_ptr()),
              "group_norm_from_stats_cat")
+    _note_split(y, img, N * HW, Cc)
     return y
 
 
@@ -511,7 +555,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     code = _C.dtype_code(x.dtype)
     if split_usable(x.dtype, K) and emit_q8 is None and weight.is_contiguous():
         # strict mode: both matrix operands as split images (the weight's is kept by the context), everything else fp32
-        x2, lda, w, code = split_rows(x2 if x2.dim() == 2 else x2.reshape(M, K)).s, K, _split_weight(weight)[0], _C.ST_F32S
+        x2, lda, w, code = _split_of(x2, M, K, lda), K, _split_weight(weight)[0], _C.ST_F32S
     epi = 0
     if bias is not None:
         epi |= _C.EPI_BIAS
@@ -545,12 +589,16 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         # (any other rank: tokens were flattened, the image boundaries are unknown - no partials, the consumer
         # GroupNorm takes its own statistics pass, as for every other producer that cannot emit them)
     act8 = None
+    # strict mode: an output that a LayerNorm-folded projection (emit_stats) or the feed-forward output projection (geglu) reads
+    # next leaves its split image too
+    img = _arm_split(out, M, N) if (code == _C.ST_F32S and (emit_stats or geglu)) else None
     if emit_q8 is None:
         _C.check(lib.st_linear(x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
                         lda, N, ldr, rows_per_image, epi, code, gws.data_ptr(), gws.numel(),
                         _ptr(stats), 0 if stats is None else stats.shape[1],
                         None if chunks is None else ctypes.byref(chunks), _ptr(cbuf), ctiles or 0,
                         None if crows is None else ctypes.byref(crows), nxt_p, nxt_b, _C.stream_ptr()), "linear")
+        _note_split(out, img, M, N)
     else:
         sc = fp8_scales(x.device)
         idx = sc.site(emit_q8)
@@ -598,11 +646,13 @@ def ln_linear(x: torch.Tensor, stats: "RowStats", w_folded: torch.Tensor, c: tor
     if split_usable(x.dtype, K) and w_folded.is_contiguous():
         # (c must be the row sums of the values the split image holds: the fold subtracts mean * c from their products)
         w_folded, c = _split_weight(w_folded, want_rowsum=True)
-        x2, lda, code = split_rows(x2 if x2.dim() == 2 else x2.reshape(M, K)).s, K, _C.ST_F32S
+        x2, lda, code = _split_of(x2, M, K, lda), K, _C.ST_F32S
     nxt_p, nxt_b = _next_weights(w_folded)
+    img = _arm_split(out, M, N) if (code == _C.ST_F32S and geglu) else None
     _C.check(lib.st_ln_linear(x2.data_ptr(), stats.buf.data_ptr(), stats.chunks, w_folded.data_ptr(),
                     c.data_ptr(), d.data_ptr(), out.data_ptr(), M, N, K,
                     lda, N, float(eps), _C.EPI_GEGLU if geglu else 0, code, nxt_p, nxt_b, _C.stream_ptr()), "ln_linear")
+    _note_split(out, img, M, N)
     return out
 
 
@@ -835,8 +885,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int,
     k_, ldk = tok(k)
     v_, ldv = tok(v)
     out = torch.empty((B, T, Cc), dtype=q.dtype, device=q.device)
+    img = _arm_split(out, B * T, Cc)              # strict mode: the output projection reads the split image
     _C.check(lib.st_attention(q_.data_ptr(), k_.data_ptr(), v_.data_ptr(), out.data_ptr(), B, T, S, num_heads, D,
                               ldq, ldk, ldv, Cc, float(scale), _C.dtype_code(q.dtype), _C.stream_ptr()), "attention")
+    _note_split(out, img, B * T, Cc)
     return out
 
 
@@ -884,7 +936,7 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
     code = _C.dtype_code(x.dtype)
     if split_usable(x.dtype, Cin) and w is weight:
         # strict mode: the pixels' channel vectors and the filter taps as split images (32 channels per segment)
-        x = split_rows(x.permute(0, 2, 3, 1).reshape(-1, Cin)).s
+        x = _split_of(x, N * H * W, Cin, Cin)
         w, code = _split_weight(weight, _conv_weight_rows)[0], _C.ST_F32S
     nxt_p, nxt_b = _next_weights(w)
     cbuf = ctiles = crows = None
@@ -935,8 +987,8 @@ def conv2d_cat(x0: torch.Tensor, x1: torch.Tensor, weight: torch.Tensor, bias: O
     gws = _gemm_workspace(x0.device)
     code = _C.dtype_code(x0.dtype)
     if split_usable(x0.dtype, C0) and C1 % SPLIT_K == 0 and w is weight:
-        x0 = split_rows(x0.permute(0, 2, 3, 1).reshape(-1, C0)).s
-        x1 = split_rows(x1.permute(0, 2, 3, 1).reshape(-1, C1)).s
+        x0 = _split_of(x0, N * H * W, C0, C0)
+        x1 = _split_of(x1, N * H * W, C1, C1)
         w, code = _split_weight(weight, _conv_weight_rows)[0], _C.ST_F32S
     nxt_p, nxt_b = _next_weights(w)
     cbuf = ctiles = crows = None

@@ -127,3 +127,88 @@ def test_attention_fp32_peaked_rows(gpu):
     ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, dim=-1) @ vh).transpose(1, 2).reshape(B, T, H * 64)
     out = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), H, 0.125)
     assert _err(out, ref) <= 2e-5          # exponents of a few hundred: the scores' 2^-22 shows in the probabilities
+
+
+# ------------------------------------------------------------------------------------------ split images from the producers
+def _image_of(t2):
+    return ops.split_rows(t2.contiguous()).s
+
+
+def _recent(ctx):
+    return ctx.__dict__.get("recent_splits", [])
+
+
+def test_producers_leave_the_split_image_of_what_they_store(gpu):
+    """st_arm_split_output: the image a producer writes beside its fp32 output is bit for bit st_split_f32 of that output
+    (GEMM epilogues in both forms, GroupNorm apply, attention), and the consumer's launch finds it instead of splitting."""
+    with ops.ExecContext() as ctx:
+        M, K, N = 1024, 1280, 1280
+        x, w, b, r = rnd("em.x", (M, K)).to(gpu), (rnd("em.w", (N, K)) * K ** -0.5).to(gpu), rnd("em.b", (N,)).to(gpu), rnd("em.r", (M, N)).to(gpu)
+        for (mm, kk, nn) in ((M, K, N), (4096, 640, 640), (96, 64, 64)):          # staged epilogue, fragment epilogue, a ragged small one
+            xx, ww = rnd("em.x2", (mm, kk)).to(gpu), (rnd("em.w2", (nn, kk)) * kk ** -0.5).to(gpu)
+            out, st = ops.linear(xx, ww, None, emit_stats=True)
+            ent = _recent(ctx)[-1]
+            assert ent[0] is out and torch.equal(ent[4].view(torch.int32), _image_of(out).view(torch.int32))
+        out, st = ops.linear(x, w, b, residual=r, emit_stats=True)
+        img = _recent(ctx)[-1][4]
+        # the LayerNorm-folded GEGLU projection behind it: finds the image, leaves its own for ff.net.2
+        g, be = (rnd("em.g", (N,)) * 0.2 + 1).to(gpu), (rnd("em.be", (N,)) * 0.2).to(gpu)
+        w1, b1 = (rnd("em.w1", (2 * 2560, N)) * N ** -0.5).to(gpu), rnd("em.b1", (2 * 2560,)).to(gpu)
+        wf, c, d = ops.fold_layer_norm(g, be, w1, b1)
+        seen = []
+        real = ops.split_rows
+        ops.split_rows = lambda t, shape=None: (seen.append(tuple(t.shape)), real(t, shape))[1]
+        try:
+            h = ops.ln_linear(out, st, wf, c, d, 1e-5, geglu=True)
+        finally:
+            ops.split_rows = real
+        assert (M, N) not in seen, f"the consumer split its input although the producer left the image: {seen}"
+        ent = _recent(ctx)[-1]
+        assert ent[0] is h and torch.equal(ent[4].view(torch.int32), _image_of(h).view(torch.int32))
+        ops.EMIT_SPLIT = False
+        try:
+            out2, st2 = ops.linear(x, w, b, residual=r, emit_stats=True)
+            h2 = ops.ln_linear(out2, st2, wf, c, d, 1e-5, geglu=True)
+        finally:
+            ops.EMIT_SPLIT = True
+        assert torch.equal(out, out2) and torch.equal(h, h2)           # same bits with and without the producers' images
+        # attention -> output projection
+        q, k, v = rnd("em.q", (2, 256, 320)).to(gpu), rnd("em.k", (2, 77, 320)).to(gpu), rnd("em.v", (2, 77, 320)).to(gpu)
+        o = ops.attention(q, k, v, 5, 0.125)
+        ent = _recent(ctx)[-1]
+        assert ent[0] is o and torch.equal(ent[4].view(torch.int32), _image_of(o.view(-1, 320)).view(torch.int32))
+        # GroupNorm(+SiLU) on a channels_last tensor -> conv
+        xi = rnd("em.xi", (2, 320, 16, 16)).to(gpu).contiguous(memory_format=torch.channels_last)
+        gw, gb = (rnd("em.gw", (320,)) * 0.2 + 1).to(gpu), rnd("em.gb", (320,)).to(gpu)
+        y = ops.group_norm(xi, 32, gw, gb, 1e-5, True)
+        ent = _recent(ctx)[-1]
+        assert ent[0] is y and torch.equal(ent[4].view(torch.int32), _image_of(y.permute(0, 2, 3, 1).reshape(-1, 320)).view(torch.int32))
+        wc = (rnd("em.wc", (64, 320, 3, 3)) * (320 * 9) ** -0.5).to(gpu).contiguous(memory_format=torch.channels_last)
+        seen.clear()
+        ops.split_rows = lambda t, shape=None: (seen.append(tuple(t.shape)), real(t, shape))[1]
+        try:
+            co = ops.conv2d(y, wc, None, 1, 1)
+        finally:
+            ops.split_rows = real
+        assert (2 * 16 * 16, 320) not in seen
+        ops.EMIT_SPLIT = False
+        try:
+            co2 = ops.conv2d(ops.group_norm(xi, 32, gw, gb, 1e-5, True), wc, None, 1, 1)
+        finally:
+            ops.EMIT_SPLIT = True
+        assert torch.equal(co, co2)
+
+
+def test_armed_image_is_never_left_unwritten(gpu):
+    """An armed launch that cannot emit is rejected (and disarms): a consumer can never pick up an image nobody wrote."""
+    from stabletriton_amd import _C
+    lib = _C.load()
+    img = torch.empty((64, 64), dtype=torch.float32, device=gpu)
+    x, w = rnd("arm.x", (64, 64)).to(gpu, torch.bfloat16), rnd("arm.w", (64, 64)).to(gpu, torch.bfloat16)
+    _C.check(lib.st_arm_split_output(img.data_ptr(), 64, 64), "arm")
+    with pytest.raises(ops.BackendError, match="cannot emit"):
+        ops.linear(x, w, None)                       # a bf16 launch
+    assert torch.isfinite(ops.linear(x, w, None).float()).all()          # disarmed: the next launch is an ordinary one
+    _C.check(lib.st_arm_split_output(img.data_ptr(), 32, 64), "arm")
+    with pytest.raises(ops.BackendError, match="armed split image"):
+        ops.linear(x.float(), w.float(), None)       # fp32, but another shape

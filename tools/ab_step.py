@@ -22,7 +22,7 @@ def one(variant, batch, dtype_name, latent):
     from stabletriton_amd.scheduler import euler_discrete_tables
     from stabletriton_amd.unet import SDXL_BASE, UNet2DConditionModel
     dev = torch.device("cuda:0")
-    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype_name]
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[dtype_name]
     with torch.device("meta"):
         m = UNet2DConditionModel(SDXL_BASE)
     m = m.to_empty(device=dev).to(dtype).eval().requires_grad_(False)

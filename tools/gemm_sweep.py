@@ -17,6 +17,10 @@ force.argtypes, force.restype = [ctypes.c_int, ctypes.c_int], None
 # only configurations the product dispatch can select (the other developer tilings are not maintained: 256x256_W8 faults)
 NAMES = {7: "64x64_W8", 8: "128x64_W8", 9: "128x128_W8", 10: "64x128_W8", 19: "256x128_W8", 23: "128x320_W8",
          25: "64x320_W8", 27: "128x80_W8", 28: "128x160_W8", 100: "256x256_8P", 101: "256x160_8P"}
+if os.environ.get("ST_BENCH_DTYPE") == "fp32":      # split operands: two accumulator sets, no eight-phase kernel
+    NAMES = {7: "64x64_W8", 8: "128x64_W8", 9: "128x128_W8", 10: "64x128_W8", 27: "128x80_W8", 25: "64x320_W8", 13: "128x128_W8_S3", 21: "128x64_W8_S3", 22: "64x128_W8_S3"}
+ctx = ops.ExecContext()      # (fp32 / strict mode: the split images of the weights are kept per context, as in a compiled module)
+ctx.__enter__()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 which = sys.argv[2] if len(sys.argv) > 2 else "all"
 shapes = [(1024 * B, 1280, 1280, 0), (1024 * B, 1280, 3840, 0), (1024 * B, 1280, 5120, 1), (1024 * B, 5120, 1280, 0),
@@ -26,7 +30,7 @@ for M, K, N, geglu in shapes:
         continue
     rows = 2 * N if geglu else N
     x, b, res = rnd(M, K), rnd(rows), rnd(M, N)
-    ncopy = max(1, min(32, int(600e6 // (rows * K * 2))))
+    ncopy = max(1, min(32, int(600e6 // (rows * K * x.element_size()))))
     ws = [rnd(rows, K) * K ** -0.5 for _ in range(ncopy)]
     it = [0]
 

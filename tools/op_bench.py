@@ -12,7 +12,7 @@ from tools.devlib import use_variant  # noqa: E402
 use_variant(os.environ.get("ST_VARIANT"))      # ST_VARIANT=<name>: a tools/_variants/<name> build (developer A/B runs)
 
 dev = torch.device("cuda:0")
-dt = torch.bfloat16
+dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[os.environ.get("ST_BENCH_DTYPE", "bf16")]      # fp32 = the strict mode (split operands)
 
 
 def timeit(fn, iters=20, warm=3):
