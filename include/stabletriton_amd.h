@@ -51,7 +51,7 @@ int         st_abi_version(void);          /* bumps on any signature or contract
                                               producer; 9: st_ln_linear_xattn; 10: ST_F16 accepted by every entry point
                                               that takes a dtype, st_ln_linear_xattn takes a dtype; 11: fp8 plan with
                                               delayed per-tensor scaling - st_linear_emit8, st_linear_fp8x, st_fp8_update_scales; 12: readers of a channel
-                                              concatenation that is never written - st_group_norm_from_stats_cat, st_conv1x1_cat; 13: ST_F32S split fp32 matrix operands, st_split_f32, st_arm_split_output) */
+                                              concatenation that is never written - st_group_norm_from_stats_cat, st_conv1x1_cat; 13: ST_F32S split fp32 matrix operands, st_split_f32, st_arm_split_output, st_attention_split) */
 const char* st_last_error(void);           /* host string, thread-local     */
 
 /* GroupNorm (+SiLU).  Replaces reference group_norm_wrapper
@@ -274,6 +274,11 @@ int st_split_f32(const float* x, void* xs, long rows, int K, long ldx, void* str
  * launch, no second read of y.  That launch disarms it.  An armed launch that cannot emit (16-bit element type, other
  * shape) is rejected.  Thread-local, like st_last_error(). */
 int st_arm_split_output(void* ys, long rows, int cols);
+/* st_attention (ST_F32) whose K and V the producer left as split images: ks / vs point at row 0, first column of head 0, of the
+ * image(s) (rows = B * S), k_cols / v_cols = values per image row (the fused q|k|v projection's image has 3 * H * D);
+ * q (B, T, ldq) and out (B, T, ldo) plain fp32.  Same results as st_attention, which splits K / V tiles itself. */
+int st_attention_split(const void* q, const void* ks, const void* vs, void* out, int B, int T, int S, int H, int D,
+                       long ldq, long k_cols, long v_cols, long ldo, float scale, void* stream);
 
 /* The reference's own timestep operator, elementwise (optimizers/replace_timesteps.py:33-40 ->
  * kernels/timestep.py:13-45): x is fp32 of shape (..., half), n elements in all;

@@ -48,6 +48,7 @@ SIGNATURES = {
     "st_fp8_update_scales": (_i, [_p, _p, _p, _i, _f, _p]),
     "st_split_f32": (_i, [_p, _p, _l, _i, _l, _p]),
     "st_arm_split_output": (_i, [_p, _l, _i]),
+    "st_attention_split": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _l, _l, _f, _p]),
 }
 
 _lib = None

@@ -361,7 +361,7 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
 
 // fp32 ("strict" parity mode): attention_f32.hip - split operands on the 16-bit matrix pipe, fp32 softmax
 int attention_f32_launch(const float* q, const float* k, const float* v, float* out, int B, int T, int S, int H,
-                         long ldq, long ldk, long ldv, long ldo, float scale, void* out_split, hipStream_t st);
+                         long ldq, long ldk, long ldv, long ldo, float scale, void* out_split, bool presplit, hipStream_t st);
 
 template <typename E>
 static int attention16_launch(const void* q, const void* k, const void* v, void* out, int B, int T, int S, int H,
@@ -417,6 +417,24 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
     if (int e = st_take_split_arm("attention", (long)B * T, H * D, dtype == ST_F32, &out_split)) return e;
     if (dtype == ST_BF16) return attention16_launch<bf16>(q, k, v, out, B, T, S, H, ldq, ldk, ldv, ldo, scale, st);
     if (dtype == ST_F16) return attention16_launch<f16>(q, k, v, out, B, T, S, H, ldq, ldk, ldv, ldo, scale, st);
-    if (dtype == ST_F32) return attention_f32_launch((const float*)q, (const float*)k, (const float*)v, (float*)out, B, T, S, H, ldq, ldk, ldv, ldo, scale, out_split, st);
+    if (dtype == ST_F32) return attention_f32_launch((const float*)q, (const float*)k, (const float*)v, (float*)out, B, T, S, H, ldq, ldk, ldv, ldo, scale, out_split, false, st);
     return st_fail("attention: unsupported dtype %d", dtype);
+}
+
+// st_attention for fp32 tensors whose K and V a producer left as split images (the q|k|v projection of self-attention:
+// st_arm_split_output): ks / vs = first byte of head 0's columns in row 0 of the image(s), k_cols / v_cols = values per image
+// row; q, out and everything else as st_attention with ST_F32.  Same arithmetic as st_attention (which splits K / V itself,
+// tile by tile): the same bits.
+extern "C" int st_attention_split(const void* q, const void* ks, const void* vs, void* out, int B, int T, int S, int H, int D,
+                                  long ldq, long k_cols, long v_cols, long ldo, float scale, void* stream) {
+    ST_REQUIRE(q && ks && vs && out, "attention_split: null pointer");
+    ST_REQUIRE(B > 0 && T > 0 && S > 0 && H > 0, "attention_split: bad shape B=%d T=%d S=%d H=%d", B, T, S, H);
+    ST_REQUIRE(D == ATT_D, "attention_split: head_dim %d not supported (only %d)", D, ATT_D);
+    ST_REQUIRE(H <= 65535 && B <= 65535, "attention_split: too many heads/batches for one launch");
+    ST_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && k_cols % 32 == 0 && v_cols % 32 == 0, "attention_split: strides must keep 16-byte alignment, image rows whole segments");
+    ST_REQUIRE(((uintptr_t)q | (uintptr_t)out) % 16 == 0 && ((uintptr_t)ks | (uintptr_t)vs) % 128 == 0, "attention_split: q / out 16-byte, image columns segment (128-byte) aligned");
+    void* out_split = nullptr;
+    if (int e = st_take_split_arm("attention_split", (long)B * T, H * D, true, &out_split)) return e;
+    return attention_f32_launch((const float*)q, (const float*)ks, (const float*)vs, (float*)out, B, T, S, H, ldq, k_cols, v_cols, ldo, scale, out_split, true,
+                                (hipStream_t)stream);
 }

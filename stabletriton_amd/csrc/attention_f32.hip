@@ -26,10 +26,13 @@ namespace {
 constexpr int SP_PLANE = ATT_KV * 128;            // one half-precision image of a 64-key tile: 64 rows of 64 halves
 constexpr int SP_BUF = 4 * SP_PLANE;              // K hi, K lo, V hi, V lo
 
-template <int NW>
+// PRE: K and V arrive as split images already (the q|k|v projection left them, st_arm_split_output): K / V point at the image
+// rows' first byte of head 0's columns, ldk / ldv are the images' row lengths in VALUES (4 bytes each); the tile staging
+// then moves halves (two 16-byte loads, two LDS stores per piece) and converts nothing.
+template <int NW, bool PRE>
 __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                              const float* __restrict__ V, float* __restrict__ O, int T, int S,
-                                                             long ldq, long ldk, long ldv, long ldo, float scale_log2e, char* __restrict__ Os, int Cs) {
+                                                             long ldq, long ldk, long ldv, long ldo, float scale_log2e, char* __restrict__ Os, int Cs, int H) {
     // Os != nullptr: also the split image of the output, rows = (batch, token), Cs = H * 64 values per row (the consumer is the
     // output projection: st_arm_split_output)
     constexpr int NT = NW * 64;
@@ -39,11 +42,25 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const float* __rest
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int head = blockIdx.y, b = blockIdx.z;
+    // 1-D grid, XCD-aware (as attn32i_kernel): consecutive block ids go round-robin to the eight XCDs, so XCD c takes the c-th
+    // contiguous eighth of the (batch, head, query block) list and the query blocks of one head - they all stream that head's K
+    // and V, 2 MB of split halves at 4096 keys - meet in ONE L2.  In (x, y, z) grid order every XCD streamed every head: the
+    // 4096-token launch re-read 1.3 GB through the fabric, 5.4 TB/s, and was bound by exactly that.
+    int head, b, xblk;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int xq = nb >> 3, xr = nb & 7, xcd = bid & 7;
+        const int w = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+        const int gx = (T + 16 * NW - 1) / (16 * NW);
+        const int hb = w / gx;
+        xblk = w - hb * gx;
+        b = hb / H;
+        head = hb - b * H;
+    }
     const int c16 = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * NW * 16 + wave * 16;
+    const int q0 = xblk * NW * 16 + wave * 16;
     const int qrow = min(q0 + c16, T - 1);
-    const float* Kb = K + (size_t)b * S * ldk + (size_t)head * ATT_D;
+    const float* Kb = K + (size_t)b * S * ldk + (size_t)head * ATT_D;      // (PRE: 64 values of an image row = 256 bytes = [hi32 | lo32 | hi32 | lo32])
     const float* Vb = V + (size_t)b * S * ldv + (size_t)head * ATT_D;
 
     // ---- Q fragments: d = 32 ks + 8 g .. + 7 of this lane's query row ------------------------------------------------
@@ -72,9 +89,15 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const float* __rest
             const int row = id >> 3, c = id & 7;
             const int key = kt * ATT_KV + row;
             const bool isv = i >= TASKS / 2;
-            const float* src = (isv ? Vb + (size_t)min(key, S - 1) * ldv : Kb + (size_t)min(key, S - 1) * ldk) + c * 8;
-            stg[i][0] = *reinterpret_cast<const f32x4*>(src);
-            stg[i][1] = *reinterpret_cast<const f32x4*>(src + 4);
+            const float* rowp = isv ? Vb + (size_t)min(key, S - 1) * ldv : Kb + (size_t)min(key, S - 1) * ldk;
+            if constexpr (PRE) {          // chunk c = values 8c .. 8c+7: hi halves at byte (c / 4) * 128 + (c % 4) * 16 of the row's 256, lo halves 64 further
+                const char* src = reinterpret_cast<const char*>(rowp) + (c >> 2) * 128 + (c & 3) * 16;
+                stg[i][0] = *reinterpret_cast<const f32x4*>(src);
+                stg[i][1] = *reinterpret_cast<const f32x4*>(src + 64);
+            } else {
+                stg[i][0] = *reinterpret_cast<const f32x4*>(rowp + c * 8);
+                stg[i][1] = *reinterpret_cast<const f32x4*>(rowp + c * 8 + 4);
+            }
             if (key >= S) { stg[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; stg[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }      // masked keys: finite zeros
         }
     };
@@ -85,9 +108,13 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const float* __rest
             const int id = t + (i % (TASKS / 2)) * NT;
             const int row = id >> 3, c = id & 7;
             const bool isv = i >= TASKS / 2;
-            const float v[8] = {stg[i][0][0], stg[i][0][1], stg[i][0][2], stg[i][0][3], stg[i][1][0], stg[i][1][1], stg[i][1][2], stg[i][1][3]};
             f16x8 hi, lo;
-            split8(v, hi, lo);
+            if constexpr (PRE) {
+                hi = __builtin_bit_cast(f16x8, stg[i][0]); lo = __builtin_bit_cast(f16x8, stg[i][1]);
+            } else {
+                const float v[8] = {stg[i][0][0], stg[i][0][1], stg[i][0][2], stg[i][0][3], stg[i][1][0], stg[i][1][1], stg[i][1][2], stg[i][1][3]};
+                split8(v, hi, lo);
+            }
             char* dst = base + (isv ? 2 * SP_PLANE : 0) + row * 128 + ((c ^ (isv ? swz_v16(row) : swz_k16(row))) << 4);
             *reinterpret_cast<f16x8*>(dst) = hi;
             *reinterpret_cast<f16x8*>(dst + SP_PLANE) = lo;
@@ -119,22 +146,43 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const float* __rest
         const char* vb_ = kb_ + 2 * SP_PLANE;
         if (kt + 1 < nkt) load_tile(kt + 1);       // in flight under this tile's matrix work
 
+        // ---- fragment reads first, matrix work behind them: left to itself hipcc reads four K fragments, waits for them, multiplies,
+        //      reads the next four ... and every group of six MFMAs starts with a full LDS round trip (a third of the trip).  All
+        //      sixteen K fragments and the V^T fragments of the first key half go out here, the second half's behind the scores.
+        f16x8 kh[4][2], kl[4][2], vh[4], vl[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            kh[kb][0] = *reinterpret_cast<const f16x8*>(kb_ + kb * 2048 + k_off0); kl[kb][0] = *reinterpret_cast<const f16x8*>(kb_ + SP_PLANE + kb * 2048 + k_off0);
+            kh[kb][1] = *reinterpret_cast<const f16x8*>(kb_ + kb * 2048 + k_off1); kl[kb][1] = *reinterpret_cast<const f16x8*>(kb_ + SP_PLANE + kb * 2048 + k_off1);
+        }
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            vh[db] = v_frag<f16>(vb_, v_off[db], v_off[db] + 2048);
+            vl[db] = v_frag<f16>(vb_ + SP_PLANE, v_off[db], v_off[db] + 2048);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- scores of this tile: s[kb][r] = key 16 kb + 4 g + r against this lane's query row, minus m_ref
         f32x4 s[4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            const f16x8 kh0 = *reinterpret_cast<const f16x8*>(kb_ + kb * 2048 + k_off0), kl0 = *reinterpret_cast<const f16x8*>(kb_ + SP_PLANE + kb * 2048 + k_off0);
-            const f16x8 kh1 = *reinterpret_cast<const f16x8*>(kb_ + kb * 2048 + k_off1), kl1 = *reinterpret_cast<const f16x8*>(kb_ + SP_PLANE + kb * 2048 + k_off1);
             f32x4 mn = {-m_ref, -m_ref, -m_ref, -m_ref}, cr = {0.f, 0.f, 0.f, 0.f};
-            mn = AttMma<f16>::m16(kh0, qh[0], mn);
-            cr = AttMma<f16>::m16(kh0, ql[0], cr);
-            cr = AttMma<f16>::m16(kl0, qh[0], cr);
-            mn = AttMma<f16>::m16(kh1, qh[1], mn);
-            cr = AttMma<f16>::m16(kh1, ql[1], cr);
-            cr = AttMma<f16>::m16(kl1, qh[1], cr);
+            mn = AttMma<f16>::m16(kh[kb][0], qh[0], mn);
+            cr = AttMma<f16>::m16(kh[kb][0], ql[0], cr);
+            cr = AttMma<f16>::m16(kl[kb][0], qh[0], cr);
+            mn = AttMma<f16>::m16(kh[kb][1], qh[1], mn);
+            cr = AttMma<f16>::m16(kh[kb][1], ql[1], cr);
+            cr = AttMma<f16>::m16(kl[kb][1], qh[1], cr);
 #pragma unroll
             for (int r = 0; r < 4; ++r) s[kb][r] = __builtin_fmaf(cr[r], 1.0f / ST_SPLIT_SCALE, mn[r]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        f16x8 vh1[4], vl1[4];                       // V^T of the second key half: in flight under the softmax
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            vh1[db] = v_frag<f16>(vb_, v_off[db] + 4096, v_off[db] + 4096 + 2048);
+            vl1[db] = v_frag<f16>(vb_ + SP_PLANE, v_off[db] + 4096, v_off[db] + 4096 + 2048);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if ((kt + 1) * ATT_KV > S) {                // mask the tail keys (only the last tile has any)
             const int kbase = kt * ATT_KV + 4 * g;
 #pragma unroll
@@ -174,11 +222,10 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const float* __rest
             split8(pv, ph, pl);
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                const f16x8 vh = v_frag<f16>(vb_, v_off[db] + kp * 4096, v_off[db] + kp * 4096 + 2048);
-                const f16x8 vl = v_frag<f16>(vb_ + SP_PLANE, v_off[db] + kp * 4096, v_off[db] + kp * 4096 + 2048);
-                om[db] = AttMma<f16>::m16(vh, ph, om[db]);
-                oc[db] = AttMma<f16>::m16(vh, pl, oc[db]);
-                oc[db] = AttMma<f16>::m16(vl, ph, oc[db]);
+                const f16x8 a = kp ? vh1[db] : vh[db], c = kp ? vl1[db] : vl[db];
+                om[db] = AttMma<f16>::m16(a, ph, om[db]);
+                oc[db] = AttMma<f16>::m16(a, pl, oc[db]);
+                oc[db] = AttMma<f16>::m16(c, ph, oc[db]);
             }
             om[4] = AttMma<f16>::m16(ones, ph, om[4]);
             oc[4] = AttMma<f16>::m16(ones, pl, oc[4]);
@@ -210,11 +257,12 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const float* __rest
 
 // (entry: st_attention with dtype ST_F32, attention.hip)
 int attention_f32_launch(const float* q, const float* k, const float* v, float* out, int B, int T, int S, int H,
-                         long ldq, long ldk, long ldv, long ldo, float scale, void* out_split, hipStream_t st) {
+                         long ldq, long ldk, long ldv, long ldo, float scale, void* out_split, bool presplit, hipStream_t st) {
     const float c = scale * 1.4426950408889634f;
     constexpr size_t LDS = 2 * SP_BUF;
     // 64 query rows per block: the 1024-token level at batch 1 is 320 blocks, two per CU (LDS 64 KiB each)
-    auto kfn = attn_split_kernel<4>;
-    hipLaunchKernelGGL(kfn, dim3(cdiv(T, 64), H, B), dim3(256), LDS, st, q, k, v, out, T, S, ldq, ldk, ldv, ldo, c, (char*)out_split, H * ATT_D);
+    auto kfn = presplit ? attn_split_kernel<4, true> : attn_split_kernel<4, false>;
+    ST_REQUIRE((long)cdiv(T, 64) * H * B < (1L << 31), "attention: too many blocks");
+    hipLaunchKernelGGL(kfn, dim3(cdiv(T, 64) * H * B), dim3(256), LDS, st, q, k, v, out, T, S, ldq, ldk, ldv, ldo, c, (char*)out_split, H * ATT_D, H);
     return st_check_launch("attention");
 }

@@ -149,6 +149,9 @@ class ExecContext:
 
     def __exit__(self, *exc):
         _tls.stack.pop()
+        # the notes on producers' split images (strict mode) hold output tensors: none may outlive the pass that made them
+        # (under a graph capture they belong to the graph's private pool)
+        self.__dict__.pop("recent_splits", None)
         return False
 
 
@@ -330,9 +333,23 @@ def _note_split(out: torch.Tensor, img: Optional[torch.Tensor], rows: int, cols:
     if img is None:
         return
     ctx = current_context(out.device)
+    if ctx.plan is None and torch.cuda.is_current_stream_capturing():
+        return          # the shared default context is never left: it must not keep tensors of somebody's graph pool alive
     lst = ctx.__dict__.setdefault("recent_splits", [])
     lst.append((out, out.data_ptr(), rows, cols, img))
     del lst[:-_RECENT_SPLITS]
+
+
+def _image_columns(t: torch.Tensor, rows: int, ld: int):
+    """(image, first column) when `t` - rows x C values at row stride ld - is a column range of a recently noted output
+    whose rows are ld values long (the K / V slices of the fused q|k|v projection), else None."""
+    if not EMIT_SPLIT:
+        return None
+    for ent in reversed(current_context(t.device).__dict__.get("recent_splits", ())):
+        off = t.data_ptr() - ent[1]
+        if ent[2] == rows and ent[3] == ld and 0 <= off < 4 * ld and off % 128 == 0:
+            return ent[4], off // 4
+    return None
 
 
 def _split_of(x: torch.Tensor, rows: int, cols: int, ld: int) -> torch.Tensor:
@@ -630,7 +647,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
 
 def ln_linear(x: torch.Tensor, stats: "RowStats", w_folded: torch.Tensor, c: torch.Tensor, d: torch.Tensor, eps: float, *,
-              geglu: bool = False) -> torch.Tensor:
+              geglu: bool = False, emit_split: bool = False) -> torch.Tensor:
     """LayerNorm(x) @ W.T (+bias) as one GEMM on gamma-folded weights with a rank-1 correction
     (see st_ln_linear in the header); `w_folded`, `c`, `d` come from `fold_layer_norm`, `stats`
     from the `linear(..., emit_stats=True)` call that produced x."""
@@ -648,7 +665,9 @@ def ln_linear(x: torch.Tensor, stats: "RowStats", w_folded: torch.Tensor, c: tor
         w_folded, c = _split_weight(w_folded, want_rowsum=True)
         x2, lda, code = _split_of(x2, M, K, lda), K, _C.ST_F32S
     nxt_p, nxt_b = _next_weights(w_folded)
-    img = _arm_split(out, M, N) if (code == _C.ST_F32S and geglu) else None
+    # strict mode: the GEGLU projection's output (read by ff.net.2) and, on request, the q|k|v projection's (its K and V columns
+    # are attention operands) leave their split images
+    img = _arm_split(out, M, N) if (code == _C.ST_F32S and (geglu or emit_split)) else None
     _C.check(lib.st_ln_linear(x2.data_ptr(), stats.buf.data_ptr(), stats.chunks, w_folded.data_ptr(),
                     c.data_ptr(), d.data_ptr(), out.data_ptr(), M, N, K,
                     lda, N, float(eps), _C.EPI_GEGLU if geglu else 0, code, nxt_p, nxt_b, _C.stream_ptr()), "ln_linear")
@@ -885,9 +904,15 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int,
     k_, ldk = tok(k)
     v_, ldv = tok(v)
     out = torch.empty((B, T, Cc), dtype=q.dtype, device=q.device)
+    ki = _image_columns(k_, B * S, ldk) if q.dtype == torch.float32 else None      # strict mode: K / V columns of a producer's split image
+    vi = _image_columns(v_, B * S, ldv) if ki is not None else None
     img = _arm_split(out, B * T, Cc)              # strict mode: the output projection reads the split image
-    _C.check(lib.st_attention(q_.data_ptr(), k_.data_ptr(), v_.data_ptr(), out.data_ptr(), B, T, S, num_heads, D,
-                              ldq, ldk, ldv, Cc, float(scale), _C.dtype_code(q.dtype), _C.stream_ptr()), "attention")
+    if ki is not None and vi is not None and D == 64:
+        _C.check(lib.st_attention_split(q_.data_ptr(), ki[0].data_ptr() + 4 * ki[1], vi[0].data_ptr() + 4 * vi[1], out.data_ptr(), B, T, S, num_heads, D,
+                                        ldq, ki[0].shape[1], vi[0].shape[1], Cc, float(scale), _C.stream_ptr()), "attention_split")
+    else:
+        _C.check(lib.st_attention(q_.data_ptr(), k_.data_ptr(), v_.data_ptr(), out.data_ptr(), B, T, S, num_heads, D,
+                                  ldq, ldk, ldv, Cc, float(scale), _C.dtype_code(q.dtype), _C.stream_ptr()), "attention")
     _note_split(out, img, B * T, Cc)
     return out
 

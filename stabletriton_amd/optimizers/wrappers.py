@@ -165,7 +165,8 @@ def ln_linear_wrapper(v: torch.Tensor, stats, layernorm: nn.LayerNorm, linears, 
     (or the GEGLU of the single projection), as ONE GEMM: the LayerNorm never runs as its own
     kernel.  `stats` are the row partials the GEMM that produced `v` emitted (emit_stats=True)."""
     wf, c, d = _ln_fold(layernorm, tuple(linears))
-    return ops.ln_linear(v, stats, wf, c, d, layernorm.eps, geglu=geglu)
+    # (three projections = q|k|v of self-attention: in strict mode the K / V columns meet the attention kernel as split images)
+    return ops.ln_linear(v, stats, wf, c, d, layernorm.eps, geglu=geglu, emit_split=len(linears) == 3)
 
 
 torch.fx.wrap("ln_linear_wrapper")

@@ -212,3 +212,35 @@ def test_armed_image_is_never_left_unwritten(gpu):
     _C.check(lib.st_arm_split_output(img.data_ptr(), 32, 64), "arm")
     with pytest.raises(ops.BackendError, match="armed split image"):
         ops.linear(x.float(), w.float(), None)       # fp32, but another shape
+
+
+def test_attention_takes_k_and_v_from_the_projection_image(gpu):
+    """Self-attention in strict mode: the fused q|k|v projection leaves the split image of its output, the attention launch
+    reads its K and V columns from it (st_attention_split) - the same bits as the launch that splits K / V tiles itself."""
+    from stabletriton_amd import _C
+    B, T, H = 2, 320, 5
+    C = H * 64
+    with ops.ExecContext() as ctx:
+        x0 = rnd("qkv.x", (B, T, C)).to(gpu) * 1.5
+        eye = torch.eye(C, device=gpu)
+        x, st = ops.linear(x0, eye, None, emit_stats=True)
+        g, be = (rnd("qkv.g", (C,)) * 0.2 + 1).to(gpu), (rnd("qkv.be", (C,)) * 0.2).to(gpu)
+        w = (rnd("qkv.w", (3 * C, C)) * C ** -0.5).to(gpu)
+        wf, c, d = ops.fold_layer_norm(g, be, w, None)
+        qkv = ops.ln_linear(x, st, wf, c, d, 1e-5, emit_split=True)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        called = []
+        lib = _C.load()
+        real = lib.st_attention_split
+        lib.st_attention_split = lambda *a: (called.append(1), real(*a))[1]
+        try:
+            o = ops.attention(q, k, v, H, 0.125)
+        finally:
+            lib.st_attention_split = real
+        assert called, "attention did not find the projection's image"
+        ops.EMIT_SPLIT = False
+        try:
+            o2 = ops.attention(q, k, v, H, 0.125)
+        finally:
+            ops.EMIT_SPLIT = True
+        assert torch.equal(o, o2)

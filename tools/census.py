@@ -36,6 +36,12 @@ def _attention(a):
             f"B={B} T={T} S={S} H={H}")
 
 
+def _attention_split(a):
+    B, T, S, H, D = a[4], a[5], a[6], a[7], a[8]
+    return ("attention_self" if S == T else "attention_cross", 4.0 * B * H * T * S * D, float((2 * B * T + 2 * B * S) * H * D * 4),
+            f"B={B} T={T} S={S} H={H} k/v split images")
+
+
 def _conv2d(a):
     N, Hin, Win, Cin, Cout, R, S, stride, pad, ups, epi, dt = a[6:18]
     He, We = (2 * Hin, 2 * Win) if ups else (Hin, Win)
@@ -109,7 +115,7 @@ def _split_f32(a):
     return "split_f32", 0.0, 8.0 * rows * K, f"rows={rows} K={K}"
 
 
-DECODERS = {"st_split_f32": _split_f32, "st_linear": _linear, "st_linear_emit8": _linear_emit8, "st_linear_fp8x": _linear_fp8x, "st_ln_linear": _ln_linear, "st_ln_linear_xattn": _ln_linear_xattn, "st_attention": _attention,
+DECODERS = {"st_split_f32": _split_f32, "st_attention_split": _attention_split, "st_linear": _linear, "st_linear_emit8": _linear_emit8, "st_linear_fp8x": _linear_fp8x, "st_ln_linear": _ln_linear, "st_ln_linear_xattn": _ln_linear_xattn, "st_attention": _attention,
             "st_conv2d": _conv2d, "st_group_norm": _group_norm, "st_group_norm_from_stats": _group_norm_from_stats,
             "st_group_norm_from_stats_cat": _group_norm_from_stats_cat, "st_conv1x1_cat": _conv1x1_cat,
             "st_layer_norm": _layer_norm, "st_geglu": _geglu, "st_quantize_fp8": _quantize_fp8,

@@ -8,7 +8,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stabletriton_amd import ops  # noqa: E402
 
-dev, dt = torch.device("cuda:0"), torch.bfloat16
+dev = torch.device("cuda:0")
+dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[os.environ.get("ST_BENCH_DTYPE", "bf16")]      # fp32 = the strict mode
 REPS = 5
 
 
