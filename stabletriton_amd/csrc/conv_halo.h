@@ -1,4 +1,5 @@
-// GEMM-shaped operators: conv3x3 / stride 1 with the input patch resident in LDS (16-bit elements) and its host side.
+// GEMM-shaped operators: conv3x3 / stride 1 with the input patch resident in LDS (16-bit elements; split fp32 operands of the
+// strict mode: channel slices of 32, three MFMAs per product, two accumulator sets) and its host side.
 // Internal to csrc/.
 #pragma once
 #include "gemm_dma.h"
@@ -19,11 +20,13 @@
 // (oy, ox) tap (r, s) reads input ((oy + r - 1) >> 1, (ox + s - 1) >> 1), zero outside).
 template <typename T, int WL2, int TH, int BN, int WGM, int WGN, bool UPS = false>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
-    static_assert(sizeof(T) == 2, "16-bit elements (bf16 / f16)");
+    static_assert(sizeof(T) == 2 || is_split<T>(), "16-bit elements (bf16 / f16) or split fp32 operands");
     constexpr int W = 1 << WL2, BM = TH * W, NW = WGM * WGN;
+    constexpr int VEC = 16 / (int)sizeof(T);                         // elements per 16-byte chunk
+    typedef typename OutT<T>::type TO;                               // element type of y, bias, residual (split operands: fp32)
     static_assert(NW == 8 && BM % (16 * WGM) == 0 && BN % (16 * WGN) == 0 && W >= 16, "tile / wave layout");
     static_assert(!UPS || TH % 2 == 0, "upsampled tiles start on an even output row");
-    constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 16, TN = WTN / 16, KB = 64;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 16, TN = WTN / 16, KB = 128 / (int)sizeof(T);      // a channel slice = 128 bytes per pixel
     constexpr int WI = UPS ? W / 2 : W;                              // input image width
     constexpr int PROWS = UPS ? TH / 2 + 2 : TH + 2;                 // input rows the tile touches
     constexpr int PWD = WI + 2, PPX = PROWS * PWD;                   // patch row pitch and pixel count
@@ -70,14 +73,14 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
         const int y = iy_base + py, x = px - 1;
         const bool ok = pp < PPX && y >= 0 && y < Hh && x >= 0 && x < WI;
         const int lc = (lane & 7) ^ (pp & 7);
-        pa_ptr[e] = ok ? Xb + ((size_t)y * WI + x) * p.Cin + lc * 8 : nullptr;
+        pa_ptr[e] = ok ? Xb + ((size_t)y * WI + x) * p.Cin + lc * VEC : nullptr;
     }
     const T* pb_ptr[B_IT];
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
         const int row = (wave + j * NW) * 8 + lr;
         const int wrow = n0 + row;
-        pb_ptr[j] = (wrow < p.N && wave + j * NW < B_PIECES) ? Wp + (size_t)wrow * p.K + ((lane & 7) ^ lr) * 8 : nullptr;
+        pb_ptr[j] = (wrow < p.N && wave + j * NW < B_PIECES) ? Wp + (size_t)wrow * p.K + ((lane & 7) ^ lr) * VEC : nullptr;
     }
     auto issue_patch = [&](int cs, int e) {         // piece e of this wave, channel slice cs (cs >= cs_hi: dummy)
         const int pidx = e * NW + wave;
@@ -108,10 +111,14 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
     for (int j = 0; j < TN; ++j) rowb[j] = wn * WTN + j * 16 + r16;
 
     f32x4 acc[TM][TN];
+    f32x4 corr[is_split<T>() ? TM : 1][is_split<T>() ? TN : 1];      // split operands: the cross products, in units of 2^-11
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) {
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (is_split<T>()) corr[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 
     // ---- prologue: the first patch, the first two weight tiles ------------------------------------------
 #pragma unroll
@@ -146,11 +153,22 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
             for (int i = 0; i < TM; ++i) { ppl[i] = pp0[i]; asm volatile("" : "+v"(ppl[i])); }
 #pragma unroll
             for (int j = 0; j < TN; ++j) { rbl[j] = rowb[j]; asm volatile("" : "+v"(rbl[j])); }
-            // both 32-wide K halves are read up front: the second half's LDS latency hides under the first half's MFMAs
-            Frag fa[2][TM], fb[2][TN];
+            // every fragment of the trip is read up front (16-bit: both 32-wide K halves, the second half's LDS latency hides
+            // under the first half's MFMAs; split operands: the hi chunk q and the lo chunk q + 4 of the one 32-wide step)
+            constexpr int NG_ = frag2<T>() ? 1 : 2;
+            Frag fa[NG_][TM], fb[NG_][TN];
+            auto rd = [&](const char* base, int row, int g) -> Frag {
+                if constexpr (frag2<T>()) {
+                    const u32x4 lo = *reinterpret_cast<const u32x4*>(base + row * 128 + ((q ^ (row & 7)) << 4));
+                    const u32x4 hi = *reinterpret_cast<const u32x4*>(base + row * 128 + (((q + 4) ^ (row & 7)) << 4));
+                    return Frag{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                } else {
+                    const int c = 4 * g + q;
+                    return *reinterpret_cast<const Frag*>(base + row * 128 + ((c ^ (row & 7)) << 4));
+                }
+            };
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int c = 4 * g + q;
+            for (int g = 0; g < NG_; ++g) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     int pp;
@@ -160,23 +178,25 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
                     } else {
                         pp = ppl[i] + r * PWD + s_;
                     }
-                    fa[g][i] = *reinterpret_cast<const Frag*>(patch + pp * 128 + ((c ^ (pp & 7)) << 4));
+                    fa[g][i] = rd(patch, pp, g);
                 }
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    fb[g][j] = *reinterpret_cast<const Frag*>(wt + rbl[j] * 128 + ((c ^ (rbl[j] & 7)) << 4));
+                for (int j = 0; j < TN; ++j) fb[g][j] = rd(wt, rbl[j], g);
             }
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
+            for (int g = 0; g < NG_; ++g)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], fb[g][j], fa[g][i]);
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (is_split<T>()) Mma<T>::run2(acc[i][j], corr[i][j], fb[g][j], fa[g][i]);
+                        else Mma<T>::run(acc[i][j], fb[g][j], fa[g][i]);
+                    }
             // pin the emitted order: DMAs, then every fragment read, then the MFMAs -
             // left alone hipcc sinks each read to just before its first use and waits lgkmcnt(0) a dozen times per trip
             __builtin_amdgcn_sched_group_barrier(0x020, n_p + B_IT, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NG_ * TM * TN * mfma_per_frag<T>(), 0);
             __builtin_amdgcn_sched_barrier(0);
             // the next trip's weight tile (issued one trip ago, before this trip's DMAs) must have landed - and
             // with it, in issue order, every patch piece of the next slice
@@ -190,6 +210,14 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
     }
     wait_vmcnt<0>();                                 // no LDS-DMA may outlive the workgroup's LDS allocation
     __builtin_amdgcn_s_barrier();
+    if constexpr (is_split<T>()) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = __builtin_fmaf(corr[i][j][e], ST_SPLIT_INV, acc[i][j][e]);
+    }
     if (p.splitk > 1) {
         if (!splitk_combine<TM, TN, BM * BN>(p, acc, tw, split, lds, t, wave, lane)) {
             unsigned int sink = 0;                   // this block is done: its slice of the next weights, then exit
@@ -198,16 +226,16 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs p) {
             return;
         }
     }
-    staged_epilogue<T, BM, BN, WGM, WGN, TM, TN, false, 2 * PB + STAGES * WT_B, true>(p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds,
+    staged_epilogue<TO, BM, BN, WGM, WGN, TM, TN, false, 2 * PB + STAGES * WT_B, true>(p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds,
                                                                                       nullptr);
 }
 
 // ---- host side of conv_halo_kernel --------------------------------------------------------------
-static inline bool conv_halo_applies(const GemmArgs& a, int R, int ups) {
+static inline bool conv_halo_applies(const GemmArgs& a, int R, int ups, int kb = 64) {      // kb: channels per slice (64 16-bit, 32 split fp32)
     static const bool off = dev_env_int("ST_CONV_HALO", 1) == 0;
     if (off) return false;
     if (R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1) return false;
-    if (a.Cin % 64 != 0 || a.N % 4 != 0 || a.N < 64) return false;
+    if (a.Cin % kb != 0 || a.N % 4 != 0 || a.N < 64) return false;
     if (ups) {           // output 64 or 128 pixels wide, tiles of 256 output pixels
         if (a.Wout != 2 * a.Win || a.Hout != 2 * a.Hin || (a.Wout != 64 && a.Wout != 128)) return false;
         return a.Hout % (256 / a.Wout) == 0 && a.M % 256 == 0;
@@ -238,9 +266,10 @@ static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
     GemmArgs b = a;
     // 256 pixels x 128 channels at the 32- and 64-pixel levels; one 128-pixel row x 160 channels at the 128-pixel level
     const bool ups = a.ups != 0;
-    const int bm = (!ups && a.Win == 128) ? 128 : 256, bn = (ups || a.Win == 128) ? 160 : 128;
+    constexpr bool SP = is_split<T>();            // split operands carry two accumulator sets: 64-channel tiles (wave tiles 64 x 32 / 32 x 32)
+    const int bm = (!ups && a.Win == 128) ? 128 : 256, bn = SP ? 64 : ((ups || a.Win == 128) ? 160 : 128);
     const int tiles = (a.M / bm) * cdiv(a.N, bn);
-    const int ncs = a.Cin / 64;
+    const int ncs = a.Cin / (128 / (int)sizeof(T));
     // K split over channel slices: aim at one round of ~240 blocks; a slice keeps at least two channel slices
     int sk = 1;
     if (a.partial && tiles < 200) {
@@ -262,10 +291,18 @@ static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
     b.stats_chunks = cdiv(a.N, bn);
     if (a.row_stats && b.stats_chunks > a.stats_capacity) return st_fail("conv2d: row_stats buffer holds %d chunks, %d needed", a.stats_capacity, b.stats_chunks);
     if (a.stats_chunks_out) *a.stats_chunks_out = a.row_stats ? b.stats_chunks : 0;
-    if (ups && a.Wout == 64) conv_halo_go<T, 6, 4, 160, 4, 2, true>(b, tiles * sk, st);
-    else if (ups) conv_halo_go<T, 7, 2, 160, 4, 2, true>(b, tiles * sk, st);
-    else if (a.Win == 32) conv_halo_go<T, 5, 8, 128, 4, 2>(b, tiles * sk, st);
-    else if (a.Win == 64) conv_halo_go<T, 6, 4, 128, 4, 2>(b, tiles * sk, st);
-    else conv_halo_go<T, 7, 1, 160, 4, 2>(b, tiles * sk, st);
+    if constexpr (SP) {
+        if (ups && a.Wout == 64) conv_halo_go<T, 6, 4, 64, 4, 2, true>(b, tiles * sk, st);
+        else if (ups) conv_halo_go<T, 7, 2, 64, 4, 2, true>(b, tiles * sk, st);
+        else if (a.Win == 32) conv_halo_go<T, 5, 8, 64, 4, 2>(b, tiles * sk, st);
+        else if (a.Win == 64) conv_halo_go<T, 6, 4, 64, 4, 2>(b, tiles * sk, st);
+        else conv_halo_go<T, 7, 1, 64, 4, 2>(b, tiles * sk, st);
+    } else {
+        if (ups && a.Wout == 64) conv_halo_go<T, 6, 4, 160, 4, 2, true>(b, tiles * sk, st);
+        else if (ups) conv_halo_go<T, 7, 2, 160, 4, 2, true>(b, tiles * sk, st);
+        else if (a.Win == 32) conv_halo_go<T, 5, 8, 128, 4, 2>(b, tiles * sk, st);
+        else if (a.Win == 64) conv_halo_go<T, 6, 4, 128, 4, 2>(b, tiles * sk, st);
+        else conv_halo_go<T, 7, 1, 160, 4, 2>(b, tiles * sk, st);
+    }
     return st_check_launch("conv2d(halo)");
 }

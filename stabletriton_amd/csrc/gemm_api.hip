@@ -219,7 +219,7 @@ extern "C" int st_conv2d(const void* x, const void* W, const void* bias, const v
         ST_REQUIRE(((uintptr_t)x | (uintptr_t)W | (uintptr_t)y) % 16 == 0, "conv2d: pointers must be 16-byte aligned");
         if (dtype == ST_BF16) return gemm_conv_bf16(a, R, upsample2x, st);
         if (dtype == ST_F16) return gemm_conv_f16(a, R, upsample2x, st);
-        if (dtype == ST_F32S) return gemm_conv_f32s(a, st);
+        if (dtype == ST_F32S) return gemm_conv_f32s(a, R, upsample2x, st);
         return gemm_conv_f32(a, st);
     }
     ST_REQUIRE(dtype != ST_F32S, "conv2d: split fp32 operands need Cin=%d to be a multiple of 32 (thin inputs take plain ST_F32)", Cin);
@@ -258,6 +258,6 @@ extern "C" int st_conv1x1_cat(const void* x0, int C0, const void* x1, int C1, co
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ST_BF16) return gemm_conv_bf16(a, 1, 0, st);
     if (dtype == ST_F16) return gemm_conv_f16(a, 1, 0, st);
-    if (dtype == ST_F32S) return gemm_conv_f32s(a, st);
+    if (dtype == ST_F32S) return gemm_conv_f32s(a, 1, 0, st);
     return gemm_conv_f32(a, st);
 }

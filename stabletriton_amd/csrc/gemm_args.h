@@ -298,5 +298,5 @@ int gemm_xattn_f16(const GemmArgs& a, hipStream_t st);
 int gemm_conv_bf16(const GemmArgs& a, int R, int ups, hipStream_t st);      // halo kernel when it applies, else implicit GEMM
 int gemm_conv_f16(const GemmArgs& a, int R, int ups, hipStream_t st);
 int gemm_conv_f32(const GemmArgs& a, hipStream_t st);
-int gemm_conv_f32s(const GemmArgs& a, hipStream_t st);
+int gemm_conv_f32s(const GemmArgs& a, int R, int ups, hipStream_t st);
 int conv_thin_run(const GemmArgs& a, int R, int dtype, hipStream_t st);
