@@ -266,8 +266,12 @@ static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
     GemmArgs b = a;
     // 256 pixels x 128 channels at the 32- and 64-pixel levels; one 128-pixel row x 160 channels at the 128-pixel level
     const bool ups = a.ups != 0;
-    constexpr bool SP = is_split<T>();            // split operands carry two accumulator sets: 64-channel tiles (wave tiles 64 x 32 / 32 x 32)
-    const int bm = (!ups && a.Win == 128) ? 128 : 256, bn = SP ? 64 : ((ups || a.Win == 128) ? 160 : 128);
+    // split operands carry two accumulator sets (256 registers at 128 channels per tile): 128-channel tiles where the output is
+    // at most 64 pixels wide and the channels divide (640 @ 64 x 64: 124 -> 89 us), 64-channel tiles elsewhere (320 @ 128 x 128:
+    // 109 against 134 us)
+    constexpr bool SP = is_split<T>();
+    const bool sp128 = SP && a.N % 128 == 0 && a.Wout <= 64;
+    const int bm = (!ups && a.Win == 128) ? 128 : 256, bn = SP ? (sp128 ? 128 : 64) : ((ups || a.Win == 128) ? 160 : 128);
     const int tiles = (a.M / bm) * cdiv(a.N, bn);
     const int ncs = a.Cin / (128 / (int)sizeof(T));
     // K split over channel slices: aim at one round of ~240 blocks; a slice keeps at least two channel slices
@@ -292,10 +296,10 @@ static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
     if (a.row_stats && b.stats_chunks > a.stats_capacity) return st_fail("conv2d: row_stats buffer holds %d chunks, %d needed", a.stats_capacity, b.stats_chunks);
     if (a.stats_chunks_out) *a.stats_chunks_out = a.row_stats ? b.stats_chunks : 0;
     if constexpr (SP) {
-        if (ups && a.Wout == 64) conv_halo_go<T, 6, 4, 64, 4, 2, true>(b, tiles * sk, st);
+        if (ups && a.Wout == 64) { if (sp128) conv_halo_go<T, 6, 4, 128, 4, 2, true>(b, tiles * sk, st); else conv_halo_go<T, 6, 4, 64, 4, 2, true>(b, tiles * sk, st); }
         else if (ups) conv_halo_go<T, 7, 2, 64, 4, 2, true>(b, tiles * sk, st);
-        else if (a.Win == 32) conv_halo_go<T, 5, 8, 64, 4, 2>(b, tiles * sk, st);
-        else if (a.Win == 64) conv_halo_go<T, 6, 4, 64, 4, 2>(b, tiles * sk, st);
+        else if (a.Win == 32) { if (sp128) conv_halo_go<T, 5, 8, 128, 4, 2>(b, tiles * sk, st); else conv_halo_go<T, 5, 8, 64, 4, 2>(b, tiles * sk, st); }
+        else if (a.Win == 64) { if (sp128) conv_halo_go<T, 6, 4, 128, 4, 2>(b, tiles * sk, st); else conv_halo_go<T, 6, 4, 64, 4, 2>(b, tiles * sk, st); }
         else conv_halo_go<T, 7, 1, 64, 4, 2>(b, tiles * sk, st);
     } else {
         if (ups && a.Wout == 64) conv_halo_go<T, 6, 4, 160, 4, 2, true>(b, tiles * sk, st);
