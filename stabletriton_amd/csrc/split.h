@@ -14,7 +14,12 @@
 
 static constexpr float ST_SPLIT_SCALE = 2048.0f;      // 2^11
 
+// (x passes through an empty asm: an opaque, ROUNDED fp32 value.  Where x is itself a product just computed - the GEGLU
+//  epilogue's value * gelu(gate) - hipcc otherwise folds `x - hi` into fma(value, gelu, -hi), the residual of the UNROUNDED
+//  product, and the image a producer leaves would differ in the last bits of lo from st_split_f32 of the fp32 value it stored;
+//  HIP's __fsub_rn is a plain subtraction and does not stop that.)
 __device__ __forceinline__ void split_f32(float x, f16& hi, f16& lo) {
+    asm volatile("" : "+v"(x));
     hi = (f16)x;
     lo = (f16)((x - (float)hi) * ST_SPLIT_SCALE);
 }

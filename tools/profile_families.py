@@ -41,6 +41,8 @@ def family(name: str):
         return "geglu"
     if "euler_kernel" in name or "step_advance" in name or "timestep" in name:
         return "loop"
+    if "split_rows_kernel" in name:                # strict mode: the few matrix operands no producer could leave as a split image
+        return "split_f32"
     if "spin_kernel" in name:
         return None
     return "torch_glue"

@@ -1,7 +1,7 @@
 # The round's bench lines (run on the GPU box from the repo root; outputs under gpurun_out/$R/final): the default call with
 # its cpu_baseline and side measurements, the driver's call, the other batch sizes, fp16, the fp8 mode, the two-rank gloo
-# rehearsal of the multi-GPU path on one card.  tools/round_profiles.sh collects the rocprofv3 / PMC set.
-R=${R:-r3}
+# rehearsal of the multi-GPU path on one card; since round 4 the strict (fp32 / split operands) mode and the refiner img2img lines of config #5.  tools/round_profiles.sh collects the rocprofv3 / PMC set.
+R=${R:-r4}
 set -x
 mkdir -p gpurun_out/$R/final && cd $GRAFT_REPO_ROOT
 o=gpurun_out/$R/final
@@ -14,6 +14,10 @@ python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extras --batch 4 >
 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extras --batch 4 --dtype fp16 > $o/bench_b4_fp16.json 2>/dev/null
 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extras --batch 4 --fp8 > $o/bench_b4_fp8.json 2>/dev/null
 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extras --fp8 > $o/bench_b1_fp8.json 2>/dev/null
+python bench.py --steps 50 --warmup 10 --mode step --no-cpu-baseline --no-extras --dtype fp32 > $o/bench_strict_fp32.json 2>/dev/null
+python bench.py --steps 50 --warmup 10 --mode step --no-cpu-baseline --no-extras --dtype fp32 --batch 4 > $o/bench_strict_fp32_b4.json 2>/dev/null
+python bench.py --model refiner --img2img 0.3 --steps 30 --warmup 15 --no-cpu-baseline --no-extras > $o/bench_refiner_img2img.json 2>/dev/null
+python bench.py --model refiner --img2img 0.3 --steps 30 --warmup 15 --no-cpu-baseline --no-extras --fp8 > $o/bench_refiner_img2img_fp8.json 2>/dev/null
 python bench.py --gpus 2 --same-device --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $o/bench_2rank_gloo_same_device.json 2> $o/bench_2rank.err
 for f in $o/bench_*.json; do python - "$f" <<'PY'
 import json,sys
