@@ -139,7 +139,12 @@ class DiffusersUNet(_HoistedUNet):
             if val is not None:
                 raise NotImplementedError(f"{name} is not part of the SDXL-base UNet path")
         if cross_attention_kwargs:
-            raise NotImplementedError("cross_attention_kwargs (attention processors / LoRA scale) are not supported: merge LoRA weights in place")
+            # a pipeline with merged LoRA weights still passes {"scale": s}: scale 1 changes nothing once the weights are merged
+            # (`refresh_weights()` after the merge); anything else would need attention processors the compiled graph has not
+            extra = {k: v for k, v in cross_attention_kwargs.items() if not (k == "scale" and float(v) == 1.0)}
+            if extra:
+                raise NotImplementedError(f"cross_attention_kwargs {sorted(extra)} (attention processors / a LoRA scale other than 1) are not "
+                                          "supported: merge the LoRA weights in place at the scale wanted and call refresh_weights()")
         cd = self.compute_dtype
         cond = {"text_embeds": added_cond_kwargs["text_embeds"].to(cd), "time_ids": added_cond_kwargs["time_ids"].to(cd)}
         out = self._run(sample, timestep, encoder_hidden_states, cond)

@@ -147,6 +147,10 @@ def test_diffusers_hook_rejects_unsupported(gpu):
         unet(xg["latent"], 10.0, encoder_hidden_states=xg["encoder_hidden_states"], added_cond_kwargs=cond, timestep_cond=xg["text_embeds"])
     out = unet(xg["latent"], 10.0, encoder_hidden_states=xg["encoder_hidden_states"], added_cond_kwargs=cond, return_dict=True)
     assert out.sample.shape == xg["latent"].shape
+    # what a pipeline with MERGED LoRA weights passes: scale 1 is the identity and is accepted (the reference swallows every
+    # keyword, unet_pt.py:469-471; here only the one that changes nothing)
+    same = unet(xg["latent"], 10.0, encoder_hidden_states=xg["encoder_hidden_states"], added_cond_kwargs=cond, cross_attention_kwargs={"scale": 1.0})[0]
+    assert torch.equal(same, out.sample)
 
 
 def test_weight_update_is_seen_by_captured_graphs(gpu):
