@@ -96,7 +96,7 @@ def _cpu_backend(monkeypatch):
         return (y, "stats") if emit_stats else y
     monkeypatch.setattr(ops, "linear", linear)
 
-    def ln_linear(x, stats, wf, c, d, eps, *, geglu=False):
+    def ln_linear(x, stats, wf, c, d, eps, *, geglu=False, emit_split=False):
         assert stats == "stats"
         mean = x.mean(-1, keepdim=True)
         rstd = (x.var(-1, unbiased=False, keepdim=True) + eps).rsqrt()

@@ -89,3 +89,31 @@ def test_f3_first_step_matches_reference_trace(sdxl_state_dict):
         eps = orc.unet_forward(sdxl_state_dict, lat * float(tables.in_scale()[0]), torch.tensor(float(tables.timesteps[0])),
                                x["encoder_hidden_states"], x["text_embeds"], x["time_ids"])
     assert abs(float(eps.abs().mean()) - float(g["eps_abs_mean"][0])) < 1e-6
+
+
+def test_storage_emulation_is_the_identity_when_off_and_rounds_when_on():
+    """`unet_oracle.storage(dtype)` (what the bf16 / fp16 gates of the GPU tests are derived from, oracle/make_rounded_golden.py):
+    off, the oracle is untouched (the pin above stays bit-exact); on, every operator result is a value of that type."""
+    import torch
+    from oracle import unet_oracle as orc
+    from stabletriton_amd import synth
+    from stabletriton_amd.unet import TINY, UNet2DConditionModel
+    m = UNet2DConditionModel(TINY).eval().requires_grad_(False)
+    synth.fill_module_(m, 0)
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    x = synth.denoise_inputs(1, 16, 1234, cross_dim=TINY.cross_dim, pooled_dim=TINY.pooled_dim)
+    args = (x["latent"], torch.tensor(321.0), x["encoder_hidden_states"], x["text_embeds"], x["time_ids"])
+    with torch.no_grad():
+        plain = orc.unet_forward(sd, *args)
+        with orc.storage(None):
+            assert torch.equal(orc.unet_forward(sd, *args), plain)
+        for dt, lo, hi in ((torch.bfloat16, 1e-4, 0.2), (torch.float16, 1e-5, 0.05)):
+            with orc.storage(dt):
+                r = orc.unet_forward(orc.rounded_state_dict(sd, dt), *args)
+            assert torch.equal(r, r.to(dt).float())                      # the output itself is a value of the storage type
+            err = float((r - plain).abs().max())
+            assert lo < err < hi, (dt, err)
+        assert torch.equal(orc.unet_forward(sd, *args), plain)           # and the switch is off again
+    for name in ("f1_unet_step_latent64", "f3_euler50_latent64", "f3_euler50_latent128", "f3_cfg50_latent64"):
+        g = golden(name + "_rounded")
+        assert float(g["fp16_rms"]) < float(g["bf16_rms"]) and float(g["bf16_max_abs"]) > 0          # the fixtures the gates read
