@@ -272,7 +272,8 @@ int st_split_f32(const float* x, void* xs, long rows, int K, long ldx, void* str
  * write, beside its output y of (rows, cols) values (cols % 32 == 0; rows = M, pixels or (batch, token)), the split image
  * of y to ys (rows * cols * 4 bytes), which a following GEMM-shaped launch takes as its ST_F32S operand: no st_split_f32
  * launch, no second read of y.  That launch disarms it.  An armed launch that cannot emit (16-bit element type, other
- * shape) is rejected.  Thread-local, like st_last_error(). */
+ * shape) is rejected.  ys == NULL disarms: a caller whose armed launch failed its own argument checks (which run before the arm
+ * is looked at) disarms before it frees the image, so that no later launch can write to it.  Thread-local, like st_last_error(). */
 int st_arm_split_output(void* ys, long rows, int cols);
 /* st_attention (ST_F32) whose K and V the producer left as split images: ks / vs point at row 0, first column of head 0, of the
  * image(s) (rows = B * S), k_cols / v_cols = values per image row (the fused q|k|v projection's image has 3 * H * D);

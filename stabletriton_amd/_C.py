@@ -84,7 +84,9 @@ def load(path=None):
 
 def check(status: int, what: str) -> None:
     if status != 0:
-        msg = load().st_last_error().decode(errors="replace")
+        lib = load()
+        msg = lib.st_last_error().decode(errors="replace")
+        lib.st_arm_split_output(None, 0, 0)      # a rejected launch may not have reached the arm: no later launch may write the image the caller is about to drop
         raise BackendError(f"{what}: {msg}")
 
 

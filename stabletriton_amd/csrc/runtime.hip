@@ -8,7 +8,8 @@ static thread_local char g_err[512] = "";
 static thread_local struct { void* p; long rows; int cols; } g_split_arm = {nullptr, 0, 0};
 
 extern "C" int st_arm_split_output(void* ys, long rows, int cols) {
-    ST_REQUIRE(ys && rows > 0 && cols > 0 && cols % 32 == 0 && (uintptr_t)ys % 16 == 0, "arm_split_output: (rows, cols) image with cols %% 32 == 0 expected");
+    if (!ys) { g_split_arm = {nullptr, 0, 0}; return 0; }      // disarm (a caller whose armed launch was rejected before it looked at the arm)
+    ST_REQUIRE(rows > 0 && cols > 0 && cols % 32 == 0 && (uintptr_t)ys % 16 == 0, "arm_split_output: (rows, cols) image with cols %% 32 == 0 expected");
     g_split_arm = {ys, rows, cols};
     return 0;
 }

@@ -212,6 +212,16 @@ def test_armed_image_is_never_left_unwritten(gpu):
     _C.check(lib.st_arm_split_output(img.data_ptr(), 32, 64), "arm")
     with pytest.raises(ops.BackendError, match="armed split image"):
         ops.linear(x.float(), w.float(), None)       # fp32, but another shape
+    # a launch rejected by its own argument checks never looks at the arm: the host disarms, so the image (about to be dropped)
+    # cannot be written by whatever emitting launch comes next
+    _C.check(lib.st_arm_split_output(img.data_ptr(), 64, 64), "arm")
+    img.fill_(7.0)
+    with pytest.raises(ops.BackendError):
+        _C.check(lib.st_linear(x.float().data_ptr(), w.float().data_ptr(), None, None, None, img.data_ptr(), 64, 64, 0, 64, 64, 0, 0, 0, 0, None, 0,
+                               None, 0, None, None, 0, None, None, 0, _C.stream_ptr()), "linear")          # K = 0: rejected up front
+    ops.linear(x.float(), w.float(), None)           # same shape as the arm: must not find it
+    torch.cuda.synchronize()
+    assert bool((img == 7.0).all())
 
 
 def test_attention_takes_k_and_v_from_the_projection_image(gpu):

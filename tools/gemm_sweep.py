@@ -18,7 +18,8 @@ force.argtypes, force.restype = [ctypes.c_int, ctypes.c_int], None
 NAMES = {7: "64x64_W8", 8: "128x64_W8", 9: "128x128_W8", 10: "64x128_W8", 19: "256x128_W8", 23: "128x320_W8",
          25: "64x320_W8", 27: "128x80_W8", 28: "128x160_W8", 100: "256x256_8P", 101: "256x160_8P"}
 if os.environ.get("ST_BENCH_DTYPE") == "fp32":      # split operands: two accumulator sets, no eight-phase kernel
-    NAMES = {7: "64x64_W8", 8: "128x64_W8", 9: "128x128_W8", 10: "64x128_W8", 27: "128x80_W8", 25: "64x320_W8", 13: "128x128_W8_S3", 21: "128x64_W8_S3", 22: "64x128_W8_S3"}
+    NAMES = {7: "64x64_W8", 8: "128x64_W8", 9: "128x128_W8", 10: "64x128_W8", 27: "128x80_W8", 13: "128x128_W8_S3", 21: "128x64_W8_S3", 22: "64x128_W8_S3",
+             15: "64x128_W8_U2", 16: "128x64_W8_U2", 17: "64x64_W8_U2", 20: "128x128_W8_S2"}
 ctx = ops.ExecContext()      # (fp32 / strict mode: the split images of the weights are kept per context, as in a compiled module)
 ctx.__enter__()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
