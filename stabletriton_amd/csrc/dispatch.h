@@ -156,10 +156,13 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
         double best = 1e30;
         for (const Cand& c : cands) {
             if (frag2<T>() && c.bn == 320) continue;                     // fp8 / split fragments are 32 bytes: the 320-wide wave tiles spill
-            if (is_split<T>() && (c.cfg == CFG_256x128_W8 || c.cfg == CFG_128x160_W8)) continue;      // two accumulator sets: wave tiles of at most 8 x 16 x 16
+            if (is_split<T>() && c.cfg == CFG_256x128_W8) continue;      // two accumulator sets: wave tiles of at most 10 x 16 x 16 (128 x 160 as 4 x 2 waves)
             if ((a.epi & ST_EPI_GEGLU) && c.bn % 32 != 0) continue;      // GEGLU: the value / gate halves of a tile are whole accumulator tiles (BN = 80 is not)
             const long nt = tiles(c.bm, c.bn);
-            const double trip = c.trip_us * (CONV ? 1.6 : 1.0);
+            // (split operands: the 128 x 160 tile runs as 4 x 2 waves with ten accumulator tiles in each of two sets; measured
+            //  0.8 us per trip - it wins the GEGLU projection of the 1280 level by whole rounds, 512 tiles against 640, 104 -> 93 us,
+            //  and loses q|k|v to 128 x 128 at its fitted 16-bit constant)
+            const double trip = (is_split<T>() && c.cfg == CFG_128x160_W8 ? 0.8 : c.trip_us) * (CONV ? 1.6 : 1.0);
             for (int k_ : sks) {
                 if (k_ > 1 && (!can_split || nk / k_ < 4 || nt > 16384)) break;
                 const double slab_mb = (double)k_ * nt * c.bm * c.bn * 4.0 / 1e6;
@@ -240,7 +243,11 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
             case CFG_128x320_W8: launch_dma<T, 128, 320, 4, 2, 2, 1, CONV>(b, st); break;
             case CFG_64x320_W8: launch_dma<T, 64, 320, 2, 4, 3, 1, CONV>(b, st); break;
             case CFG_128x80_W8: launch_dma<T, 128, 80, 8, 1, 4, 1, CONV>(b, st); break;
-            case CFG_128x160_W8: launch_dma<T, 128, 160, 8, 1, 4, 1, CONV>(b, st); break;
+            case CFG_128x160_W8:
+                // (split operands: 4 x 2 waves of 32 x 80 - ten accumulator tiles in each of the two sets - instead of 8 x 1 of 16 x 160)
+                if constexpr (is_split<T>()) launch_dma<T, 128, 160, 4, 2, 4, 1, CONV>(b, st);
+                else launch_dma<T, 128, 160, 8, 1, 4, 1, CONV>(b, st);
+                break;
 #ifdef ST_DEV_CONFIGS
             case CFG_64x80_W4: launch_dma<T, 64, 80, 4, 1, 6, 1, CONV>(b, st); break;
             case CFG_128x256_W8: launch_dma<T, 128, 256, 4, 2, 3, 1, CONV>(b, st); break;       // tile/pipeline variants kept for A/B sweeps (tools/op_bench.py with ST_GEMM_FORCE)
