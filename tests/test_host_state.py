@@ -117,3 +117,38 @@ def test_rccl_self_check_fails_a_partial_communicator(tmp_path):
     assert bench.rccl_self_check({"nranks_logged": None, "transports": [], "channels": 0}, 8, ranks_seen=8) is None
     assert "4" in bench.rccl_self_check({"nranks_logged": 8, "transports": [], "channels": 0}, 8, ranks_seen=4)
     assert "4" in bench.rccl_self_check({"nranks_logged": 4, "transports": [], "channels": 0}, 8, ranks_seen=8)
+
+
+def test_split_image_notes_follow_the_output_memory_and_die_with_the_pass():
+    """Host side of st_arm_split_output (strict mode): a producer's split image is found by the consumer through the OUTPUT's
+    memory (address, rows, row length), column ranges of it (the K / V slices of a fused q|k|v output) by their offset, the
+    list keeps only the last few outputs, and nothing outlives the execution context's pass.  CPU tensors: no launch involved."""
+    import torch
+    from stabletriton_amd import ops
+    ops_ = ops
+    with ops_.ExecContext() as ctx:
+        outs = [torch.zeros(8, 96) for _ in range(ops_._RECENT_SPLITS + 2)]
+        imgs = [torch.full((8, 96), float(i)) for i in range(len(outs))]
+        for o, im in zip(outs, imgs):
+            ops_._note_split(o, im, 8, 96)
+        assert len(ctx.recent_splits) == ops_._RECENT_SPLITS                      # the oldest notes are gone ...
+        assert ops_._image_columns(outs[0], 8, 96) is None
+        last = outs[-1]
+        got = ops_._image_columns(last, 8, 96)                                   # ... the newest is found by address
+        assert got is not None and got[0] is imgs[-1] and got[1] == 0
+        mid = last[:, 32:64]                                                     # a column range: same rows, same row stride
+        got = ops_._image_columns(mid, 8, 96)
+        assert got is not None and got[0] is imgs[-1] and got[1] == 32
+        assert ops_._image_columns(last[:, 16:48], 8, 96) is None                # not on a 32-value segment
+        assert ops_._image_columns(last[:4], 4, 96) is None                      # other row count: not this matrix
+        assert ops_._image_columns(torch.zeros(8, 96), 8, 96) is None            # another tensor
+        held = [e[0] for e in ctx.recent_splits]
+        assert all(any(h is o for o in outs) for h in held)                      # the notes HOLD the outputs (their memory cannot be recycled)
+    assert not hasattr(ctx, "recent_splits")                                     # the pass is over: nothing is kept
+    before, ops_.EMIT_SPLIT = ops_.EMIT_SPLIT, False
+    try:
+        with ops_.ExecContext() as ctx:
+            ops_._note_split(outs[0], imgs[0], 8, 96)
+            assert ops_._image_columns(outs[0], 8, 96) is None                   # switched off: consumers split for themselves
+    finally:
+        ops_.EMIT_SPLIT = before

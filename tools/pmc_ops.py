@@ -17,6 +17,7 @@ import json
 import os
 import sys
 
+ES2 = 2.0 if os.environ.get("ST_BENCH_DTYPE", "bf16") == "fp32" else 1.0      # algorithmic bytes below are written for 2-byte elements: x2 for the strict mode's fp32 tensors
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "pmc_ops")
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
@@ -31,7 +32,7 @@ def meta(name):
                    "attn_cross_1024": (1024, 77, 20), "attn_self_1024_b4": (1024, 1024, 20), "attn_self_4096_b4": (4096, 4096, 10)}[name]
         fam = "attention_self" if "self" in name else "attention_cross"
         cnt = {"attn_self_4096": 10, "attn_self_1024": 60, "attn_cross_4096": 10, "attn_cross_1024": 60}.get(name, 0)
-        return fam, 4.0 * b * H * T * S * 64, 2.0 * b * H * 64 * (2 * T + 2 * S), cnt
+        return fam, 4.0 * b * H * T * S * 64, ES2 * 2.0 * b * H * 64 * (2 * T + 2 * S), cnt
     if name.startswith("xattn"):
         M, C = (int(v) for v in p[1].split("x"))
         H = C // 64
@@ -42,15 +43,15 @@ def meta(name):
         g = 2 if "g" in (p[2] if len(p) > 2 else "") else 1
         cnt = {"linear_1024x1280x5120_lng": 60, "linear_1024x5120x1280": 60, "linear_1024x1280x1280": 192, "linear_1024x1280x3840_ln": 60,
                "linear_4096x640x640": 40, "linear_4096x640x2560_lng": 10, "linear_4096x2560x640": 10}.get(name, 0)
-        return "linear", 2.0 * M * K * N * g, 2.0 * (M * K + g * N * K + M * N), cnt
+        return "linear", 2.0 * M * K * N * g, ES2 * 2.0 * (M * K + g * N * K + M * N), cnt
     if name.startswith("conv"):
         C, H = int(p[1]), int(p[2])
         cnt = {"conv_1280_32": 10, "conv_640_64": 6, "conv_320_128": 7}.get(name, 0)
-        return "conv2d", 2.0 * H * H * C * C * 9, 2.0 * (2 * H * H * C + 9 * C * C), cnt
+        return "conv2d", 2.0 * H * H * C * C * 9, ES2 * 2.0 * (2 * H * H * C + 9 * C * C), cnt
     if name.startswith("gn"):
         C, H = int(p[1]), int(p[2])
         cnt = {"gn_320_128": 8, "gn_1280_32": 16, "gn_640_64": 11}.get(name, 0)
-        return "group_norm", 0.0, 2.0 * 2 * H * H * C, cnt
+        return "group_norm", 0.0, ES2 * 2.0 * 2 * H * H * C, cnt
     return "calib", 0.0, 0.0, 0
 
 
