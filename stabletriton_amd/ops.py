@@ -315,7 +315,9 @@ def split_usable(dtype: torch.dtype, K: int) -> bool:
 # partials -> the LayerNorm-folded projection) leaves the image beside its output and notes it here; the consumer finds it by
 # the output's memory (address, rows, row length) and skips its own st_split_f32 launch.  An entry HOLDS the output tensor,
 # so its memory cannot be handed to another tensor while the note exists, and the list keeps only the last few outputs
-# (consumers follow their producers within a handful of launches): a miss costs one launch, never a wrong operand.
+# (consumers follow their producers within a handful of launches), and a note is only honoured while the output's version
+# counter is the one it had when the image was written (an in-place update in between: the consumer splits for itself): a
+# miss costs one launch, never a wrong operand.
 _RECENT_SPLITS = 6
 EMIT_SPLIT = True             # False: every consumer splits its own input (tests compare)
 
@@ -336,7 +338,7 @@ def _note_split(out: torch.Tensor, img: Optional[torch.Tensor], rows: int, cols:
     if ctx.plan is None and torch.cuda.is_current_stream_capturing():
         return          # the shared default context is never left: it must not keep tensors of somebody's graph pool alive
     lst = ctx.__dict__.setdefault("recent_splits", [])
-    lst.append((out, out.data_ptr(), rows, cols, img))
+    lst.append((out, out.data_ptr(), rows, cols, img, out._version))      # (the version: an in-place update of the output later makes the image stale)
     del lst[:-_RECENT_SPLITS]
 
 
@@ -347,7 +349,7 @@ def _image_columns(t: torch.Tensor, rows: int, ld: int):
         return None
     for ent in reversed(current_context(t.device).__dict__.get("recent_splits", ())):
         off = t.data_ptr() - ent[1]
-        if ent[2] == rows and ent[3] == ld and 0 <= off < 4 * ld and off % 128 == 0:
+        if ent[2] == rows and ent[3] == ld and 0 <= off < 4 * ld and off % 128 == 0 and t._version == ent[5]:
             return ent[4], off // 4
     return None
 
@@ -356,7 +358,7 @@ def _split_of(x: torch.Tensor, rows: int, cols: int, ld: int) -> torch.Tensor:
     """The split image of the (rows, cols) fp32 matrix at x's address (row stride ld): a producer's, if one was noted, else made now."""
     if ld == cols:
         for ent in reversed(current_context(x.device).__dict__.get("recent_splits", ())):
-            if ent[1] == x.data_ptr() and ent[2] == rows and ent[3] == cols:
+            if ent[1] == x.data_ptr() and ent[2] == rows and ent[3] == cols and x._version == ent[5]:
                 return ent[4]
     x2 = x if (x.dim() == 2 and x.shape[1] == cols) else x.as_strided((rows, cols), (ld, 1))
     return split_rows(x2).s

@@ -142,6 +142,8 @@ def test_split_image_notes_follow_the_output_memory_and_die_with_the_pass():
         assert ops_._image_columns(last[:, 16:48], 8, 96) is None                # not on a 32-value segment
         assert ops_._image_columns(last[:4], 4, 96) is None                      # other row count: not this matrix
         assert ops_._image_columns(torch.zeros(8, 96), 8, 96) is None            # another tensor
+        last.add_(1.0)                                                           # an in-place update: the image is stale, the note no longer honoured
+        assert ops_._image_columns(last, 8, 96) is None and ops_._image_columns(last[:, 32:64], 8, 96) is None
         held = [e[0] for e in ctx.recent_splits]
         assert all(any(h is o for o in outs) for h in held)                      # the notes HOLD the outputs (their memory cannot be recycled)
     assert not hasattr(ctx, "recent_splits")                                     # the pass is over: nothing is kept

@@ -199,6 +199,20 @@ def test_producers_leave_the_split_image_of_what_they_store(gpu):
         assert torch.equal(co, co2)
 
 
+def test_in_place_update_of_a_producer_output_is_not_missed(gpu):
+    """A note on a producer's image is honoured only while the output is what the producer wrote: an in-place update bumps the
+    tensor's version counter and the consumer splits the updated values itself."""
+    with ops.ExecContext():
+        xi = rnd("ip.x", (1, 64, 16, 16)).to(gpu).contiguous(memory_format=torch.channels_last)
+        gw, gb = (rnd("ip.gw", (64,)) * 0.2 + 1).to(gpu), rnd("ip.gb", (64,)).to(gpu)
+        wc = (rnd("ip.wc", (64, 64, 3, 3)) * (64 * 9) ** -0.5).to(gpu).contiguous(memory_format=torch.channels_last)
+        y = ops.group_norm(xi, 32, gw, gb, 1e-5, True)
+        y.mul_(3.0)
+        got = ops.conv2d(y, wc, None, 1, 1)
+        want = ops.conv2d(y.clone(memory_format=torch.preserve_format), wc, None, 1, 1)
+        assert torch.equal(got, want)
+
+
 def test_armed_image_is_never_left_unwritten(gpu):
     """An armed launch that cannot emit is rejected (and disarms): a consumer can never pick up an image nobody wrote."""
     from stabletriton_amd import _C
