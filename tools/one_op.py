@@ -17,6 +17,8 @@ def rnd(*shape):
     return (torch.rand(*shape, device=dev, dtype=torch.float32) * 2 - 1).to(dt)
 
 
+_ctx = ops.ExecContext()      # (strict mode: the split images of the weights are kept per context, as in a compiled module)
+_ctx.__enter__()
 kind, a = sys.argv[1], sys.argv[2:]
 if kind == "linear":
     M, K, N = (int(v) for v in a[:3])
