@@ -39,6 +39,11 @@ KERNEL = {"split_f32": "split_rows_kernel (strict mode: fp32 -> split fp16 pair 
           "group_norm": "gn_cols_finalize+gn_apply_nhwc (statistics from the producer's epilogue; standalone: gn_stats_nhwc+gn_finalize+gn_apply_nhwc)", "layer_norm": "ln_kernel", "geglu": "geglu_kernel"}
 
 
+STRICT_KERNEL = {"linear": "gemm_dma_kernel<fsp, CONV=false> (split fp32 operands: 3 x v_mfma_f32_16x16x32_f16 per 32 k)",
+                 "conv2d": "conv_halo_kernel<fsp> / gemm_dma_kernel<fsp, CONV=true> (split operands)",
+                 "attention_self": "attn_split_kernel<4, PRE>", "attention_cross": "attn_split_kernel<4, false>"}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,13 +196,13 @@ def census(loop):
     return fam, step_ms, pair_ms, glue_ms
 
 
-def committed_profile(name):
+def committed_profile(name, tag=""):
     """Per-family numbers of the committed rocprofv3 run of this command (profiles/rNN_families.json, written by
     tools/profile_families.py from the kernel-trace CSV) and the PMC traffic (profiles/rNN_traffic.json), or None."""
     import glob
     out = {}
     try:
-        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_families.json")))[-1]
+        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]{tag}_families.json")))[-1]      # (the bf16 headline's: not r04_strict_* / r04_refiner_*)
         rec = json.load(open(latest)).get("families", {}).get(name)
         if rec:
             out = {"source": os.path.relpath(latest, ROOT), "ms_per_step": rec["ms_per_step"], "avg_launch_us": rec["avg_launch_us"],
@@ -206,7 +211,7 @@ def committed_profile(name):
         pass
     traffic = mfma_busy = None
     try:
-        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]{tag}_traffic.json")))[-1]
         t = json.load(open(latest))
         traffic = t.get(f"{name}_bytes_per_launch")
         mfma_busy = t.get(f"{name}_mfma_busy")
@@ -215,7 +220,7 @@ def committed_profile(name):
     return out, traffic, mfma_busy
 
 
-def roofline_of(name, f, boundary_ms, committed=True):
+def roofline_of(name, f, boundary_ms, committed=True, tag=""):
     """`boundary_ms`: what one launch costs in the replayed graph on top of its kernel-only time - the dependent-launch
     boundary in front of every kernel, which rocprofv3 attributes to the kernel (its trace shows back-to-back kernels with
     no gaps) and an event-bracketed launch does not see: (graph step time - census kernel-only time) / launches."""
@@ -226,7 +231,7 @@ def roofline_of(name, f, boundary_ms, committed=True):
         ach, peak, unit = f["flops"] / sec / 1e12, (PEAK_FP8_TFLOPS if name == "linear_fp8" else PEAK_BF16_TFLOPS), "TFLOP/s"
     else:
         ach, peak, unit = f["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s"
-    prof, traffic, mfma_busy = committed_profile(name) if committed else ({}, None, None)
+    prof, traffic, mfma_busy = committed_profile(name, tag) if committed else ({}, None, None)
     r = {"kernel": KERNEL[name], "op": name, "bound": BOUND[name], "achieved": round(ach, 2), "peak": peak, "unit": unit,
          "frac": round(ach / peak, 4), "traffic": traffic, "launches_per_step": f["launches"],
          "avg_launch_us": round(ms * 1e3 / f["launches"], 2), "ms_per_step": round(ms, 3),
@@ -317,12 +322,9 @@ def extras(args, model, gm, loop, mode, dtype, dev, n_sched, cond, x):
             fam, census_ms, _, _ = census(lp)
             n_launch = sum(f["launches"] for f in fam.values())
             boundary = max(ms - census_ms, 0.0) / n_launch
-            roofs = {k: roofline_of(k, v, boundary, committed=False) for k, v in fam.items()}
-            names = {"linear": "gemm_dma_kernel<fsp, CONV=false> (split fp32 operands: 3 x v_mfma_f32_16x16x32_f16 per 32 k)",
-                     "conv2d": "gemm_dma_kernel<fsp, CONV=true> (implicit GEMM on split operands)",
-                     "attention_self": "attn_split_kernel<4>", "attention_cross": "attn_split_kernel<4>"}
+            roofs = {k: roofline_of(k, v, boundary, tag="_strict") for k, v in fam.items()}      # (rocprof / counters: profiles/rNN_strict_*)
             for k, r in roofs.items():
-                r["kernel"] = names.get(k, r["kernel"])
+                r["kernel"] = STRICT_KERNEL.get(k, r["kernel"])
             rec["roofline"] = roofs[max(fam, key=lambda k: fam[k]["ms"])]
             rec["kernels"] = [{k: r[k] for k in ("op", "bound", "achieved", "unit", "frac", "launches_per_step", "ms_per_step", "kernel_only_ms")}
                               for r in sorted(roofs.values(), key=lambda r: -r["ms_per_step"])]
@@ -541,7 +543,14 @@ def main():
                 fam, census_ms, marker_ms, glue_ms = census(loop)
                 n_launch = sum(f["launches"] for f in fam.values())
                 boundary_ms = max(ms_per_step - census_ms, 0.0) / n_launch
-                roofs = {k: roofline_of(k, v, boundary_ms) for k, v in fam.items()}
+                # the committed rocprofv3 / counter summaries beside the live numbers: those of the same command (bf16 headline,
+                # strict mode, refiner img2img fp8); other variants of the run carry none
+                tag = "_strict" if dtype == torch.float32 else ("_refiner" if (args.model == "refiner" and args.fp8) else "")
+                plain = tag or (args.model == "base" and not args.fp8 and args.batch == 1 and dtype == torch.bfloat16)
+                roofs = {k: roofline_of(k, v, boundary_ms, committed=bool(plain), tag=tag) for k, v in fam.items()}
+                if dtype == torch.float32:
+                    for k, r in roofs.items():
+                        r["kernel"] = STRICT_KERNEL.get(k, r["kernel"])
                 dominant = max(fam, key=lambda k: fam[k]["ms"])
                 result["roofline"] = roofs[dominant]
                 result["kernels"] = sorted(roofs.values(), key=lambda r: -r["ms_per_step"])
