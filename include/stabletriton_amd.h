@@ -160,7 +160,9 @@ int st_ln_linear_xattn(const void* x, const float* row_stats, int row_stats_chun
 /* Fused attention core: out = softmax(q k^T * scale) v per head, no mask.
  * Replaces attention_wrapper (optimizers/replace_attention.py:60-68); inputs
  * keep the (B, T, H*D) / (B, S, H*D) projection layout of unet_pt.py:133-142.
- * ld* are token strides in elements (>= H*D), batch strides are T*ldq etc. */
+ * ld* are token strides in elements (>= H*D), batch strides are T*ldq etc.
+ * D (head_dim) in {16, 32, 64, 128}, the reference operator's set (kernels/attention_fa2.py:118-123); 64 - every SDXL
+ * head - runs on the tuned kernels, the other three on one generic kernel (csrc/attention_anyd.hip). */
 int st_attention(const void* q, const void* k, const void* v, void* out,
                  int B, int T, int S, int H, int D,
                  long ldq, long ldk, long ldv, long ldo,

@@ -363,6 +363,10 @@ __global__ __launch_bounds__((NW + (LD ? 1 : 0)) * 64) void attn32i_kernel(const
 int attention_f32_launch(const float* q, const float* k, const float* v, float* out, int B, int T, int S, int H,
                          long ldq, long ldk, long ldv, long ldo, float scale, void* out_split, bool presplit, hipStream_t st);
 
+// head_dim 16, 32, 128 (attention_anyd.hip)
+int attention_anyd_launch(int dtype, const void* q, const void* k, const void* v, void* out, int B, int T, int S, int H, int D,
+                          long ldq, long ldk, long ldv, long ldo, float scale, void* out_split, hipStream_t st);
+
 template <typename E>
 static int attention16_launch(const void* q, const void* k, const void* v, void* out, int B, int T, int S, int H,
                               long ldq, long ldk, long ldv, long ldo, float scale, hipStream_t st) {
@@ -407,7 +411,7 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
                             long ldq, long ldk, long ldv, long ldo, float scale, int dtype, void* stream) {
     ST_REQUIRE(q && k && v && out, "attention: null pointer");
     ST_REQUIRE(B > 0 && T > 0 && S > 0 && H > 0, "attention: bad shape B=%d T=%d S=%d H=%d", B, T, S, H);
-    ST_REQUIRE(D == ATT_D, "attention: head_dim %d not supported (only %d)", D, ATT_D);
+    ST_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128, "attention: head_dim %d not supported (16, 32, 64, 128)", D);
     ST_REQUIRE(H <= 65535 && B <= 65535, "attention: too many heads/batches for one launch");
     const int vec = st_dtype_is16(dtype) ? 8 : 4;
     ST_REQUIRE(ldq % vec == 0 && ldk % vec == 0 && ldv % vec == 0 && ldo % 4 == 0, "attention: strides must keep 16-byte alignment");
@@ -415,6 +419,7 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
     hipStream_t st = (hipStream_t)stream;
     void* out_split = nullptr;
     if (int e = st_take_split_arm("attention", (long)B * T, H * D, dtype == ST_F32, &out_split)) return e;
+    if (D != ATT_D) return attention_anyd_launch(dtype, q, k, v, out, B, T, S, H, D, ldq, ldk, ldv, ldo, scale, out_split, st);
     if (dtype == ST_BF16) return attention16_launch<bf16>(q, k, v, out, B, T, S, H, ldq, ldk, ldv, ldo, scale, st);
     if (dtype == ST_F16) return attention16_launch<f16>(q, k, v, out, B, T, S, H, ldq, ldk, ldv, ldo, scale, st);
     if (dtype == ST_F32) return attention_f32_launch((const float*)q, (const float*)k, (const float*)v, (float*)out, B, T, S, H, ldq, ldk, ldv, ldo, scale, out_split, false, st);

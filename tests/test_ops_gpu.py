@@ -162,6 +162,48 @@ def test_attention(gpu, dtype, B, T, S, H):
     assert_close(out, ref, dtype, "attention")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("D", [16, 32, 128])
+@pytest.mark.parametrize("B,T,S,H", [(1, 256, 256, 4), (2, 100, 77, 3), (1, 200, 1000, 2), (1, 64, 1, 1), (2, 300, 333, 3), (1, 1024, 1024, 5)])
+def test_attention_other_head_sizes(gpu, dtype, D, B, T, S, H):
+    """The reference's operator takes head_dim 16 / 32 / 64 / 128 (kernels/attention_fa2.py:118-123); SDXL uses 64 only.
+    The other three run on attn_anyd_kernel (csrc/attention_anyd.hip), in every dtype, ragged T / S included; the
+    scale argument is honoured (the oracle's is head_dim^-1/2)."""
+    C = H * D
+    q, k, v = rnd("attd.q", (B, T, C)), rnd("attd.k", (B, S, C)), rnd("attd.v", (B, S, C))
+    ref = orc.attention_core(rounded(q, dtype), rounded(k, dtype), rounded(v, dtype), H)
+    out = ops.attention(q.to(gpu, dtype), k.to(gpu, dtype), v.to(gpu, dtype), H, D ** -0.5)
+    assert_close(out, ref, dtype, f"attention head_dim {D}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("D", [16, 32, 128])
+def test_attention_other_head_sizes_lazy_maximum_and_strided_operands(gpu, dtype, D):
+    """attn_anyd_kernel: rows whose maximum outruns the lag late, in the masked last tile, rows that start from a very negative
+    first tile, large scores; q / k / v are column slices of one fused projection (strided rows), as in a compiled graph."""
+    B, T, S, H = 2, 80, 330, 3
+    C = H * D
+    q, k, v = rnd("attdl.q", (B, T, C)), rnd("attdl.k", (B, S, C)), rnd("attdl.v", (B, S, C))
+    amp = (64 / D) ** 0.5                     # the same score scale for every head size
+    k[:, 329] = q[:, 2] * 8.0 * amp
+    k[:, 200] = q[:, 30] * 5.0 * amp
+    k[:, 70] = q[:, 79] * 1.5 * amp
+    k[:, :64] = k[:, :64] - q[:, 4:5] * 4.0 * amp
+    q[:, 5] = q[:, 5] * 12.0 * amp
+    ref = orc.attention_core(rounded(q, dtype), rounded(k, dtype), rounded(v, dtype), H)
+    qg = torch.cat([q, q], dim=-1).to(gpu, dtype)[..., C:]
+    kvg = torch.cat([k, v], dim=-1).to(gpu, dtype)
+    out = ops.attention(qg, kvg[..., :C], kvg[..., C:], H, D ** -0.5)
+    assert_close(out, ref, dtype, f"attention head_dim {D}, lazy maximum")
+
+
+def test_attention_rejects_unsupported_head_sizes(gpu):
+    for D in (8, 40, 80, 256):
+        q = torch.zeros(1, 64, 2 * D, device=gpu, dtype=torch.bfloat16)
+        with pytest.raises(ops.BackendError, match="head_dim"):
+            ops.attention(q, q, q, 2, D ** -0.5)
+
+
 def test_attention_peaked_softmax(gpu):
     """Force the online-softmax rescale: one key dominates late in the sequence."""
     B, T, S, H = 1, 128, 320, 2

@@ -199,6 +199,23 @@ def test_producers_leave_the_split_image_of_what_they_store(gpu):
         assert torch.equal(co, co2)
 
 
+@pytest.mark.parametrize("D", [16, 32, 128])
+def test_attention_fp32_other_head_sizes_against_float64_and_their_image(gpu, D):
+    """attn_anyd_kernel in fp32: split operands like the head_dim-64 kernel (same 3e-6 against float64), and the image it
+    leaves for the output projection is st_split_f32 of what it stored."""
+    B, T, S, H = 2, 200, 333, 4
+    C = H * D
+    q, k, v = rnd("spd.q", (B, T, C)), rnd("spd.k", (B, S, C)), rnd("spd.v", (B, S, C))
+    qh, kh, vh = (t.double().view(B, -1, H, D).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * D ** -0.5, dim=-1) @ vh).transpose(1, 2).reshape(B, T, C)
+    with ops.ExecContext() as ctx:
+        out = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), H, D ** -0.5)
+        assert _err(out, ref) <= 3e-6
+        if C % 32 == 0:
+            ent = _recent(ctx)[-1]
+            assert ent[0] is out and torch.equal(ent[4].view(torch.int32), _image_of(out.view(-1, C)).view(torch.int32))
+
+
 def test_in_place_update_of_a_producer_output_is_not_missed(gpu):
     """A note on a producer's image is honoured only while the output is what the producer wrote: an in-place update bumps the
     tensor's version counter and the consumer splits the updated values itself."""

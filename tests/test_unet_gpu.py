@@ -66,6 +66,27 @@ def test_tiny_unet_step(gpu, dtype, tol, batch, hw):
     assert err <= tol
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, ABS_TOL_STRICT), (torch.bfloat16, 0.1), (torch.float16, 0.025)])
+@pytest.mark.parametrize("head_dim", [32, 128])
+def test_tiny_unet_step_other_head_sizes(gpu, dtype, tol, head_dim):
+    """A model with the reference's other head sizes (kernels/attention_fa2.py:118-123) compiles through the same passes:
+    fuse_attention matches, the text-context query path takes the two-launch route (the fused one is head_dim 64 only),
+    the generic attention kernel runs; strict mode inside the same 1e-3."""
+    import dataclasses
+    spec = dataclasses.replace(TINY, head_dim=head_dim)
+    m, gm = build(spec, dtype, gpu, graph=False)
+    sd = {k: v.float().cpu() for k, v in m.state_dict().items()}
+    x, xg = tiny_inputs(dtype, gpu, 2, 16)
+    xr = {k: v.to(dtype).float() for k, v in x.items()}
+    t = torch.tensor(500.0)
+    ref = orc.unet_forward(sd, xr["latent"], t, xr["encoder_hidden_states"], xr["text_embeds"], xr["time_ids"], head_dim=head_dim)
+    with torch.no_grad():
+        out = gm(xg["latent"], t.to(gpu), xg["encoder_hidden_states"], {"text_embeds": xg["text_embeds"], "time_ids": xg["time_ids"]})[0]
+    err = float((out.float().cpu() - ref).abs().max())
+    print(f"tiny step head_dim {head_dim} {dtype}: max abs err {err:.2e}")
+    assert err <= tol
+
+
 def test_graph_cache_replays_and_rekeys(gpu):
     m, gm_plain = build(TINY, torch.float32, gpu, graph=False)
     gm = optimize_model(m, cuda_graph=True)
