@@ -419,6 +419,10 @@ extern "C" int st_attention(const void* q, const void* k, const void* v, void* o
     hipStream_t st = (hipStream_t)stream;
     void* out_split = nullptr;
     if (int e = st_take_split_arm("attention", (long)B * T, H * D, dtype == ST_F32, &out_split)) return e;
+#ifdef ST_DEV_CONFIGS
+    static const int force_anyd = att_dev_env_int("ST_ATT_ANYD", 0);       // dev knob: head_dim 64 on the generic kernel too
+    if (force_anyd) return attention_anyd_launch(dtype, q, k, v, out, B, T, S, H, D, ldq, ldk, ldv, ldo, scale, out_split, st);
+#endif
     if (D != ATT_D) return attention_anyd_launch(dtype, q, k, v, out, B, T, S, H, D, ldq, ldk, ldv, ldo, scale, out_split, st);
     if (dtype == ST_BF16) return attention16_launch<bf16>(q, k, v, out, B, T, S, H, ldq, ldk, ldv, ldo, scale, st);
     if (dtype == ST_F16) return attention16_launch<f16>(q, k, v, out, B, T, S, H, ldq, ldk, ldv, ldo, scale, st);

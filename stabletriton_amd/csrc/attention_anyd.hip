@@ -257,6 +257,9 @@ int launch_t(const void* q, const void* k, const void* v, void* out, int B, int 
              long ldo, float c, void* out_split, hipStream_t st) {
     if (D == 16) return launch_d<TI, 16>(q, k, v, out, B, T, S, H, ldq, ldk, ldv, ldo, c, out_split, st);
     if (D == 32) return launch_d<TI, 32>(q, k, v, out, B, T, S, H, ldq, ldk, ldv, ldo, c, out_split, st);
+#ifdef ST_DEV_CONFIGS
+    if (D == 64) return launch_d<TI, 64>(q, k, v, out, B, T, S, H, ldq, ldk, ldv, ldo, c, out_split, st);      // (ST_ATT_ANYD: the generic kernel beside the tuned ones)
+#endif
     if (D == 128) return launch_d<TI, 128>(q, k, v, out, B, T, S, H, ldq, ldk, ldv, ldo, c, out_split, st);
     return st_fail("attention: head_dim %d not supported (16, 32, 64, 128)", D);
 }
