@@ -34,7 +34,7 @@ def test_abi_version_and_error_string(lib):
     # argument validation happens on the host, before any launch: exercise it without a GPU
     rc = lib.st_layer_norm(None, None, None, None, 4, 64, 1e-5, _C.ST_BF16, None)
     assert rc != 0 and b"null" in lib.st_last_error()
-    rc = lib.st_attention(1, 1, 1, 1, 1, 8, 8, 2, 32, 64, 64, 64, 64, 1.0, _C.ST_BF16, None)
+    rc = lib.st_attention(1, 1, 1, 1, 1, 8, 8, 2, 40, 80, 80, 80, 80, 1.0, _C.ST_BF16, None)
     assert rc != 0 and b"head_dim" in lib.st_last_error()
     rc = lib.st_linear(16, 16, None, None, None, 16, 4, 8, 12, 12, 8, 0, 0, 0, _C.ST_BF16, None, 0, None, 0, None, None, 0, None, None, 0, None)
     assert rc != 0 and b"multiples" in lib.st_last_error()

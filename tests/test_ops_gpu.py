@@ -362,8 +362,8 @@ def test_ops_fail_loudly(gpu):
     with pytest.raises(ops.BackendError):
         ops.linear(x.to(gpu).double(), w.to(gpu).double())   # fp64 is not a supported dtype
     with pytest.raises(ops.BackendError):
-        ops.attention(torch.zeros(1, 8, 96, device=gpu), torch.zeros(1, 8, 96, device=gpu),
-                      torch.zeros(1, 8, 96, device=gpu), 3, 1.0)   # head_dim 32 unsupported
+        ops.attention(torch.zeros(1, 8, 120, device=gpu), torch.zeros(1, 8, 120, device=gpu),
+                      torch.zeros(1, 8, 120, device=gpu), 3, 1.0)   # head_dim 40: not one of the operator's 16 / 32 / 64 / 128
     with pytest.raises(ops.BackendError):                  # the fused query-projection + attention launch takes short contexts only
         C = 128
         xg, st = ops.linear(torch.zeros(1, 128, C, device=gpu, dtype=torch.float16), torch.eye(C, device=gpu, dtype=torch.float16), None, emit_stats=True)
