@@ -46,12 +46,13 @@ enum {
     ST_EPI_ROWBIAS   = 16   /* + rowbias[batch(m)][n]     (time-embedding add)    */
 };
 
-int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 13
+int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 14
                                               (6: next-weights hint passed per call, st_timestep_sincos; 7: fp8 entry points; 8: GroupNorm partials from the
                                               producer; 9: st_ln_linear_xattn; 10: ST_F16 accepted by every entry point
                                               that takes a dtype, st_ln_linear_xattn takes a dtype; 11: fp8 plan with
                                               delayed per-tensor scaling - st_linear_emit8, st_linear_fp8x, st_fp8_update_scales; 12: readers of a channel
-                                              concatenation that is never written - st_group_norm_from_stats_cat, st_conv1x1_cat; 13: ST_F32S split fp32 matrix operands, st_split_f32, st_arm_split_output, st_attention_split) */
+                                              concatenation that is never written - st_group_norm_from_stats_cat, st_conv1x1_cat; 13: ST_F32S split fp32 matrix operands, st_split_f32, st_arm_split_output, st_attention_split; 14: st_attention
+                                              takes head_dim 16 / 32 / 128 beside 64) */
 const char* st_last_error(void);           /* host string, thread-local     */
 
 /* GroupNorm (+SiLU).  Replaces reference group_norm_wrapper
