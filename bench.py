@@ -544,8 +544,10 @@ def main():
                 n_launch = sum(f["launches"] for f in fam.values())
                 boundary_ms = max(ms_per_step - census_ms, 0.0) / n_launch
                 # the committed rocprofv3 / counter summaries beside the live numbers: those of the same command (bf16 headline,
-                # strict mode, refiner img2img fp8); other variants of the run carry none
+                # strict mode, refiner img2img fp8, bs=4); other variants of the run carry none
                 tag = "_strict" if dtype == torch.float32 else ("_refiner" if (args.model == "refiner" and args.fp8) else "")
+                if not tag and args.model == "base" and not args.fp8 and args.batch == 4 and dtype == torch.bfloat16:
+                    tag = "_b4"                     # (BASELINE config #3)
                 plain = tag or (args.model == "base" and not args.fp8 and args.batch == 1 and dtype == torch.bfloat16)
                 roofs = {k: roofline_of(k, v, boundary_ms, committed=bool(plain), tag=tag) for k, v in fam.items()}
                 if dtype == torch.float32:

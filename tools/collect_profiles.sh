@@ -8,7 +8,7 @@ ks=$(ls -t gpurun_out/$R/prof_final/prof/*/*kernel_stats.csv | head -1); ds=$(ls
 cp "$ks" profiles/r${N}_bench_kernel_stats.csv; cp "$ds" profiles/r${N}_bench_domain_stats.csv
 python tools/profile_families.py profiles/r${N}_bench_kernel_stats.csv profiles/r${N}_families.json > /dev/null
 python tools/pmc_ops.py gpurun_out/$R/prof_final/pmc r$N > /dev/null
-for what in strict refiner; do      # (round 4: the strict mode and the refiner img2img fp8 line, same command under rocprofv3)
+for what in strict refiner b4; do      # (round 4: the strict mode, the refiner img2img fp8 line, the bs=4 line of config #3: same commands under rocprofv3)
   ks=$(ls -t gpurun_out/$R/prof_final/prof_$what/*/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$ks" ] || continue
   cp "$ks" profiles/r${N}_${what}_kernel_stats.csv

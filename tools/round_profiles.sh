@@ -11,7 +11,9 @@ cd $GRAFT_REPO_ROOT/$out/prof && find . -name "*kernel_trace.csv" -delete
 cd /tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof_strict -- python3 $GRAFT_REPO_ROOT/bench.py --dtype fp32 --steps 50 --warmup 10 --mode step --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/$out/prof_strict_bench.json 2> $GRAFT_REPO_ROOT/$out/prof_strict_bench.err
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof_refiner -- python3 $GRAFT_REPO_ROOT/bench.py --model refiner --img2img 0.3 --steps 30 --warmup 15 --no-cpu-baseline --no-extras --fp8 > $GRAFT_REPO_ROOT/$out/prof_refiner_bench.json 2> $GRAFT_REPO_ROOT/$out/prof_refiner_bench.err
-find $GRAFT_REPO_ROOT/$out/prof_strict $GRAFT_REPO_ROOT/$out/prof_refiner -name "*kernel_trace.csv" -delete
+# (config #3: the bs=4 line)
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof_b4 -- python3 $GRAFT_REPO_ROOT/bench.py --batch 4 --steps 50 --warmup 10 --no-cpu-baseline --no-extras  > $GRAFT_REPO_ROOT/$out/prof_b4_bench.json 2> $GRAFT_REPO_ROOT/$out/prof_b4_bench.err
+find $GRAFT_REPO_ROOT/$out/prof_strict $GRAFT_REPO_ROOT/$out/prof_refiner $GRAFT_REPO_ROOT/$out/prof_b4 -name "*kernel_trace.csv" -delete
 cd $GRAFT_REPO_ROOT
 python tools/gemm_vs_vendor.py $out/vendor_bf16.json bf16 > $out/vendor_bf16.log 2>&1
 python tools/gemm_vs_vendor.py $out/vendor_fp16.json fp16 > $out/vendor_fp16.log 2>&1
