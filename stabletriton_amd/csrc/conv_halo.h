@@ -274,14 +274,32 @@ static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
     const int bm = (!ups && a.Win == 128) ? 128 : 256, bn = SP ? (sp128 ? 128 : 64) : ((ups || a.Win == 128) ? 160 : 128);
     const int tiles = (a.M / bm) * cdiv(a.N, bn);
     const int ncs = a.Cin / (128 / (int)sizeof(T));
-    // K split over channel slices: aim at one round of ~240 blocks; a slice keeps at least two channel slices
+    // K split over channel slices (a slice keeps at least two channel slices), by a time model fitted to the sweeps of
+    // tools/conv_splitk_sweep.py (1280 @ 32 x 32 at batch 1: 144 / 83 / 65 / 55 / 50 / 51 us for 1 ... 6 slices):
+    //   rounds of 256 blocks x (tap trips per slice x 0.77 us + 5.4 us of prologue and epilogue) + per slice 1.2 us and its fp32
+    //   slab written and read once at ~4 TB/s.
+    // At batch 1 this is the rule of rounds 2-3 (one round of ~240 blocks: 40 tiles -> 6 slices, 80 -> 3, 128 -> 2); at batch 2 / 4
+    // it no longer picks the splits that only add a second, mostly empty round (160 tiles x 2 slices = 320 blocks: the step at
+    // batch 4 35.66 -> 34.89 ms, at batch 2 20.88 -> 20.61, same box, tools/ab_step.py; per shape profiles/r04_conv_splits.txt).
     int sk = 1;
-    if (a.partial && tiles < 200) {
-        static const int target = dev_env_int("ST_HALO_BLOCKS", 240);
-        sk = (target + tiles / 2) / tiles;
-        if (sk > ncs / 2) sk = ncs / 2;
-        if (sk < 1) sk = 1;
-        while (sk > 1 && ((size_t)sk * tiles * bm * bn * 4 + 65536 > a.partial_bytes || tiles > 16384)) --sk;
+    if (SP) {            // split operands (strict mode, tuned at batch 1 only): one round of ~240 blocks
+        if (a.partial && tiles < 200) {
+            sk = (240 + tiles / 2) / tiles;
+            if (sk > ncs / 2) sk = ncs / 2;
+            if (sk < 1) sk = 1;
+            while (sk > 1 && ((size_t)sk * tiles * bm * bn * 4 + 65536 > a.partial_bytes || tiles > 16384)) --sk;
+        }
+    } else if (a.partial && tiles <= 16384) {
+        static const int force = dev_env_int("ST_HALO_SPLITS", 0);          // dev knob: this many slices where allowed
+        const double trip_us = 0.77 * bn / 128.0, slab_us = 2.0 * tiles * bm * bn * 4.0 / 4.0e6;
+        const int trips = ncs * 9, max_sk = ncs / 2 < 8 ? ncs / 2 : 8;
+        double best = 1e30;
+        for (int s_ = 1; s_ <= max_sk || s_ == 1; ++s_) {
+            if (s_ > 1 && (size_t)s_ * tiles * bm * bn * 4 + 65536 > a.partial_bytes) break;
+            const int rounds = (tiles * s_ + 255) / 256;
+            const double t = rounds * (trips / (double)s_ * trip_us + 5.4) + (s_ > 1 ? s_ * (1.2 + slab_us) : 0.0);
+            if (force ? s_ == force : t < best - 0.5) { best = t; sk = s_; }      // (near ties: the fewer slices)
+        }
     }
     if (sk > 1) { b.splitk = sk; b.tile_counters = (int*)a.partial; b.partial = a.partial + 16384; }
     else b.splitk = 1;

@@ -1,6 +1,6 @@
 """Developer A/B: the halo conv's K split summed in-launch (last arriver of a tile) against the separate combine launch
 (splitk_combine_kernel), per shape and number of slices; also checks that both give the same bits.  Needs a dev build
-(-DST_DEV_CONFIGS: ST_HALO_SEP, ST_HALO_BLOCKS), ST_VARIANT=<name>.  One process per setting (the knobs are read once).
+(-DST_DEV_CONFIGS: ST_HALO_SEP, ST_HALO_BLOCKS - the slice knob of the tree that experiment was made on), ST_VARIANT=<name>.  One process per setting (the knobs are read once).
 usage: conv_sep_ab.py            -> the step's 3x3 shapes x {in-launch, separate} x several slice targets"""
 import hashlib
 import os

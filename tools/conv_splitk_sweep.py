@@ -1,12 +1,12 @@
-"""Developer sweep: the halo conv's time against the number of K slices (ST_HALO_BLOCKS = blocks aimed at; dev build
--DST_DEV_CONFIGS, ST_VARIANT=<name>).  One process per setting (the knob is read once).
-usage: conv_splitk_sweep.py            -> runs itself for the step's three 3x3 levels and several targets"""
+"""Developer sweep: the halo conv's time against the number of K slices (ST_HALO_SPLITS = slices; 0 = the launcher's own time
+model; dev build -DST_DEV_CONFIGS, ST_VARIANT=<name>).  One process per setting (the knob is read once).
+usage: conv_splitk_sweep.py [batch ...]   -> runs itself for the step's 3x3 shapes at the given batch sizes (default 1 2 4)"""
 import os
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if len(sys.argv) > 1:
+if len(sys.argv) == 5:
     sys.path.insert(0, ROOT)
     import torch
     from tools.op_bench import timeit, rnd  # noqa: E402  (selects the ST_VARIANT build)
@@ -23,11 +23,15 @@ if len(sys.argv) > 1:
     us = timeit(lambda: ops.conv2d(x, w, b, 1, 1))
     print(f"RESULT {us:.1f}")
     sys.exit(0)
-for shape in ((1, 1280, 32, 1280), (1, 640, 64, 640), (1, 320, 128, 320), (1, 2560, 32, 1280), (1, 1920, 32, 1280)):
-    line = f"conv N={shape[0]} Cin={shape[1]} H={shape[2]} Cout={shape[3]}:"
-    for target in (40, 80, 120, 160, 200, 240, 320):
-        env = dict(os.environ, ST_HALO_BLOCKS=str(target))
-        out = subprocess.run([sys.executable, os.path.abspath(__file__)] + [str(v) for v in shape], capture_output=True, text=True, env=env)
-        r = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
-        line += f"  {target}: {r[0].split()[1] if r else 'ERR'}"
-    print(line, flush=True)
+batches = [int(v) for v in sys.argv[1:]] or [1, 2, 4]      # (a bare batch list: the self-invocations above pass four numbers)
+for nb in batches:
+    for shape in ((nb, 1280, 32, 1280), (nb, 640, 64, 640), (nb, 320, 128, 320), (nb, 2560, 32, 1280), (nb, 1920, 32, 1280), (nb, 1280, 64, 640)):
+        line = f"conv N={shape[0]} Cin={shape[1]} H={shape[2]} Cout={shape[3]}:"
+        for splits in (0, 1, 2, 3, 4, 5, 6, 8):
+            env = dict(os.environ, ST_HALO_SPLITS=str(splits))
+            out = subprocess.run([sys.executable, os.path.abspath(__file__)] + [str(v) for v in shape], capture_output=True, text=True, env=env)
+            r = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+            if not r and splits == 0:
+                print(out.stderr[-600:], flush=True)
+            line += f"  {'model' if splits == 0 else splits}: {r[0].split()[1] if r else 'ERR'}"
+        print(line, flush=True)
