@@ -1,6 +1,6 @@
 """Developer sweep: every tile configuration x K split of the LDS-DMA GEMM for the Linear shapes of a batch size,
 against the cost model's own choice (needs the -DST_DEV_CONFIGS library: ST_VARIANT=dev).
-usage: gemm_sweep.py <batch> [geglu|plain|all]"""
+usage: gemm_sweep.py <batch> [geglu|plain|all] [base|refiner]"""
 import ctypes
 import os
 import sys
@@ -26,6 +26,9 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 which = sys.argv[2] if len(sys.argv) > 2 else "all"
 shapes = [(1024 * B, 1280, 1280, 0), (1024 * B, 1280, 3840, 0), (1024 * B, 1280, 5120, 1), (1024 * B, 5120, 1280, 0),
           (4096 * B, 640, 640, 0), (4096 * B, 640, 1920, 0), (4096 * B, 640, 2560, 1), (4096 * B, 2560, 640, 0)]
+if len(sys.argv) > 3 and sys.argv[3] == "refiner":      # SDXL-refiner (config #5): 768 channels at 64 x 64, 1536 at 32 x 32
+    shapes = [(1024 * B, 1536, 1536, 0), (1024 * B, 1536, 4608, 0), (1024 * B, 1536, 6144, 1), (1024 * B, 6144, 1536, 0),
+              (4096 * B, 768, 768, 0), (4096 * B, 768, 2304, 0), (4096 * B, 768, 3072, 1), (4096 * B, 3072, 768, 0)]
 for M, K, N, geglu in shapes:
     if which == "geglu" and not geglu or which == "plain" and geglu:
         continue
