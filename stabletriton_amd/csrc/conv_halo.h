@@ -281,23 +281,19 @@ static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
     // At batch 1 this is the rule of rounds 2-3 (one round of ~240 blocks: 40 tiles -> 6 slices, 80 -> 3, 128 -> 2); at batch 2 / 4
     // it no longer picks the splits that only add a second, mostly empty round (160 tiles x 2 slices = 320 blocks: the step at
     // batch 4 35.66 -> 34.89 ms, at batch 2 20.88 -> 20.61, same box, tools/ab_step.py; per shape profiles/r04_conv_splits.txt).
+    // Split operands (strict mode): the same with its own two constants; at batch 1 the old choices, at batch 4 three slices where
+    // the old rule took two (1280 @ 32 x 32: 432 -> 343 us).
     int sk = 1;
-    if (SP) {            // split operands (strict mode, tuned at batch 1 only): one round of ~240 blocks
-        if (a.partial && tiles < 200) {
-            sk = (240 + tiles / 2) / tiles;
-            if (sk > ncs / 2) sk = ncs / 2;
-            if (sk < 1) sk = 1;
-            while (sk > 1 && ((size_t)sk * tiles * bm * bn * 4 + 65536 > a.partial_bytes || tiles > 16384)) --sk;
-        }
-    } else if (a.partial && tiles <= 16384) {
+    if (a.partial && tiles <= 16384) {
         static const int force = dev_env_int("ST_HALO_SPLITS", 0);          // dev knob: this many slices where allowed
-        const double trip_us = 0.77 * bn / 128.0, slab_us = 2.0 * tiles * bm * bn * 4.0 / 4.0e6;
+        // (split operands: 32-channel slices, three MFMAs per product - the trip costs about the same, the fixed part about twice)
+        const double trip_us = (SP ? 0.75 : 0.77) * bn / 128.0, fixed_us = SP ? 10.0 : 5.4, slab_us = 2.0 * tiles * bm * bn * 4.0 / 4.0e6;
         const int trips = ncs * 9, max_sk = ncs / 2 < 8 ? ncs / 2 : 8;
         double best = 1e30;
         for (int s_ = 1; s_ <= max_sk || s_ == 1; ++s_) {
             if (s_ > 1 && (size_t)s_ * tiles * bm * bn * 4 + 65536 > a.partial_bytes) break;
             const int rounds = (tiles * s_ + 255) / 256;
-            const double t = rounds * (trips / (double)s_ * trip_us + 5.4) + (s_ > 1 ? s_ * (1.2 + slab_us) : 0.0);
+            const double t = rounds * (trips / (double)s_ * trip_us + fixed_us) + (s_ > 1 ? s_ * (1.2 + slab_us) : 0.0);
             if (force ? s_ == force : t < best - 0.5) { best = t; sk = s_; }      // (near ties: the fewer slices)
         }
     }
