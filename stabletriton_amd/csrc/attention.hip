@@ -392,6 +392,13 @@ static int attention16_launch(const void* q, const void* k, const void* v, void*
     // is 220 blocks instead of 160 (15.3 -> 13.9 us).
     int nw = (long)cdiv(T, 256) * H * B <= 128 ? 4 : 7;
     if (nw == 4 && (long)cdiv(T, 128) * H * B <= 176 && (long)cdiv(T, 96) * H * B <= 256) nw = 3;
+    // Eight self-loading waves (256 rows per block) where that saves a whole round of blocks over seven + loader (224 rows): a round
+    // of the eight-wave blocks takes 1.2x as long (tools/attn_nw_sweep.py: the refiner's 12 heads x 4,096 tokens at batch 4 are 878
+    // blocks = 4 rounds of 65 us against 768 = 3 rounds of 77 us)
+    if (nw == 7) {
+        const long r7 = cdiv((long)cdiv(T, 224) * H * B, 256L), r8 = cdiv((long)cdiv(T, 256) * H * B, 256L);
+        if (6 * r8 < 5 * r7) nw = 8;
+    }
     if (force_nw == 3 || force_nw == 4 || force_nw == 8 || force_nw == 7) nw = force_nw;
     auto kfn = nw == 8 ? attn32i_kernel<E, 8, false> : nw == 7 ? attn32i_kernel<E, 7, true> : nw == 3 ? attn32i_kernel<E, 3, true> : attn32i_kernel<E, 4, true>;
     int threads = nw == 4 ? 320 : nw == 3 ? 256 : 512;

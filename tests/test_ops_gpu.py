@@ -151,9 +151,10 @@ def test_ln_linear(gpu, dtype, M, K, N, geglu):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,T,S,H", [(1, 256, 256, 10), (2, 128, 77, 5), (1, 1024, 1024, 20), (1, 100, 33, 2),
                                      (1, 64, 1, 1), (1, 4096, 77, 10), (1, 256, 640, 2), (1, 200, 1000, 3),
-                                     (1, 4096, 320, 10), (2, 300, 333, 3), (1, 513, 257, 2), (1, 768, 768, 32)])
+                                     (1, 4096, 320, 10), (2, 300, 333, 3), (1, 513, 257, 2), (1, 768, 768, 32), (2, 256, 300, 100)])
 # S >= 256: attn32i_kernel (three compute waves per block where that fills more CUs; (1, 768, 768, 32) takes four,
-# (1, 4096, 320, 10) the seven-wave blocks); S < 256: attn16v2_kernel
+# (1, 4096, 320, 10) the seven-wave blocks, (2, 256, 300, 100) the eight-wave blocks: 200 blocks of 256 rows in one round where
+# 224-row blocks would need two); S < 256: attn16v2_kernel
 def test_attention(gpu, dtype, B, T, S, H):
     C = H * 64
     q, k, v = rnd("att.q", (B, T, C)), rnd("att.k", (B, S, C)), rnd("att.v", (B, S, C))
