@@ -240,7 +240,8 @@ static inline bool conv_halo_applies(const GemmArgs& a, int R, int ups, int kb =
         if (a.Wout != 2 * a.Win || a.Hout != 2 * a.Hin || (a.Wout != 64 && a.Wout != 128)) return false;
         return a.Hout % (256 / a.Wout) == 0 && a.M % 256 == 0;
     }
-    if (a.Win != 32 && a.Win != 64 && a.Win != 128) return false;
+    // (16 x 16: the SDXL-refiner's fourth level, one whole image per tile; 16-bit elements only)
+    if (a.Win != 32 && a.Win != 64 && a.Win != 128 && !(a.Win == 16 && kb == 64)) return false;
     const int bm = a.Win == 128 ? 128 : 256, th = bm / a.Win;
     return a.Hin == a.Hout && a.Win == a.Wout && a.Hin % th == 0 && a.M % bm == 0;
 }
@@ -288,7 +289,7 @@ static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
         static const int force = dev_env_int("ST_HALO_SPLITS", 0);          // dev knob: this many slices where allowed
         // (split operands: 32-channel slices, three MFMAs per product - the trip costs about the same, the fixed part about twice)
         const double trip_us = (SP ? 0.75 : 0.77) * bn / 128.0, fixed_us = SP ? 10.0 : 5.4, slab_us = 2.0 * tiles * bm * bn * 4.0 / 4.0e6;
-        const int trips = ncs * 9, max_sk = ncs / 2 < 8 ? ncs / 2 : 8;
+        const int trips = ncs * 9, cap = tiles <= 16 ? 16 : 8, max_sk = ncs / 2 < cap ? ncs / 2 : cap;      // (a dozen tiles: the 16 x 16 level)
         double best = 1e30;
         for (int s_ = 1; s_ <= max_sk || s_ == 1; ++s_) {
             if (s_ > 1 && (size_t)s_ * tiles * bm * bn * 4 + 65536 > a.partial_bytes) break;
@@ -318,6 +319,7 @@ static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
     } else {
         if (ups && a.Wout == 64) conv_halo_go<T, 6, 4, 160, 4, 2, true>(b, tiles * sk, st);
         else if (ups) conv_halo_go<T, 7, 2, 160, 4, 2, true>(b, tiles * sk, st);
+        else if (a.Win == 16) conv_halo_go<T, 4, 16, 128, 4, 2>(b, tiles * sk, st);
         else if (a.Win == 32) conv_halo_go<T, 5, 8, 128, 4, 2>(b, tiles * sk, st);
         else if (a.Win == 64) conv_halo_go<T, 6, 4, 128, 4, 2>(b, tiles * sk, st);
         else conv_halo_go<T, 7, 1, 160, 4, 2>(b, tiles * sk, st);

@@ -1,0 +1,11 @@
+"""Developer timing: the 3x3 convs of the SDXL-refiner's 16 x 16 level (1536 -> 1536, 3072 -> 1536 channels) at batch 1 / 2 / 4;
+ST_VARIANT=<name> times a tools/_variants build instead of the product (round 4: the halo kernel against the implicit-GEMM path)."""
+import torch, sys, os
+sys.path.insert(0, ".")
+from tools.op_bench import timeit, rnd
+from stabletriton_amd import ops
+cl=torch.channels_last
+for N in (1, 2, 4):
+    for Cin,Cout in ((1536,1536),(3072,1536)):
+        x=rnd(N,Cin,16,16).contiguous(memory_format=cl); w=(rnd(Cout,Cin,3,3)*(9*Cin)**-0.5).contiguous(memory_format=cl); b=rnd(Cout)
+        print(os.environ.get("ST_VARIANT","product"), N, Cin,Cout, round(timeit(lambda: ops.conv2d(x,w,b,1,1)),1),"us", flush=True)
