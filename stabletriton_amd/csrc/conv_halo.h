@@ -272,7 +272,14 @@ static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
     // 109 against 134 us)
     constexpr bool SP = is_split<T>();
     const bool sp128 = SP && a.N % 128 == 0 && a.Wout <= 64;
-    const int bm = (!ups && a.Win == 128) ? 128 : 256, bn = SP ? (sp128 ? 128 : 64) : ((ups || a.Win == 128) ? 160 : 128);
+    const int bm = (!ups && a.Win == 128) ? 128 : 256;
+    int bn = SP ? (sp128 ? 128 : 64) : ((ups || a.Win == 128) ? 160 : 128);
+    if (!SP && !ups && a.Win == 128) {
+        // 128-pixel rows: 160 channels per tile (320 = 2 x 160: SDXL-base's first level is one round of 256 tiles at batch 1), or
+        // 128 where that takes fewer rounds x tile width (the refiner's 384 channels: 3 x 128 instead of 160 + 160 + a ragged 64)
+        auto cost = [&](int w) { return (long)cdiv((long)(a.M / bm) * cdiv(a.N, w), 256L) * w; };
+        if (cost(128) < cost(160)) bn = 128;
+    }
     const int tiles = (a.M / bm) * cdiv(a.N, bn);
     const int ncs = a.Cin / (128 / (int)sizeof(T));
     // K split over channel slices (a slice keeps at least two channel slices), by a time model fitted to the sweeps of
@@ -322,6 +329,7 @@ static int conv_halo_launch(const GemmArgs& a, hipStream_t st) {
         else if (a.Win == 16) conv_halo_go<T, 4, 16, 128, 4, 2>(b, tiles * sk, st);
         else if (a.Win == 32) conv_halo_go<T, 5, 8, 128, 4, 2>(b, tiles * sk, st);
         else if (a.Win == 64) conv_halo_go<T, 6, 4, 128, 4, 2>(b, tiles * sk, st);
+        else if (bn == 128) conv_halo_go<T, 7, 1, 128, 4, 2>(b, tiles * sk, st);
         else conv_halo_go<T, 7, 1, 160, 4, 2>(b, tiles * sk, st);
     }
     return st_check_launch("conv2d(halo)");

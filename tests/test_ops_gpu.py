@@ -304,7 +304,9 @@ CONVS = [  # N, Cin, H, W, Cout, k, stride, pad, upsample
     (1, 64, 128, 128, 320, 3, 1, 1, False), (1, 128, 64, 64, 200, 3, 1, 1, False), (2, 192, 32, 32, 136, 3, 1, 1, False),
     (1, 64, 32, 32, 160, 3, 1, 1, True), (2, 64, 64, 64, 96, 3, 1, 1, True),
     # 16-pixel rows (the refiner's fourth level: a whole image per tile), two images / a K long enough for a dozen channel slices
-    (2, 192, 16, 16, 136, 3, 1, 1, False), (1, 1536, 16, 16, 256, 3, 1, 1, False)]
+    (2, 192, 16, 16, 136, 3, 1, 1, False), (1, 1536, 16, 16, 256, 3, 1, 1, False),
+    # 128-pixel rows with 128-channel tiles (the refiner's 384 channels: three tiles, fewer rounds than 160 + 160 + 64)
+    (1, 64, 128, 128, 384, 3, 1, 1, False)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
