@@ -1,6 +1,6 @@
 """Developer sweep: the three projections of the fp8 plan (q|k|v, GEGLU projection, feed-forward output) in e4m3 on every tile
 configuration x K split against the cost model's choice (needs a -DST_DEV_CONFIGS build of gemm_api / gemm_fp8 / gemm_4w:
-ST_VARIANT=<name>).  usage: python tools/fp8_sweep.py [batch ...]"""
+ST_VARIANT=<name>).  usage: python tools/fp8_sweep.py [batch ...] [refiner]"""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.op_bench import timeit, rnd
@@ -8,9 +8,12 @@ from stabletriton_amd import _C, ops
 force = _C.load().st_debug_force_gemm
 force.argtypes, force.restype = [ctypes.c_int, ctypes.c_int], None
 NAMES = {7: "64x64", 8: "128x64", 9: "128x128", 10: "64x128", 19: "256x128", 27: "128x80", 28: "128x160", 100: "8p-256", 101: "8p-160"}
-batches = [int(b) for b in sys.argv[1:]] or [1, 2, 4]
+refiner = "refiner" in sys.argv[1:]              # SDXL-refiner's projections (config #5) instead of SDXL-base's
+batches = [int(b) for b in sys.argv[1:] if b != "refiner"] or [1, 2, 4]
+BASE = ((1024, 1280, 3840, "ln"), (1024, 1280, 5120, "lng"), (1024, 5120, 1280, "res"), (4096, 640, 1920, "ln"), (4096, 640, 2560, "lng"), (4096, 2560, 640, "res"))
+REFI = ((1024, 1536, 4608, "ln"), (1024, 1536, 6144, "lng"), (1024, 6144, 1536, "res"), (4096, 768, 2304, "ln"), (4096, 768, 3072, "lng"), (4096, 3072, 768, "res"))
 for B in batches:
-    for (Mi, K, N, kind) in ((1024, 1280, 3840, "ln"), (1024, 1280, 5120, "lng"), (1024, 5120, 1280, "res"), (4096, 640, 1920, "ln"), (4096, 640, 2560, "lng"), (4096, 2560, 640, "res")):
+    for (Mi, K, N, kind) in (REFI if refiner else BASE):
         M = Mi * B
         geglu = kind == "lng"
         rows = 2 * N if geglu else N
