@@ -13,6 +13,9 @@ reference source is copied.
     python oracle/make_golden.py f1_b4          # ~1 min   (BASELINE config #3 rows: batch 4, per-row distinct conditioning)
     python oracle/make_golden.py f3_b2          # ~8 min   (two independent 50-step trajectories in one batch, latent 64)
     python oracle/make_golden.py f3_cfg         # ~8 min   (the Diffusers call-site protocol: CFG batch 2, 50 steps, latent 64)
+    python oracle/make_golden.py f2_large       # ~1 min   (SURVEY 8c's attention sizes: T=1024 @ C=1280, T=4096 @ C=640; GroupNorm at 128 x 128)
+    python oracle/make_golden.py f3_64_f64 f3_cfg_f64   # the reference module in DOUBLE precision through the same loops: what
+                                                # the reference's own fp32 arithmetic deviates from (the noise floor the 1e-3 gates are read against)
 """
 from __future__ import annotations
 
@@ -224,6 +227,66 @@ def f3_cfg(ref, hw=64):
     save(f"f3_cfg50_latent{hw}", final=final, latent_hw=hw, guidance_scale=CFG_SCALE)
 
 
+@torch.no_grad()
+def f2_large(ref):
+    """SURVEY 8(c)'s F2 attention sizes - self (T=1024, 20 heads) and text-context (S=77) at C=1280, self (T=4096, 10 heads) and
+    text-context at C=640 (unet_pt.py:98-147) - and GroupNorm on the 128 x 128 feature maps whose groups do not fit one block
+    (960 channels: 491,520 elements per group).  Stored sub-sampled like f2_ops, in a file of their own."""
+    arrays = {}
+
+    def filled(mod, prefix):
+        for n, p in mod.named_parameters():
+            p.copy_(synth.param_tensor(f"{prefix}.{n}", tuple(p.shape), WEIGHT_SEED))
+        return mod.eval()
+
+    for c, t in ((1280, 1024), (640, 4096)):
+        a = filled(ref.Attention(c), f"f2.attn_self{c}_T{t}")
+        x = synth.normal(f"f2.attn_self{c}_T{t}.x", (1, t, c), INPUT_SEED)
+        arrays[f"attn_self{c}_T{t}"] = a(x)
+        a = filled(ref.Attention(c, 2048), f"f2.attn_cross{c}_T{t}")
+        ctx = synth.normal(f"f2.attn_cross{c}_T{t}.ctx", (1, 77, 2048), INPUT_SEED)
+        arrays[f"attn_cross{c}_T{t}"] = a(x, ctx)
+    for c, eps in ((960, 1e-5), (320, 1e-5), (640, 1e-6)):
+        gn = filled(torch.nn.GroupNorm(32, c, eps=eps), f"f2.gn{c}_128")
+        x = synth.normal(f"f2.gn{c}_128.x", (1, c, 128, 128), INPUT_SEED)
+        arrays[f"gn{c}_128"] = gn(x)
+    save("f2_ops_large", **{k: subsample(v) for k, v in arrays.items()})
+
+
+@torch.no_grad()
+def f3_f64(ref, cfg: bool, hw=64):
+    """The reference module converted to DOUBLE (`.double()`: the same fp32 weight values, float64 arithmetic) through the same
+    loop with the same fp32 table constants.  Recorded beside it: how far the reference's own fp32 run (the committed golden the
+    strict gates compare with) is from this - the noise floor of any fp32 summation order; a gate tighter than it measures luck."""
+    name = f"f3_cfg50_latent{hw}" if cfg else f"f3_euler50_latent{hw}"
+    ref32 = torch.from_numpy(np.load(os.path.join(OUT, name + ".npz"))["final"])
+    m = ref_unet(ref).double()
+    x = synth.denoise_inputs(2 if cfg else 1, hw, INPUT_SEED)
+    ehs = x["encoder_hidden_states"].double()
+    cond = {"text_embeds": x["text_embeds"].double(), "time_ids": x["time_ids"].double()}
+    tables = euler_discrete_tables(50)
+    t0 = time.time()
+    n = [0]
+
+    def fn(x_in, t):
+        n[0] += 1
+        if n[0] % 5 == 0:
+            print(f"  step {n[0]}  {time.time() - t0:.0f}s", flush=True)
+        return m(x_in, t, ehs, cond)[0]
+
+    if cfg:
+        final = orc.euler_denoise_cfg(fn, x["latent"][:1], tables, CFG_SCALE, state_dtype=torch.float64)
+    else:
+        final = orc.euler_denoise(fn, x["latent"], tables, state_dtype=torch.float64)
+    dev = (ref32.double() - final).abs()
+    print(f"{name}: reference fp32 vs float64: max abs {float(dev.max()):.3e} rms {float(dev.pow(2).mean().sqrt()):.3e}"
+          f"  |latent| max {float(final.abs().max()):.2f}")
+    save(name + "_f64", final=final, ref_fp32_max_abs=float(dev.max()), ref_fp32_rms=float(dev.pow(2).mean().sqrt()), latent_hw=hw,
+         **({"guidance_scale": CFG_SCALE} if cfg else {}))
+    global _REF_UNET
+    _REF_UNET = None            # the module is double now: later fixtures of this process build a fresh one
+
+
 if __name__ == "__main__":
     torch.set_num_threads(os.cpu_count() or 8)
     ref = load_reference()
@@ -238,6 +301,12 @@ if __name__ == "__main__":
             f3_b2(ref)
         elif what == "f3_cfg":
             f3_cfg(ref)
+        elif what == "f2_large":
+            f2_large(ref)
+        elif what == "f3_64_f64":
+            f3_f64(ref, cfg=False)
+        elif what == "f3_cfg_f64":
+            f3_f64(ref, cfg=True)
         elif what.startswith("f3_"):
             f3(ref, int(what[3:]))
         else:

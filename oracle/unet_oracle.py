@@ -221,34 +221,36 @@ def euler_img2img(unet_fn, init_latent, noise_unit, tables, strength: float) -> 
     return x
 
 
-def euler_denoise(unet_fn, latent_unit, tables, n_steps: Optional[int] = None) -> torch.Tensor:
+def euler_denoise(unet_fn, latent_unit, tables, n_steps: Optional[int] = None, state_dtype=torch.float32) -> torch.Tensor:
     """Euler-discrete epsilon-prediction loop (restated diffusers==0.21.2
     EulerDiscreteScheduler, see stabletriton_amd/scheduler.py header; parity of
     the scheduler arithmetic itself is unpinned).  `unet_fn(x_in, t)` returns
-    eps; `latent_unit` is unit-variance noise; state is kept in fp32."""
-    x = latent_unit.float() * tables.init_noise_sigma
+    eps; `latent_unit` is unit-variance noise; state is kept in fp32 (`state_dtype=torch.float64`: the
+    same loop with the same fp32 table constants in double precision - oracle/make_golden.py's truth runs)."""
+    x = latent_unit.to(state_dtype) * tables.init_noise_sigma
     n = tables.n_steps if n_steps is None else n_steps
     in_scale, dsigma = tables.in_scale(), tables.dsigma()
     for i in range(n):
         x_in = x * float(in_scale[i])
         eps = unet_fn(x_in, torch.tensor(float(tables.timesteps[i])))
-        x = x + eps.float() * float(dsigma[i])
+        x = x + eps.to(state_dtype) * float(dsigma[i])
     return x
 
 
-def euler_denoise_cfg(unet_fn, latent_unit, tables, guidance_scale: float, n_steps: Optional[int] = None) -> torch.Tensor:
+def euler_denoise_cfg(unet_fn, latent_unit, tables, guidance_scale: float, n_steps: Optional[int] = None,
+                      state_dtype=torch.float32) -> torch.Tensor:
     """Classifier-free-guidance form of the loop, as the reference's call site runs it
     (implementations/Diffusers/load_sdxl_pipeline.py:39-46 -> diffusers 0.21.2
     StableDiffusionXLPipeline.__call__: `latent_model_input = cat([latents] * 2)`,
     `noise_pred = uncond + g * (text - uncond)`; third-party arithmetic, parity unpinned like
     the scheduler).  `unet_fn(x_in2, t)` takes the duplicated (2, ...) input, row 0 = negative
     conditioning; `latent_unit` is (1, ...)."""
-    x = latent_unit.float() * tables.init_noise_sigma
+    x = latent_unit.to(state_dtype) * tables.init_noise_sigma
     n = tables.n_steps if n_steps is None else n_steps
     in_scale, dsigma = tables.in_scale(), tables.dsigma()
     for i in range(n):
         x_in = torch.cat([x, x]) * float(in_scale[i])
-        eps2 = unet_fn(x_in, torch.tensor(float(tables.timesteps[i]))).float()
+        eps2 = unet_fn(x_in, torch.tensor(float(tables.timesteps[i]))).to(state_dtype)
         eps = eps2[0:1] + guidance_scale * (eps2[1:2] - eps2[0:1])
         x = x + eps * float(dsigma[i])
     return x

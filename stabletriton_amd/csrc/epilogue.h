@@ -703,3 +703,232 @@ __device__ __forceinline__ void staged_epilogue(const GemmArgs& p, f32x4 (&acc)[
     }
     staged_epilogue_impl<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, LDS_BYTES, STATS, -1>(p, acc, m0, n0, tile_n, wm, r16, q, colmap, lds, lnrows);
 }
+
+// =============================================================================
+// Direct epilogue (the eight-phase kernel, round 5): accumulators -> output straight from registers, 16 bytes per lane.
+// The MFMA is issued swapped (W as the A operand), so a lane (r16, q) holds the four output columns 4q .. 4q+3 of a 16-column
+// accumulator tile: 8 bytes of a 16-bit row - the fragment epilogue's 32-byte row segments.  WHICH row of W sits behind
+// accumulator-tile row rho is free, though: it is fixed by the DMA's per-lane source address and nothing else.  The kernels
+// that take this epilogue stage W PERMUTED: of a PAIR of accumulator tiles (jj = 0, 1; 32 rows of W) row rho of tile jj
+// holds output column 8 (rho / 4) + 4 jj + rho % 4 of the pair, so the lane's two f32x4 are EIGHT consecutive columns: one
+// 16-byte store (residual load, bias load) per lane and row, 64 contiguous bytes per row and wave-instruction, and a
+// GEGLU whose value and gate meet in the lane (the wave's tiles are [values of its output columns | gates of the same]).
+// Against the staged form (13,000 cycles on a 256 x 256 tile, 24 % of a 45-us launch: DESIGN.md section 6) nothing goes
+// through LDS and no barrier is passed (row statistics excepted).
+//   WTN = 64 (TN = 4): pairs (0,1) (2,3); GEGLU: (0,1) = values, (2,3) = gates of the wave's 32 output columns.
+//   WTN = 80 (TN = 5): pairs (0,1) (3,4), tile 2 alone (4 columns per lane, unpermuted); GEGLU: (0,1) = values and (3,4) =
+//   gates of output columns 0 .. 31, tile 2 = values of columns 32 .. 39 in rows 0 .. 7 and their gates in rows 8 .. 15 (the
+//   gate comes from lane + 32).
+// Arithmetic order per element = epilogue_compute4's.  Feature sets (MODE, exact): any of LN, BIAS, RES, ROWS.
+// =============================================================================
+// The next launch's weights, touched by LDS-DMA into a dump area (one dword per 128-byte line, as touch_next_weights): the
+// register form's destination is an inline-asm output that the compiler believes valid at once - under the register pressure of
+// the direct epilogue it split the live range (v_mov to another register) and handed the original to an address computation,
+// which the late-returning loads then overwrote (first GPU run of round 5: memory aperture violation in the denoise step, where
+// next_w is set; the operator tests pass NULL).  An LDS-DMA has no destination register, and the builtin is compiler-visible.
+typedef __attribute__((address_space(3))) void epi_lds_void_t;
+typedef __attribute__((address_space(1))) const void epi_gbl_cvoid_t;
+__device__ __forceinline__ void touch_next_weights_dma(const GemmArgs& p, unsigned lds_dump_addr) {
+    if (!p.next_w || p.helper_blocks > 0) return;
+    const size_t lines = p.next_bytes >> 7;
+    const size_t per = p.next_per ? (size_t)p.next_per : (lines + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < lines ? lo + per : lines;
+    const size_t step = blockDim.x;
+    for (size_t l = lo + threadIdx.x; l < hi; l += step)
+        __builtin_amdgcn_global_load_lds((epi_gbl_cvoid_t*)((const char*)p.next_w + (l << 7)), (epi_lds_void_t*)(uintptr_t)lds_dump_addr, 4, 0, 0);
+}
+
+struct DirectCol { int col; bool gate; };
+// accumulator tile j, tile row rho (= row of the W fragment) -> output column inside the wave's WTNO columns (and: gate half?)
+template <int TN, bool GEGLU>
+__host__ __device__ __forceinline__ constexpr DirectCol direct_col(int j, int rho) {
+    static_assert(TN == 4 || TN == 5, "direct epilogue: wave tiles of 64 or 80 columns");
+    const int pc = 8 * (rho >> 2) + (rho & 3);          // + 4 jj
+    if (TN == 4) {
+        if (GEGLU) return DirectCol{pc + 4 * (j & 1), j >= 2};
+        return DirectCol{32 * (j >> 1) + pc + 4 * (j & 1), false};
+    }
+    if (GEGLU) {
+        if (j < 2) return DirectCol{pc + 4 * j, false};
+        if (j > 2) return DirectCol{pc + 4 * (j - 3), true};
+        return DirectCol{32 + (rho & 7), rho >= 8};
+    }
+    if (j < 2) return DirectCol{pc + 4 * j, false};
+    if (j > 2) return DirectCol{48 + pc + 4 * (j - 3), false};
+    return DirectCol{32 + rho, false};
+}
+// the feature sets with a direct instance (host and device agree through this one function)
+// (`tall`: the 128-row wave tiles of the 256 x 256 shape - 128 accumulator registers - leave no room for the row statistics:
+//  those launches keep the staged form)
+__host__ __device__ __forceinline__ constexpr bool direct_mode_ok(int flags, bool lnf, bool tall) {
+    if (lnf) return flags == EPI_F_LN || flags == (EPI_F_LN | EPI_F_BIAS);
+    if (flags == 0 || flags == EPI_F_BIAS || flags == (EPI_F_BIAS | EPI_F_RES)) return true;
+    return !tall && (flags == (EPI_F_BIAS | EPI_F_ROWS) || flags == (EPI_F_BIAS | EPI_F_RES | EPI_F_ROWS));
+}
+
+template <typename TO, int TM, int TN, int WTM, int WTN, int WGM, int WGN, bool GEGLU, int MODE>
+__device__ __forceinline__ void direct_epilogue_impl(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int tile_n, int wm, int wn, int r16, int q,
+                                                     char* lds, const float2* lnrows, unsigned lds_dump_addr) {
+    static_assert(sizeof(TO) == 2, "direct epilogue: 16-bit outputs");
+    constexpr bool has_ln = bool(MODE & EPI_F_LN), has_bias = bool(MODE & EPI_F_BIAS), has_res = bool(MODE & EPI_F_RES), emit_rows = bool(MODE & EPI_F_ROWS);
+    typedef typename EpiVec<TO>::type OV;               // 8 x 16 bit
+    typedef typename Raw4<TO>::type R4;                 // 4 x 16 bit
+    constexpr int WTNO = GEGLU ? WTN / 2 : WTN;
+    constexpr int NW_ = GEGLU ? 1 : 2;                  // wide groups (8 columns per lane)
+    constexpr bool NARROW = (TN == 5);                  // + one group of 4 columns per lane (GEGLU: lanes q < 2 only)
+    const int nw0 = n0 + wn * WTNO;                     // first output column of this wave
+    const int lane = (int)(threadIdx.x & 63);
+    // wide group w: value tiles jv, jv + 1; gate tiles jg, jg + 1; first column cb
+    auto jv_of = [](int w) { return TN == 4 ? 2 * w : (w == 0 ? 0 : 3); };
+    auto cb_of = [](int w) { return TN == 4 ? 32 * w : (w == 0 ? 0 : 48); };
+    constexpr int JG = TN == 4 ? 2 : 3;
+    const bool nlive = !GEGLU || q < 2;                 // narrow group: lanes that own output columns
+    const int nn = nw0 + 32 + 4 * (GEGLU ? (q & 1) : q);      // narrow group: first column of this lane (clamped for the idle lanes)
+    const TO* __restrict__ bias = (const TO*)p.bias;
+
+    // ---- pass 1: every load, back to back (one round trip) ------------------------------------------------------------
+    OV bv[NW_] = {}, bg[NW_] = {};
+    f32x4 cv[NW_][2] = {}, dv[NW_][2] = {}, cg[NW_][2] = {}, dg[NW_][2] = {};
+    R4 nbv = {}, nbg = {};
+    f32x4 ncv = {}, ndv = {}, ncg = {}, ndg = {};
+#pragma unroll
+    for (int w = 0; w < NW_; ++w) {
+        const int n = nw0 + cb_of(w) + 8 * q;
+        if (has_bias) { bv[w] = *reinterpret_cast<const OV*>(bias + n); if (GEGLU) bg[w] = *reinterpret_cast<const OV*>(bias + p.N + n); }
+        if (has_ln) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                cv[w][h] = *reinterpret_cast<const f32x4*>(p.ln_c + n + 4 * h); dv[w][h] = *reinterpret_cast<const f32x4*>(p.ln_d + n + 4 * h);
+                if (GEGLU) { cg[w][h] = *reinterpret_cast<const f32x4*>(p.ln_c + p.N + n + 4 * h); dg[w][h] = *reinterpret_cast<const f32x4*>(p.ln_d + p.N + n + 4 * h); }
+            }
+        }
+    }
+    if constexpr (NARROW) {
+        if (has_bias) { nbv = ld_raw4<TO>(bias + nn); if (GEGLU) nbg = ld_raw4<TO>(bias + p.N + nn); }
+        if (has_ln) {
+            ncv = *reinterpret_cast<const f32x4*>(p.ln_c + nn); ndv = *reinterpret_cast<const f32x4*>(p.ln_d + nn);
+            if (GEGLU) { ncg = *reinterpret_cast<const f32x4*>(p.ln_c + p.N + nn); ndg = *reinterpret_cast<const f32x4*>(p.ln_d + p.N + nn); }
+        }
+    }
+    // residual: all rows at once, except on the tall wave tiles (TM = 8: 128 accumulator registers + 64 of residual spill) -
+    // there in two batches of row tiles, the second requested once the first batch's accumulators have been packed
+    constexpr int RB_ = (has_res && TM >= 8) ? TM / 2 : TM;      // row tiles per residual batch
+    OV res[has_res ? RB_ : 1][NW_] = {};
+    R4 nres[has_res && NARROW ? RB_ : 1] = {};
+    auto load_res = [&](int i0) {
+        const TO* __restrict__ R = (const TO*)p.residual;
+#pragma unroll
+        for (int i = 0; i < RB_; ++i) {
+            const size_t m = (size_t)(m0 + wm * WTM + (i0 + i) * 16 + r16);
+#pragma unroll
+            for (int w = 0; w < NW_; ++w) res[has_res ? i : 0][w] = *reinterpret_cast<const OV*>(R + m * p.ldr + nw0 + cb_of(w) + 8 * q);
+            if constexpr (NARROW) nres[has_res ? i : 0] = ld_raw4<TO>(R + m * p.ldr + nn);
+        }
+    };
+    if constexpr (has_res) load_res(0);
+    float mean[has_ln ? TM : 1] = {}, rstd[has_ln ? TM : 1] = {};
+    if constexpr (has_ln) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { const float2 s = lnrows[wm * WTM + i * 16 + r16]; mean[i] = s.x; rstd[i] = s.y; }
+    }
+    touch_next_weights_dma(p, lds_dump_addr);           // the next launch's weights: in flight until the exit
+
+    // ---- pass 2: arithmetic; the rounded results replace the accumulators (packed) -------------------------------------
+    OV outw[TM][NW_];
+    R4 outn[NARROW ? TM : 1];
+    float rs1[emit_rows ? TM : 1] = {}, rs2[emit_rows ? TM : 1] = {};
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        if constexpr (has_res && RB_ < TM) { if (i == RB_) { __builtin_amdgcn_sched_barrier(0); load_res(RB_); } }      // (not hoisted above the first batch's arithmetic)
+#pragma unroll
+        for (int w = 0; w < NW_; ++w) {
+            const int jv = jv_of(w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = acc[i][jv + (e >> 2)][e & 3];
+                float g = GEGLU ? acc[i][JG + (e >> 2)][e & 3] : 0.f;
+                if (has_ln) { v = ln_fold(v, mean[i], rstd[i], cv[w][e >> 2][e & 3], dv[w][e >> 2][e & 3]); if (GEGLU) g = ln_fold(g, mean[i], rstd[i], cg[w][e >> 2][e & 3], dg[w][e >> 2][e & 3]); }
+                if (has_bias) { v += Elem<TO>::to_f(bv[w][e]); if (GEGLU) g += Elem<TO>::to_f(bg[w][e]); }
+                if (GEGLU) v *= gelu_for<TO>(g);
+                if (has_res) v += Elem<TO>::to_f(res[has_res ? i % RB_ : 0][w][e]);
+                const TO o = Elem<TO>::from_f(v);
+                outw[i][w][e] = o;
+                if (emit_rows) { const float s = Elem<TO>::to_f(o); rs1[i] += s; rs2[i] = fmaf(s, s, rs2[i]); }
+            }
+        }
+        if constexpr (NARROW) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[i][2][e];
+                float g = 0.f;
+                if (GEGLU) g = __shfl(v, (lane + 32) & 63, 64);          // rows 8 .. 15 of tile 2 (lanes q = 2, 3) hold the gates of rows 0 .. 7's columns
+                if (has_ln) { v = ln_fold(v, mean[i], rstd[i], ncv[e], ndv[e]); if (GEGLU) g = ln_fold(g, mean[i], rstd[i], ncg[e], ndg[e]); }
+                if (has_bias) { v += Elem<TO>::to_f(nbv[e]); if (GEGLU) g += Elem<TO>::to_f(nbg[e]); }
+                if (GEGLU) v *= gelu_for<TO>(g);
+                if (has_res) v += Elem<TO>::to_f(nres[has_res ? i % RB_ : 0][e]);
+                const TO o = Elem<TO>::from_f(v);
+                outn[i][e] = o;
+                if (emit_rows && nlive) { const float s = Elem<TO>::to_f(o); rs1[i] += s; rs2[i] = fmaf(s, s, rs2[i]); }
+            }
+        }
+        // one row tile at a time: left alone the scheduler interleaves all of them and keeps every value both packed and
+        // unpacked (the row-statistics instances of the 128-row wave tiles spilled 17 registers)
+        if constexpr (emit_rows) __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- pass 3: nothing but stores -------------------------------------------------------------------------------------
+    TO* __restrict__ C = (TO*)p.C;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const size_t m = (size_t)(m0 + wm * WTM + i * 16 + r16);
+#pragma unroll
+        for (int w = 0; w < NW_; ++w) *reinterpret_cast<OV*>(C + m * p.ldc + nw0 + cb_of(w) + 8 * q) = outw[i][w];
+        if constexpr (NARROW) { if (nlive) *reinterpret_cast<R4*>(C + m * p.ldc + nn) = outn[i]; }
+    }
+    if constexpr (emit_rows) {
+        // LayerNorm partials of the rows just stored: lane -> the four q lanes -> the WGN waves of the tile row (LDS) -> one
+        // float2 per (row, N tile); fixed order: bit-reproducible.  (The ring is free: every wave passed the barrier behind the K loop.)
+        float2* sm = reinterpret_cast<float2*>(lds);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float a1 = rs1[i], a2 = rs2[i];
+            a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
+            a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+            if (q == 0) sm[(wm * WTM + i * 16 + r16) * WGN + wn] = make_float2(a1, a2);
+        }
+        __syncthreads();
+        for (int row = threadIdx.x; row < WGM * WTM; row += WGM * WGN * 64) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGN; ++w) { const float2 x = sm[row * WGN + w]; a1 += x.x; a2 += x.y; }
+            reinterpret_cast<float2*>(p.row_stats)[(size_t)(m0 + row) * p.stats_chunks + tile_n] = make_float2(a1, a2);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
+// feature set of a launch as the direct epilogue sees it (-1: not a direct set); host and device
+static __host__ __device__ __forceinline__ int direct_flags(const GemmArgs& p, bool lnf, bool tall) {
+    if ((p.epi & (ST_EPI_ROWBIAS | ST_EPI_SILU)) || p.col_scale || p.q8_out || p.sp_out || !p.C || (!lnf && p.col_stats) || (lnf && p.row_stats)) return -1;
+    const int f = ((p.epi & ST_EPI_BIAS) ? EPI_F_BIAS : 0) | ((p.epi & ST_EPI_RESIDUAL) ? EPI_F_RES : 0) | (p.ln_c ? EPI_F_LN : 0) | (p.row_stats ? EPI_F_ROWS : 0);
+    return direct_mode_ok(f, lnf, tall) ? f : -1;
+}
+
+template <typename TO, int TM, int TN, int WTM, int WTN, int WGM, int WGN, bool GEGLU, bool LNF>
+__device__ __forceinline__ void direct_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int tile_n, int wm, int wn, int r16, int q,
+                                                char* lds, const float2* lnrows, unsigned lds_dump_addr) {
+    const int flags = direct_flags(p, LNF, TM >= 8);
+#define ST_DIR_CASE(M)                                                                                                        \
+    case (M):                                                                                                                 \
+        direct_epilogue_impl<TO, TM, TN, WTM, WTN, WGM, WGN, GEGLU, (M)>(p, acc, m0, n0, tile_n, wm, wn, r16, q, lds, lnrows, lds_dump_addr); \
+        return;
+    if constexpr (LNF) {
+        switch (flags) { ST_DIR_CASE(EPI_F_LN) ST_DIR_CASE(EPI_F_LN | EPI_F_BIAS) default: break; }
+    } else {
+        switch (flags) { ST_DIR_CASE(0) ST_DIR_CASE(EPI_F_BIAS) ST_DIR_CASE(EPI_F_BIAS | EPI_F_RES) default: break; }
+        if constexpr (TM < 8) {
+            switch (flags) { ST_DIR_CASE(EPI_F_BIAS | EPI_F_ROWS) ST_DIR_CASE(EPI_F_BIAS | EPI_F_RES | EPI_F_ROWS) default: break; }
+        }
+    }
+#undef ST_DIR_CASE
+    // (not reached: the host launches the permuted kernel only when direct_flags() names one of the sets above - gemm8p_launch)
+}

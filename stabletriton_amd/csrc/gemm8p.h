@@ -24,7 +24,7 @@
 // Staged epilogue (GEGLU: tile columns [values | gates]), LayerNorm folding, statistics, next-weights touches and the
 // XCD-aware tile order are the ones of gemm_dma_kernel.  No K split.
 // =============================================================================
-template <typename T, bool GEGLU, bool LNF, int BN = 256, int WGM = 2, int WGN = 4>
+template <typename T, bool GEGLU, bool LNF, int BN = 256, int WGM = 2, int WGN = 4, bool DIRECT = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     static_assert(sizeof(T) <= 2, "16-bit elements (bf16 / f16) or e4m3 bytes");
     constexpr int BM = 256, NW = 8;
@@ -60,6 +60,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     const TileId tid = tile_of_block(p, bid, nblk);
     const int tile_m = tid.tile_m, tile_n = tid.tile_n;
     const int m0 = tile_m * BM, n0 = tile_n * BNO;
+#ifdef ST_PROBE8      // developer build (tools/gemm8p_probe.py): cycle stamps of wave 0 into the split-K workspace, 32 bytes per block
+    unsigned long long pr_t0 = __builtin_readcyclecounter(), pr_t1 = 0, pr_t2 = 0;
+#endif
     const T* __restrict__ Ap = (const T*)p.A;
     const T* __restrict__ Wp = (const T*)p.W;
     const T* zeros = reinterpret_cast<const T*>(g_zero16);
@@ -73,13 +76,24 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     const T* b0_src[2];
     const T* b1_src[2];
     auto w_row = [&](int c) { return GEGLU ? (c < BN / 2 ? (size_t)(n0 + c) : (size_t)p.N + n0 + (c - BN / 2)) : (size_t)(n0 + c); };
+    // DIRECT: W staged permuted (epilogue.h, direct epilogue): accumulator tile j of wave column wc, tile row rho -> row of W
+    auto w_row_direct = [&](int wc, int j, int rho) {
+        const DirectCol dc = direct_col<TN, GEGLU>(j, rho);
+        return (size_t)(dc.gate ? p.N : 0) + n0 + wc * (GEGLU ? WTN / 2 : WTN) + dc.col;
+    };
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int idx = (2 * wave + e) * 8 + lr;
         a_src[e] = Ap + (size_t)(m0 + (idx / (TMH * 16)) * WTM + (idx % (TMH * 16))) * p.lda + lc * EV;      // half h adds TMH*16 rows
         const int i0 = idx < RB0 ? idx : 0, i1 = idx < RB1 ? idx : 0;
-        b0_src[e] = Wp + w_row((i0 / (TN0 * 16)) * WTN + (i0 % (TN0 * 16))) * p.K + lc * EV;
-        b1_src[e] = Wp + w_row((i1 / (TN1 * 16)) * WTN + TN0 * 16 + (i1 % (TN1 * 16))) * p.K + lc * EV;
+        if constexpr (DIRECT) {
+            const int in0 = i0 % (TN0 * 16), in1 = i1 % (TN1 * 16);
+            b0_src[e] = Wp + w_row_direct(i0 / (TN0 * 16), in0 >> 4, in0 & 15) * p.K + lc * EV;
+            b1_src[e] = Wp + w_row_direct(i1 / (TN1 * 16), TN0 + (in1 >> 4), in1 & 15) * p.K + lc * EV;
+        } else {
+            b0_src[e] = Wp + w_row((i0 / (TN0 * 16)) * WTN + (i0 % (TN0 * 16))) * p.K + lc * EV;
+            b1_src[e] = Wp + w_row((i1 / (TN1 * 16)) * WTN + TN0 * 16 + (i1 % (TN1 * 16))) * p.K + lc * EV;
+        }
     }
     const size_t a_half = (size_t)(TMH * 16) * p.lda;
     const int nk = p.K / KB;
@@ -168,7 +182,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     // A half in use, B0 (kept for the fourth phase), B1.  16-bit: [..][kk] = the operand of k step kk; e4m3: [..][0] is the whole
     // 128-k operand, assembled from the two 16-byte reads (chunks q and q + 4) where they land
     constexpr int NKK = sizeof(T) == 1 ? 1 : 2;
-    Frag fa[TMH][NKK], fb0[TN0][NKK], fb1[TN1][NKK];
+    // Round 5: the fragment reads of a K tile used to be 12 / 4 / 8 / 0 ds_read_b128 per wave over the four phases, and phase 0's
+    // read segment (four waves at once) took ~350 cycles against the 256 of the other half's MFMAs.  Phase 3 multiplies from A1
+    // and B0 only - B1's registers are free - so the first TMH/2 row tiles of the NEXT K tile's A0 are read there (fan): 8 / 4 / 8 / 4.
+    constexpr int TMP = TMH / 2;                      // A0 row tiles read one phase early
+    Frag fa[TMH][NKK], fan[TMP][NKK], fb0[TN0][NKK], fb1[TN1][NKK];
     auto read_op = [&](const char* base, const int (&off)[2], Frag (&dst)[NKK]) {
         if constexpr (sizeof(T) == 1) {
             const Half lo = *reinterpret_cast<const Half*>(base + off[0]), hi = *reinterpret_cast<const Half*>(base + off[1]);
@@ -181,6 +199,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     auto read_a = [&](const char* tile, int h) {
 #pragma unroll
         for (int i = 0; i < TMH; ++i) read_op(tile + h * HA + i * 2048, a_off, fa[i]);
+    };
+    auto read_a0_early = [&](const char* tile) {      // row tiles [0, TMP) of A0 -> fan
+#pragma unroll
+        for (int i = 0; i < TMP; ++i) read_op(tile + i * 2048, a_off, fan[i]);
+    };
+    auto read_a0_rest = [&](const char* tile) {       // row tiles [TMP, TMH) of A0 -> fa
+#pragma unroll
+        for (int i = TMP; i < TMH; ++i) read_op(tile + i * 2048, a_off, fa[i]);
     };
     auto read_b0 = [&](const char* tile) {
 #pragma unroll
@@ -197,12 +223,13 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
         for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
             for (int i = 0; i < TMH; ++i) {
+                const Frag& a = (mh == 0 && i < TMP) ? fan[i < TMP ? i : 0][kk] : fa[i][kk];      // A0's first row tiles came a phase early
                 if constexpr (nh == 0) {
 #pragma unroll
-                    for (int j = 0; j < TN0; ++j) Mma<T>::run(acc[mh * TMH + i][j], fb0[j][kk], fa[i][kk]);
+                    for (int j = 0; j < TN0; ++j) Mma<T>::run(acc[mh * TMH + i][j], fb0[j][kk], a);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < TN1; ++j) Mma<T>::run(acc[mh * TMH + i][TN0 + j], fb1[j][kk], fa[i][kk]);
+                    for (int j = 0; j < TN1; ++j) Mma<T>::run(acc[mh * TMH + i][TN0 + j], fb1[j][kk], a);
                 }
             }
         __builtin_amdgcn_s_setprio(0);
@@ -221,10 +248,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0)
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
+#ifdef ST_PROBE8
+    pr_t1 = __builtin_readcyclecounter();
+#endif
+    read_a0_early(lds);                               // (A0 of K tile 0 has landed: the prologue's wait and barrier)
     for (int kt = 0; kt < nk; ++kt) {
         const char* tile = lds + (kt & 1) * TILE_B;
         // phase 0: (A0, B0); refill B1 of tile kt+1 (last read in phase 1 of tile kt-1)
-        read_a(tile, 0); read_b0(tile);
+        read_a0_rest(tile); read_b0(tile);
         issue_half(kt + 1, 3);
         ST_PHASE_SYNC();
         quadrant(I0{}, I0{});
@@ -241,7 +272,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
         ST_PHASE_SYNC();
         quadrant(I1{}, I1{});
         ST_PHASE_END();
-        // phase 3: (A1, B0) from registers; refill B0 of tile kt+2 (last read in phase 0 of this tile)
+        // phase 3: (A1, B0) from registers; the first row tiles of A0 of tile kt+1 (issued in phase 2 of tile kt-1: five phases
+        // back, landed for every wave - the same distance as every other read of the loop; behind the last K tile this reads
+        // stale LDS that nobody multiplies); refill B0 of tile kt+2 (last read in phase 0 of this tile)
+        read_a0_early(lds + ((kt + 1) & 1) * TILE_B);
         issue_half(kt + 2, 2);
         ST_PHASE_SYNC();
         quadrant(I1{}, I0{});
@@ -252,8 +286,22 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     if (wave < 4) __builtin_amdgcn_s_barrier();      // barrier counts of the two halves are equal again
     wait_vmcnt<0>();                                  // no LDS-DMA may outlive the workgroup's LDS allocation
     __builtin_amdgcn_s_barrier();
-    staged_epilogue<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, 2 * TILE_B, !LNF, sizeof(T) == 1>(p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds,
-                                                                        reinterpret_cast<const float2*>(lnrows));
+#ifdef ST_PROBE8
+    pr_t2 = __builtin_readcyclecounter();
+#endif
+    if constexpr (DIRECT)
+        direct_epilogue<TO, TM, TN, WTM, WTN, WGM, WGN, GEGLU, LNF>(p, acc, m0, n0, tile_n, wm, wn, r16, q, lds, reinterpret_cast<const float2*>(lnrows),
+                                                                    lds_addr_of(lds) + 2 * TILE_B + BM * 8);
+    else
+        staged_epilogue<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, 2 * TILE_B, !LNF, sizeof(T) == 1>(p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds,
+                                                                            reinterpret_cast<const float2*>(lnrows));
+#ifdef ST_PROBE8
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores acknowledged: the block's whole life
+    if (p.partial && t == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.partial) + 65536) + (size_t)bid * 4;
+        o[0] = pr_t0; o[1] = pr_t1; o[2] = pr_t2; o[3] = __builtin_readcyclecounter();
+    }
+#endif
 }
 
 // the two shapes of gemm8p: 256 (2 x 4 waves) and 160 columns (4 x 2 waves)
@@ -263,10 +311,10 @@ static inline bool gemm8p_applies(const GemmArgs& a, int bn, int kb = 64) {
            !(a.epi & ST_EPI_ROWBIAS) && (!a.row_stats || !(a.epi & ST_EPI_GEGLU));
 }
 
-template <typename T, bool GEGLU, bool LNF, int BN, int WGM, int WGN>
+template <typename T, bool GEGLU, bool LNF, int BN, int WGM, int WGN, bool DIRECT = false>
 static void gemm8p_go(const GemmArgs& a, hipStream_t st) {
     constexpr size_t lds = 2 * (size_t)(2 * 128 * 128 + BN * 128) + 256 * 8 + 1024;
-    auto kfn = gemm8p_kernel<T, GEGLU, LNF, BN, WGM, WGN>;
+    auto kfn = gemm8p_kernel<T, GEGLU, LNF, BN, WGM, WGN, DIRECT>;
     static unsigned long long lds_ok = 0;
     ensure_dynamic_lds(kfn, lds, &lds_ok);
     GemmArgs b = a;
@@ -292,9 +340,27 @@ static void gemm8p_go(const GemmArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(kfn, dim3(main_blocks + b.helper_blocks), dim3(512), lds, st, b);
 }
 
+// Does the launch take the direct (register) epilogue?  Its feature set has an instance (epilogue.h: direct_flags) and every
+// 16-byte access is aligned; 16-bit outputs only (the e4m3 instances keep the staged form: scales, e4m3 copies).
+template <typename T>
+static inline bool gemm8p_direct(const GemmArgs& a, bool tall) {
+    if constexpr (sizeof(T) != 2) return false;
+    static const bool off = dev_env_int("ST_8P_STAGED", 0) != 0;      // (developer A/B)
+    if (off || direct_flags(a, a.ln_c != nullptr, tall) < 0) return false;
+    auto al16 = [](const void* p_) { return ((uintptr_t)p_ & 15) == 0; };
+    return a.ldc % 8 == 0 && al16(a.C) && (!(a.epi & ST_EPI_RESIDUAL) || (a.ldr % 8 == 0 && al16(a.residual))) && al16(a.bias) && al16(a.ln_c) && al16(a.ln_d);
+}
+
 template <typename T, int BN, int WGM, int WGN>
 static void gemm8p_launch(const GemmArgs& a, hipStream_t st) {
     const bool geglu = a.epi & ST_EPI_GEGLU;
+    if constexpr (sizeof(T) == 2) {
+        if (gemm8p_direct<T>(a, 256 / WGM / 16 >= 8)) {      // (tall = 128-row wave tiles: TM = 8)
+            if (a.ln_c) { if (geglu) gemm8p_go<T, true, true, BN, WGM, WGN, true>(a, st); else gemm8p_go<T, false, true, BN, WGM, WGN, true>(a, st); }
+            else { if (geglu) gemm8p_go<T, true, false, BN, WGM, WGN, true>(a, st); else gemm8p_go<T, false, false, BN, WGM, WGN, true>(a, st); }
+            return;
+        }
+    }
     if (a.ln_c) { if (geglu) gemm8p_go<T, true, true, BN, WGM, WGN>(a, st); else gemm8p_go<T, false, true, BN, WGM, WGN>(a, st); }
     else { if (geglu) gemm8p_go<T, true, false, BN, WGM, WGN>(a, st); else gemm8p_go<T, false, false, BN, WGM, WGN>(a, st); }
 }

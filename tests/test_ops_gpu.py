@@ -91,6 +91,73 @@ def test_linear(gpu, dtype, M, K, N):
 
 
 @pytest.mark.parametrize("dtype", HALF_DTYPES)
+@pytest.mark.parametrize("M,K,N,geglu", [(4096, 1280, 3840, False),      # 240 tiles of 256 x 256 (wave tiles 128 x 64: two column pairs)
+                                         (1024, 1280, 10240, False),     # 256 tiles of 256 x 160 (wave tiles 64 x 80: pair, single tile, pair)
+                                         (8192, 640, 640, False),        # 256 x 160 with a short K (ten K tiles)
+                                         (4096, 1280, 5120, True),       # GEGLU on 256 x 256: values and gates of 32 output columns per wave
+                                         (1024, 1280, 5120, True)])      # GEGLU on 256 x 160: the half tile whose gates come from lane + 32
+def test_linear_eight_phase_register_epilogue(gpu, dtype, M, K, N, geglu):
+    """The large Linear problems run on the eight-phase kernel; round 5 stores their results straight from the accumulator
+    registers over a permuted staging of W (csrc/epilogue.h, direct epilogue): every feature set with a direct instance, both
+    wave-tile shapes, against the fp32 product of the rounded operands; the LayerNorm partials against direct sums of the output."""
+    rows = 2 * N if geglu else N
+    x, w, b = rnd("l8.x", (M, K)), rnd("l8.w", (rows, K)) * K ** -0.5, rnd("l8.b", (rows,))
+    xr, wr, br = rounded(x, dtype), rounded(w, dtype), rounded(b, dtype)
+    xg, wg, bg = x.to(gpu, dtype), w.to(gpu, dtype), b.to(gpu, dtype)
+    if geglu:
+        ref = orc.geglu(F.linear(xr, wr, br))
+        assert_close(ops.linear(xg, wg, bg, geglu=True), ref, dtype, "linear+bias+geglu")
+        return
+    base = F.linear(xr, wr)
+    assert_close(ops.linear(xg, wg, None), base, dtype, "linear")
+    assert_close(ops.linear(xg, wg, bg), base + br, dtype, "linear+bias")
+    r = rnd("l8.r", (M, N))
+    rg = r.to(gpu, dtype)
+    assert_close(ops.linear(xg, wg, bg, residual=rg), base + br + rounded(r, dtype), dtype, "linear+bias+residual")
+    for res in (None, rg):
+        out, stats = ops.linear(xg, wg, bg, residual=res, emit_stats=True)
+        plain = ops.linear(xg, wg, bg, residual=res)
+        assert torch.equal(out, plain), "emitting the row partials must not change the output"
+        o = out.double().cpu()
+        s = stats.buf.double().sum(1).cpu()
+        assert torch.allclose(s[:, 0], o.sum(1), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(s[:, 1], (o ** 2).sum(1), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", HALF_DTYPES)
+def test_next_weights_hints_do_not_change_results(gpu, dtype):
+    """Inside a compiled module every GEMM-shaped launch is told which weights the NEXT launch reads and touches them
+    (ops.WeightPlan); the operator tests above launch without a plan.  Here a three-launch step (LayerNorm-folded q|k|v on
+    256 x 256 tiles, a GEGLU projection on 256 x 160 tiles, a small projection with the fragment epilogue) runs under a plan:
+    recording pass, then hinted passes - the same bits as without hints.  (Round 5: the register-destination touches of the
+    new register epilogue were overwritten in flight; only the full denoise step, where hints are on, showed it.)"""
+    M, K = 4096, 1280
+    x = rnd("nw.x", (M, K)) * 1.3 + 0.2
+    g, be = rnd("nw.g", (K,)) * 0.2 + 1.0, rnd("nw.b", (K,)) * 0.2
+    w1, b1 = rnd("nw.w1", (3840, K)) * K ** -0.5, rnd("nw.b1", (3840,))
+    w2, b2 = rnd("nw.w2", (10240, K)) * K ** -0.5, rnd("nw.b2", (10240,))
+    w3, b3 = rnd("nw.w3", (K, K)) * K ** -0.5, rnd("nw.b3", (K,))
+    xg, stats = ops.linear(x.to(gpu, dtype), torch.eye(K).to(gpu, dtype), None, emit_stats=True)
+    wf1, c1, d1 = ops.fold_layer_norm(g.to(gpu, dtype), be.to(gpu, dtype), w1.to(gpu, dtype), b1.to(gpu, dtype))
+    wf2, c2, d2 = ops.fold_layer_norm(g.to(gpu, dtype), be.to(gpu, dtype), w2.to(gpu, dtype), b2.to(gpu, dtype))
+    w3g, b3g = w3.to(gpu, dtype), b3.to(gpu, dtype)
+
+    def step():
+        return (ops.ln_linear(xg, stats, wf1, c1, d1, 1e-5), ops.ln_linear(xg[:1024], stats_small, wf2, c2, d2, 1e-5, geglu=True),
+                ops.linear(xg, w3g, b3g, residual=xg))
+
+    xs, stats_small = ops.linear(x[:1024].to(gpu, dtype), torch.eye(K).to(gpu, dtype), None, emit_stats=True)
+    plain = step()
+    ctx = ops.ExecContext()
+    for _ in range(4):                   # pass 1 records the launch order, passes 2.. carry the hints
+        with ctx.step():
+            hinted = step()
+        for a, b in zip(plain, hinted):
+            assert torch.equal(a, b)
+    assert ctx.plan.state == "replay" and len(ctx.plan.entries) == 3
+
+
+@pytest.mark.parametrize("dtype", HALF_DTYPES)
 def test_split_k_is_bit_reproducible(gpu, dtype):
     """The in-launch K split sums its slabs in slice order whichever block finishes last: repeated
     launches (and launches interleaved with other split GEMMs that share the workspace) agree bitwise."""

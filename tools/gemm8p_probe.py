@@ -1,0 +1,41 @@
+"""Developer probe of the eight-phase GEMM: cycle stamps (s_memtime) of wave 0 of every block - entry, first K tile landed,
+K loop done, stores acknowledged - from a -DST_PROBE8 build:
+    tools/build_one_variant.sh probe8 gemm_dense_bf16.hip gemm_api.hip -DST_PROBE8 -DST_DEV_CONFIGS
+    ST_VARIANT=probe8 python tools/gemm8p_probe.py [M K N [geglu]] ...
+Prints the median / max over blocks of prologue, loop (and per K tile), epilogue in cycles, the launch's span, and its time."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools.op_bench import timeit, rnd  # noqa: E402  (selects the ST_VARIANT build)
+from stabletriton_amd import ops  # noqa: E402
+
+shapes = [(4096, 1280, 3840, 0), (4096, 1280, 5120, 1), (1024, 1280, 5120, 1), (16384, 640, 2560, 1), (16384, 2560, 640, 0)]
+if len(sys.argv) >= 4:
+    shapes = [(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 0)]
+ctx = ops.ExecContext()
+with ctx:
+    for M, K, N, geglu in shapes:
+        rows = 2 * N if geglu else N
+        x, w, b = rnd(M, K), rnd(rows, K) * K ** -0.5, rnd(rows)
+        ws = ctx.gemm_workspace(x.device)
+        for _ in range(3):
+            ops.linear(x, w, b, geglu=bool(geglu))
+        torch.cuda.synchronize()
+        ws[65536:65536 + 32 * 4096].zero_()
+        ops.linear(x, w, b, geglu=bool(geglu))
+        torch.cuda.synchronize()
+        st = ws[65536:65536 + 32 * 4096].view(torch.int64).view(-1, 4).cpu()
+        st = st[st[:, 0] != 0]
+        if st.numel() == 0:
+            print(f"M={M} K={K} N={N} g={geglu}: no stamps (not on the eight-phase kernel, or not a probe build)")
+            continue
+        pro, loop, epi = (st[:, 1] - st[:, 0]).float(), (st[:, 2] - st[:, 1]).float(), (st[:, 3] - st[:, 2]).float()
+        span = int(st[:, 3].max() - st[:, 0].min())
+        us = timeit(lambda: ops.linear(x, w, b, geglu=bool(geglu)), iters=20)
+        nk = K // 64
+        print(f"M={M} K={K} N={N} g={geglu}: {st.shape[0]} blocks | prologue med {pro.median():.0f} max {pro.max():.0f} | loop med {loop.median():.0f} "
+              f"({loop.median() / nk:.0f} / K tile) max {loop.max():.0f} | epilogue med {epi.median():.0f} max {epi.max():.0f} | first entry -> last exit {span} cyc | {us:.1f} us",
+              flush=True)
