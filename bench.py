@@ -322,7 +322,8 @@ def extras(args, model, gm, loop, mode, dtype, dev, n_sched, cond, x):
             fam, census_ms, _, _ = census(lp)
             n_launch = sum(f["launches"] for f in fam.values())
             boundary = max(ms - census_ms, 0.0) / n_launch
-            roofs = {k: roofline_of(k, v, boundary, tag="_strict") for k, v in fam.items()}      # (rocprof / counters: profiles/rNN_strict_*)
+            strict_prof = args.batch == 1 and args.model == "base" and args.img2img is None      # (profiles/rNN_strict_* is the bs=1 SDXL-base strict step)
+            roofs = {k: roofline_of(k, v, boundary, committed=strict_prof, tag="_strict") for k, v in fam.items()}
             for k, r in roofs.items():
                 r["kernel"] = STRICT_KERNEL.get(k, r["kernel"])
             rec["roofline"] = roofs[max(fam, key=lambda k: fam[k]["ms"])]
@@ -527,7 +528,8 @@ def main():
                        "weight_broadcasts": n_bcast},
             "finite": finite, "capture_s": round(t_capture, 2), "weights_s": round(t_fill, 2),
             "prompt_setup_ms": round(prompt_setup_ms, 2), "steps_per_image": steps_per_image,
-            "it_per_s_incl_prompt_setup": round(world * args.batch * n_sched / (n_sched * ms_per_step * 1e-3 + prompt_setup_ms * 1e-3), 3),
+            # (the prompt setup is paid once per IMAGE: an img2img trajectory runs steps_per_image steps, not the whole schedule)
+            "it_per_s_incl_prompt_setup": round(world * args.batch * steps_per_image / (steps_per_image * ms_per_step * 1e-3 + prompt_setup_ms * 1e-3), 3),
         }
         if world > 1:
             result["bcast_s"] = round(t_bcast, 3)
@@ -545,10 +547,20 @@ def main():
                 boundary_ms = max(ms_per_step - census_ms, 0.0) / n_launch
                 # the committed rocprofv3 / counter summaries beside the live numbers: those of the same command (bf16 headline,
                 # strict mode, refiner img2img fp8, bs=4); other variants of the run carry none
-                tag = "_strict" if dtype == torch.float32 else ("_refiner" if (args.model == "refiner" and args.fp8) else "")
-                if not tag and args.model == "base" and not args.fp8 and args.batch == 4 and dtype == torch.bfloat16:
+                # a committed rocprof / counter profile is attached only when batch, model, element type and workload all match
+                # the command it was taken from (tools/round_profiles.sh): headline, strict bs=1, config #3, refiner img2img fp8
+                base16 = args.model == "base" and not args.fp8 and args.img2img is None and dtype == torch.bfloat16
+                tag = None
+                if base16 and args.batch == 1:
+                    tag = ""
+                elif base16 and args.batch == 4:
                     tag = "_b4"                     # (BASELINE config #3)
-                plain = tag or (args.model == "base" and not args.fp8 and args.batch == 1 and dtype == torch.bfloat16)
+                elif args.model == "base" and not args.fp8 and args.img2img is None and dtype == torch.float32 and args.batch == 1:
+                    tag = "_strict"
+                elif args.model == "refiner" and args.fp8 and args.img2img is not None and args.batch == 1 and dtype == torch.bfloat16:
+                    tag = "_refiner"
+                plain = tag is not None
+                tag = tag or ""
                 roofs = {k: roofline_of(k, v, boundary_ms, committed=bool(plain), tag=tag) for k, v in fam.items()}
                 if dtype == torch.float32:
                     for k, r in roofs.items():

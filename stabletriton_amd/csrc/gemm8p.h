@@ -61,7 +61,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     const int tile_m = tid.tile_m, tile_n = tid.tile_n;
     const int m0 = tile_m * BM, n0 = tile_n * BNO;
 #ifdef ST_PROBE8      // developer build (tools/gemm8p_probe.py): cycle stamps of wave 0 into the split-K workspace, 32 bytes per block
-    unsigned long long pr_t0 = __builtin_readcyclecounter(), pr_t1 = 0, pr_t2 = 0;
+    unsigned long long pr_t0 = __builtin_readcyclecounter(), pr_t1 = 0, pr_t2 = 0, pr_r0 = __builtin_amdgcn_s_memrealtime();      // (realtime: constant 100 MHz)
 #endif
     const T* __restrict__ Ap = (const T*)p.A;
     const T* __restrict__ Wp = (const T*)p.W;
@@ -298,8 +298,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
 #ifdef ST_PROBE8
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores acknowledged: the block's whole life
     if (p.partial && t == 0) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.partial) + 65536) + (size_t)bid * 4;
-        o[0] = pr_t0; o[1] = pr_t1; o[2] = pr_t2; o[3] = __builtin_readcyclecounter();
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.partial) + 65536) + (size_t)bid * 8;
+        o[0] = pr_t0; o[1] = pr_t1; o[2] = pr_t2; o[3] = __builtin_readcyclecounter(); o[4] = pr_r0; o[5] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
 }

@@ -331,13 +331,40 @@ def _arm_split(out: torch.Tensor, rows: int, cols: int):
     return img
 
 
+class _Armed:
+    """`with _Armed(_arm_split(...)) as img:` around the launch that is to write the image: an exception raised between the arm and
+    the launch (argument conversion, a rejected shape) disarms, so the arm cannot outlive the frame that owns `img` and make a
+    LATER launch of the same shape write into memory the allocator has handed to somebody else."""
+    __slots__ = ("img",)
+
+    def __init__(self, img):
+        self.img = img
+
+    def __enter__(self):
+        return self.img
+
+    def __exit__(self, et, ev, tb):
+        if et is not None and self.img is not None:
+            _C.load().st_arm_split_output(None, 0, 0)
+        return False
+
+
+def _split_notes(device, create: bool = False):
+    """The notes of the current context; the shared default context (no plan, never left, used by any thread) keeps none of its
+    own: eager strict-mode calls outside a compiled module note per THREAD (bounded: the last few outputs)."""
+    ctx = current_context(device)
+    holder = ctx.__dict__ if ctx.plan is not None else _tls.__dict__
+    if create:
+        return holder.setdefault("recent_splits", [])
+    return holder.get("recent_splits", ())
+
+
 def _note_split(out: torch.Tensor, img: Optional[torch.Tensor], rows: int, cols: int) -> None:
     if img is None:
         return
-    ctx = current_context(out.device)
-    if ctx.plan is None and torch.cuda.is_current_stream_capturing():
-        return          # the shared default context is never left: it must not keep tensors of somebody's graph pool alive
-    lst = ctx.__dict__.setdefault("recent_splits", [])
+    if current_context(out.device).plan is None and torch.cuda.is_current_stream_capturing():
+        return          # no context of its own: the notes must not keep tensors of somebody's graph pool alive
+    lst = _split_notes(out.device, create=True)
     lst.append((out, out.data_ptr(), rows, cols, img, out._version))      # (the version: an in-place update of the output later makes the image stale)
     del lst[:-_RECENT_SPLITS]
 
@@ -347,7 +374,7 @@ def _image_columns(t: torch.Tensor, rows: int, ld: int):
     whose rows are ld values long (the K / V slices of the fused q|k|v projection), else None."""
     if not EMIT_SPLIT:
         return None
-    for ent in reversed(current_context(t.device).__dict__.get("recent_splits", ())):
+    for ent in reversed(_split_notes(t.device)):
         off = t.data_ptr() - ent[1]
         if ent[2] == rows and ent[3] == ld and 0 <= off < 4 * ld and off % 128 == 0 and t._version == ent[5]:
             return ent[4], off // 4
@@ -357,7 +384,7 @@ def _image_columns(t: torch.Tensor, rows: int, ld: int):
 def _split_of(x: torch.Tensor, rows: int, cols: int, ld: int) -> torch.Tensor:
     """The split image of the (rows, cols) fp32 matrix at x's address (row stride ld): a producer's, if one was noted, else made now."""
     if ld == cols:
-        for ent in reversed(current_context(x.device).__dict__.get("recent_splits", ())):
+        for ent in reversed(_split_notes(x.device)):
             if ent[1] == x.data_ptr() and ent[2] == rows and ent[3] == cols and x._version == ent[5]:
                 return ent[4]
     x2 = x if (x.dim() == 2 and x.shape[1] == cols) else x.as_strided((rows, cols), (ld, 1))
@@ -414,10 +441,10 @@ def group_norm(x: torch.Tensor, num_groups: int, weight: torch.Tensor, bias: tor
     # scratch for the partial statistics: allocated per call from torch's caching allocator (stream-ordered; under
     # graph capture it belongs to the graph's private pool, so replays never alias a buffer somebody else owns)
     ws = torch.empty(lib.st_group_norm_workspace_bytes(N, Cc, HW, num_groups), dtype=torch.uint8, device=x.device)
-    img = _arm_split(y, N * HW, Cc) if layout == _C.ST_NHWC else None      # strict mode: the conv / proj_in behind it reads the split image
-    _C.check(lib.st_group_norm(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups,
-                               float(eps), int(bool(silu)), layout, _C.dtype_code(x.dtype), ws.data_ptr(),
-                               _C.stream_ptr()), "group_norm")
+    with _Armed(_arm_split(y, N * HW, Cc) if layout == _C.ST_NHWC else None) as img:      # strict mode: the conv / proj_in behind it reads the split image
+        _C.check(lib.st_group_norm(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups,
+                                   float(eps), int(bool(silu)), layout, _C.dtype_code(x.dtype), ws.data_ptr(),
+                                   _C.stream_ptr()), "group_norm")
     _note_split(y, img, N * HW, Cc)
     return y
 
@@ -459,12 +486,12 @@ def group_norm_from_stats(x: torch.Tensor, sources, num_groups: int, weight: tor
     ws = torch.empty(lib.st_group_norm_workspace_bytes(N, Cc, HW, num_groups), dtype=torch.uint8, device=x.device)
     s0 = sources[0]
     s1 = sources[1] if len(sources) == 2 else None
-    img = _arm_split(y, N * HW, Cc)
-    _C.check(lib.st_group_norm_from_stats(x.data_ptr(), w.data_ptr(),
-                    b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups, float(eps), int(bool(silu)), _C.dtype_code(x.dtype),
-                    s0.buf.data_ptr(), s0.channels, s0.rows, None if s1 is None else s1.buf.data_ptr(),
-                    0 if s1 is None else s1.channels, 0 if s1 is None else s1.rows, ws.data_ptr(), _C.stream_ptr()),
-             "group_norm_from_stats")
+    with _Armed(_arm_split(y, N * HW, Cc)) as img:
+        _C.check(lib.st_group_norm_from_stats(x.data_ptr(), w.data_ptr(),
+                        b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups, float(eps), int(bool(silu)), _C.dtype_code(x.dtype),
+                        s0.buf.data_ptr(), s0.channels, s0.rows, None if s1 is None else s1.buf.data_ptr(),
+                        0 if s1 is None else s1.channels, 0 if s1 is None else s1.rows, ws.data_ptr(), _C.stream_ptr()),
+                 "group_norm_from_stats")
     _note_split(y, img, N * HW, Cc)
     return y
 
@@ -492,11 +519,11 @@ def group_norm_from_stats_cat(x0: torch.Tensor, x1: torch.Tensor, sources, num_g
     b = bias if bias.dtype == x0.dtype else bias.to(x0.dtype)
     ws = torch.empty(lib.st_group_norm_workspace_bytes(N, Cc, HW, num_groups), dtype=torch.uint8, device=x0.device)
     s0, s1 = sources
-    img = _arm_split(y, N * HW, Cc)
-    _C.check(lib.st_group_norm_from_stats_cat(x0.data_ptr(), x1.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups,
-                                              float(eps), int(bool(silu)), _C.dtype_code(x0.dtype), s0.buf.data_ptr(), s0.channels, s0.rows,
-                                              s1.buf.data_ptr(), s1.channels, s1.rows, ws.data_ptr(), _C.stream_ptr()),
-             "group_norm_from_stats_cat")
+    with _Armed(_arm_split(y, N * HW, Cc)) as img:
+        _C.check(lib.st_group_norm_from_stats_cat(x0.data_ptr(), x1.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, Cc, HW, num_groups,
+                                                  float(eps), int(bool(silu)), _C.dtype_code(x0.dtype), s0.buf.data_ptr(), s0.channels, s0.rows,
+                                                  s1.buf.data_ptr(), s1.channels, s1.rows, ws.data_ptr(), _C.stream_ptr()),
+                 "group_norm_from_stats_cat")
     _note_split(y, img, N * HW, Cc)
     return y
 
@@ -610,25 +637,25 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     act8 = None
     # strict mode: an output that a LayerNorm-folded projection (emit_stats) or the feed-forward output projection (geglu) reads
     # next leaves its split image too
-    img = _arm_split(out, M, N) if (code == _C.ST_F32S and (emit_stats or geglu)) else None
-    if emit_q8 is None:
-        _C.check(lib.st_linear(x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
-                        lda, N, ldr, rows_per_image, epi, code, gws.data_ptr(), gws.numel(),
-                        _ptr(stats), 0 if stats is None else stats.shape[1],
-                        None if chunks is None else ctypes.byref(chunks), _ptr(cbuf), ctiles or 0,
-                        None if crows is None else ctypes.byref(crows), nxt_p, nxt_b, _C.stream_ptr()), "linear")
-        _note_split(out, img, M, N)
-    else:
-        sc = fp8_scales(x.device)
-        idx = sc.site(emit_q8)
-        q8 = torch.empty((M, N), dtype=torch.uint8, device=x.device)
-        act8 = Fp8Act(q8, idx, out.shape)
-        _C.check(lib.st_linear_emit8(x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
-                        lda, N, ldr, rows_per_image, epi, _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(),
-                        _ptr(stats), 0 if stats is None else stats.shape[1],
-                        None if chunks is None else ctypes.byref(chunks), _ptr(cbuf), ctiles or 0,
-                        None if crows is None else ctypes.byref(crows), q8.data_ptr(), N, sc.inv_scale[idx:].data_ptr(), sc.amax[idx:].data_ptr(),
-                        nxt_p, nxt_b, _C.stream_ptr()), "linear_emit8")
+    with _Armed(_arm_split(out, M, N) if (code == _C.ST_F32S and (emit_stats or geglu)) else None) as img:
+        if emit_q8 is None:
+            _C.check(lib.st_linear(x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
+                            lda, N, ldr, rows_per_image, epi, code, gws.data_ptr(), gws.numel(),
+                            _ptr(stats), 0 if stats is None else stats.shape[1],
+                            None if chunks is None else ctypes.byref(chunks), _ptr(cbuf), ctiles or 0,
+                            None if crows is None else ctypes.byref(crows), nxt_p, nxt_b, _C.stream_ptr()), "linear")
+            _note_split(out, img, M, N)
+        else:
+            sc = fp8_scales(x.device)
+            idx = sc.site(emit_q8)
+            q8 = torch.empty((M, N), dtype=torch.uint8, device=x.device)
+            act8 = Fp8Act(q8, idx, out.shape)
+            _C.check(lib.st_linear_emit8(x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K,
+                            lda, N, ldr, rows_per_image, epi, _C.dtype_code(x.dtype), gws.data_ptr(), gws.numel(),
+                            _ptr(stats), 0 if stats is None else stats.shape[1],
+                            None if chunks is None else ctypes.byref(chunks), _ptr(cbuf), ctiles or 0,
+                            None if crows is None else ctypes.byref(crows), q8.data_ptr(), N, sc.inv_scale[idx:].data_ptr(), sc.amax[idx:].data_ptr(),
+                            nxt_p, nxt_b, _C.stream_ptr()), "linear_emit8")
     if act8 is not None:
         if emit_colstats:
             raise BackendError("linear: emit_q8 with emit_colstats is not supported")
@@ -669,10 +696,10 @@ def ln_linear(x: torch.Tensor, stats: "RowStats", w_folded: torch.Tensor, c: tor
     nxt_p, nxt_b = _next_weights(w_folded)
     # strict mode: the GEGLU projection's output (read by ff.net.2) and, on request, the q|k|v projection's (its K and V columns
     # are attention operands) leave their split images
-    img = _arm_split(out, M, N) if (code == _C.ST_F32S and (geglu or emit_split)) else None
-    _C.check(lib.st_ln_linear(x2.data_ptr(), stats.buf.data_ptr(), stats.chunks, w_folded.data_ptr(),
-                    c.data_ptr(), d.data_ptr(), out.data_ptr(), M, N, K,
-                    lda, N, float(eps), _C.EPI_GEGLU if geglu else 0, code, nxt_p, nxt_b, _C.stream_ptr()), "ln_linear")
+    with _Armed(_arm_split(out, M, N) if (code == _C.ST_F32S and (geglu or emit_split)) else None) as img:
+        _C.check(lib.st_ln_linear(x2.data_ptr(), stats.buf.data_ptr(), stats.chunks, w_folded.data_ptr(),
+                        c.data_ptr(), d.data_ptr(), out.data_ptr(), M, N, K,
+                        lda, N, float(eps), _C.EPI_GEGLU if geglu else 0, code, nxt_p, nxt_b, _C.stream_ptr()), "ln_linear")
     _note_split(out, img, M, N)
     return out
 
@@ -908,13 +935,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int,
     out = torch.empty((B, T, Cc), dtype=q.dtype, device=q.device)
     ki = _image_columns(k_, B * S, ldk) if q.dtype == torch.float32 else None      # strict mode: K / V columns of a producer's split image
     vi = _image_columns(v_, B * S, ldv) if ki is not None else None
-    img = _arm_split(out, B * T, Cc)              # strict mode: the output projection reads the split image
-    if ki is not None and vi is not None and D == 64:
-        _C.check(lib.st_attention_split(q_.data_ptr(), ki[0].data_ptr() + 4 * ki[1], vi[0].data_ptr() + 4 * vi[1], out.data_ptr(), B, T, S, num_heads, D,
-                                        ldq, ki[0].shape[1], vi[0].shape[1], Cc, float(scale), _C.stream_ptr()), "attention_split")
-    else:
-        _C.check(lib.st_attention(q_.data_ptr(), k_.data_ptr(), v_.data_ptr(), out.data_ptr(), B, T, S, num_heads, D,
-                                  ldq, ldk, ldv, Cc, float(scale), _C.dtype_code(q.dtype), _C.stream_ptr()), "attention")
+    with _Armed(_arm_split(out, B * T, Cc)) as img:              # strict mode: the output projection reads the split image
+        if ki is not None and vi is not None and D == 64:
+            _C.check(lib.st_attention_split(q_.data_ptr(), ki[0].data_ptr() + 4 * ki[1], vi[0].data_ptr() + 4 * vi[1], out.data_ptr(), B, T, S, num_heads, D,
+                                            ldq, ki[0].shape[1], vi[0].shape[1], Cc, float(scale), _C.stream_ptr()), "attention_split")
+        else:
+            _C.check(lib.st_attention(q_.data_ptr(), k_.data_ptr(), v_.data_ptr(), out.data_ptr(), B, T, S, num_heads, D,
+                                      ldq, ldk, ldv, Cc, float(scale), _C.dtype_code(q.dtype), _C.stream_ptr()), "attention")
     _note_split(out, img, B * T, Cc)
     return out
 

@@ -19,7 +19,7 @@ import torch
 from . import ops
 
 _lib = torch.library.Library("st", "DEF")
-_lib.define("attention(Tensor q, Tensor k, Tensor v, int num_heads, float scale) -> Tensor")
+_lib.define("attention(Tensor q, Tensor k, Tensor v, int num_heads, float scale, int head_dim=64) -> Tensor")      # head_dim: 16 / 32 / 64 / 128 (st_attention)
 _lib.define("group_norm_silu(Tensor x, int num_groups, Tensor weight, Tensor bias, float eps, bool silu) -> Tensor")
 _lib.define("geglu(Tensor state, Tensor gate) -> Tensor")
 _lib.define("linear_act(Tensor x, Tensor weight, Tensor? bias, bool silu, bool geglu=False, Tensor? residual=None) -> Tensor")
@@ -29,7 +29,18 @@ _lib.define("layer_norm(Tensor x, Tensor weight, Tensor bias, float eps) -> Tens
 
 
 # ---- HIP kernels: the C-ABI launchers --------------------------------------------------------------
-def _attention(q, k, v, num_heads, scale):
+ATTENTION_HEAD_DIMS = (16, 32, 64, 128)      # what st_attention takes (include/stabletriton_amd.h; kernels/attention_fa2.py:118-123)
+
+
+def _check_attention(q, k, v, num_heads, head_dim):
+    torch._check(q.dim() == 3 and k.dim() == 3 and v.dim() == 3, lambda: "attention expects (B, T, H*D) tensors")
+    torch._check(head_dim in ATTENTION_HEAD_DIMS, lambda: f"attention: head_dim {head_dim} not in {ATTENTION_HEAD_DIMS}")
+    torch._check(q.shape[-1] == num_heads * head_dim and k.shape[-1] == q.shape[-1] and v.shape == k.shape,
+                 lambda: f"attention: the last dimension must be num_heads * head_dim = {num_heads * head_dim} on q, k and v")
+
+
+def _attention(q, k, v, num_heads, scale, head_dim=64):
+    _check_attention(q, k, v, num_heads, head_dim)
     return ops.attention(q, k, v, num_heads, scale)
 
 
@@ -59,9 +70,8 @@ for _name, _fn in (("attention", _attention), ("group_norm_silu", _group_norm_si
 
 
 # ---- Meta kernels: shapes, dtypes, layouts ---------------------------------------------------------
-def _meta_attention(q, k, v, num_heads, scale):
-    torch._check(q.dim() == 3 and k.dim() == 3 and v.dim() == 3, lambda: "attention expects (B, T, H*D) tensors")
-    torch._check(q.shape[-1] == num_heads * 64, lambda: "head_dim must be 64")
+def _meta_attention(q, k, v, num_heads, scale, head_dim=64):
+    _check_attention(q, k, v, num_heads, head_dim)
     return q.new_empty(q.shape)
 
 

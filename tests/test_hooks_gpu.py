@@ -21,10 +21,12 @@ from tests.util import golden
 pytestmark = pytest.mark.gpu
 ABS_TOL_STRICT = 1e-3
 # Classifier-free guidance forms eps = eps_neg + g (eps_pos - eps_neg) = 5 eps_pos - 4 eps_neg at g = 5: whatever separates two
-# fp32 implementations of the UNet (summation order: 1e-5 per step, tests/test_unet_gpu.py F1) enters the latent nine times
-# larger, fifty times over.  Without guidance the 50-step final latent agrees to 6e-5 (F3, bound 1e-3); with it the measured
-# deviation is 1.0e-3 on a latent of magnitude 51 (2e-5 relative), so this protocol is gated at 2e-3 and the value is printed.
-ABS_TOL_STRICT_CFG = 2e-3
+# fp32 implementations of the UNet enters the latent nine times larger, fifty times over.  Round 5 derives the bound instead of
+# asserting it: oracle/make_golden.py f3_cfg_f64 ran the REFERENCE module in float64 through this protocol; the reference's own
+# fp32 run deviates 9.3e-5 from that (2.4e-5 without guidance), so the bound is max(1e-3, 2 x 9.3e-5) = north_star's 1e-3,
+# measured against the float64 vector.
+def cfg_strict_bound():
+    return max(ABS_TOL_STRICT, 2.0 * float(golden("f3_cfg50_latent64_f64")["ref_fp32_max_abs"]))
 
 
 class StubPipeline:
@@ -94,8 +96,11 @@ def test_diffusers_callsite_sdxl_fp32(gpu, sdxl_fp32):
     out = pipe(x["latent"][:1], x["encoder_hidden_states"], x["text_embeds"], x["time_ids"])
     ref = torch.from_numpy(g["final"])
     err = float((out - ref).abs().max())
-    print(f"F3-cfg fp32 call site: max abs err on final latent {err:.2e} (|ref| max {float(ref.abs().max()):.2f})")
-    assert err <= ABS_TOL_STRICT_CFG
+    g64 = golden("f3_cfg50_latent64_f64")
+    err64 = float((out.double() - torch.from_numpy(g64["final"])).abs().max())
+    print(f"F3-cfg fp32 call site: max abs err on final latent {err:.2e} vs the reference's fp32 run, {err64:.2e} vs its float64 run "
+          f"(reference fp32 vs float64: {float(g64['ref_fp32_max_abs']):.2e}; |ref| max {float(ref.abs().max()):.2f}; bound {cfg_strict_bound():.1e})")
+    assert err64 <= cfg_strict_bound()
 
 
 def test_diffusers_callsite_sdxl_fp16_pipeline(gpu, sdxl_bf16):
@@ -113,7 +118,7 @@ def test_diffusers_callsite_sdxl_fp16_pipeline(gpu, sdxl_bf16):
     assert torch.isfinite(out).all()
     # bound: twice what the storage alone costs in this protocol (oracle/make_rounded_golden.py f3_cfg: the oracle with an fp16
     # latent state, fp16 tensors at the UNet boundary and every UNet tensor rounded to bf16; guidance multiplies it by 9)
-    assert rms <= 2.0 * float(golden("f3_cfg50_latent64_rounded")["bf16_rms"])
+    assert rms <= 1.3 * float(golden("f3_cfg50_latent64_rounded")["bf16_rms"])      # (1.3: tests/test_unet_gpu.py STORAGE_FACTOR)
 
 
 def test_diffusers_callsite_sdxl_fp16_module(gpu, sdxl_fp16_pair):
@@ -132,7 +137,7 @@ def test_diffusers_callsite_sdxl_fp16_module(gpu, sdxl_fp16_pair):
     print(f"F3-cfg fp16 pipeline / fp16 kernels: final latent rms err {rms:.2e} = {100 * rms / ref_rms:.2f} % of rms {ref_rms:.2f}, "
           f"max abs {float((out - ref).abs().max()):.2e}")
     assert torch.isfinite(out).all()
-    assert rms <= 2.0 * float(golden("f3_cfg50_latent64_rounded")["fp16_rms"])       # (the same with fp16 UNet storage)
+    assert rms <= 1.3 * float(golden("f3_cfg50_latent64_rounded")["fp16_rms"])       # (the same with fp16 UNet storage)
 
 
 def test_diffusers_hook_rejects_unsupported(gpu):

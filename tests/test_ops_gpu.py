@@ -20,7 +20,8 @@ def rnd(name, shape, scale=1.0):
 @pytest.mark.parametrize("silu", [False, True])
 @pytest.mark.parametrize("cl", [False, True])
 @pytest.mark.parametrize("shape", [(1, 320, 16, 16), (2, 640, 8, 8), (1, 960, 32, 32), (1, 1920, 8, 8), (2, 2560, 4, 4),
-                                   (1, 64, 5, 7), (3, 128, 1, 1)])
+                                   (1, 64, 5, 7), (3, 128, 1, 1),
+                                   (1, 960, 128, 128), (1, 320, 128, 128)])      # groups of 491,520 / 163,840 elements, 32 work items
 def test_group_norm(gpu, dtype, silu, cl, shape):
     x = rnd("gn.x", shape) * 1.5 + 0.7
     w = rnd("gn.w", (shape[1],)) * 0.2 + 1.0

@@ -1,5 +1,6 @@
 """Pin the CPU oracle against the vectors recorded from the REFERENCE itself
 (oracle/make_golden.py imported /root/reference/.../unet_pt.py and stored its outputs)."""
+import numpy as np
 import pytest
 import torch
 
@@ -57,6 +58,42 @@ def test_f2_ops_match_reference_bitwise():
     for c, eps in ((320, 1e-5), (640, 1e-6), (960, 1e-5), (1280, 1e-6), (1920, 1e-5), (2560, 1e-5)):
         sd = {"n.weight": synth.param_tensor(f"f2.gn{c}.weight", (c,), 0), "n.bias": synth.param_tensor(f"f2.gn{c}.bias", (c,), 0)}
         check(f"gn{c}", orc.group_norm(sd, "n", synth.normal(f"f2.gn{c}.x", (1, c, 8, 8), seed), eps))
+
+
+def test_f2_large_ops_match_reference_bitwise():
+    """SURVEY 8(c)'s F2 sizes (round 5): attention self (T=1024, 20 heads) / text context (S=77) at C=1280, self (T=4096, 10 heads)
+    / text context at C=640, GroupNorm on 128 x 128 maps (960 channels: 491,520 elements per group): oracle == reference, bit for bit."""
+    g = golden("f2_ops_large")
+    seed = 1234
+
+    def check(name, out):
+        ref = torch.from_numpy(g[name])
+        got = _sub(out).reshape(ref.shape)
+        assert torch.equal(got, ref), f"{name}: max diff {float((got - ref).abs().max()):.3e}"
+
+    with torch.no_grad():
+        for c, t in ((1280, 1024), (640, 4096)):
+            x = synth.normal(f"f2.attn_self{c}_T{t}.x", (1, t, c), seed)
+            sd = {"a." + k: v for k, v in _sd(f"f2.attn_self{c}_T{t}", _shapes(U.Attention(c, 64))).items()}
+            check(f"attn_self{c}_T{t}", orc.attention(sd, "a", x))
+            ctx = synth.normal(f"f2.attn_cross{c}_T{t}.ctx", (1, 77, 2048), seed)
+            sd = {"a." + k: v for k, v in _sd(f"f2.attn_cross{c}_T{t}", _shapes(U.Attention(c, 64, 2048))).items()}
+            check(f"attn_cross{c}_T{t}", orc.attention(sd, "a", x, ctx))
+        for c, eps in ((960, 1e-5), (320, 1e-5), (640, 1e-6)):
+            sd = {"n.weight": synth.param_tensor(f"f2.gn{c}_128.weight", (c,), 0), "n.bias": synth.param_tensor(f"f2.gn{c}_128.bias", (c,), 0)}
+            check(f"gn{c}_128", orc.group_norm(sd, "n", synth.normal(f"f2.gn{c}_128.x", (1, c, 128, 128), seed), eps))
+
+
+def test_f64_truth_fixtures_are_consistent():
+    """The float64 runs of the reference (oracle/make_golden.py f3_64_f64 / f3_cfg_f64): the recorded deviation of the reference's
+    own fp32 run IS the difference of the two committed vectors, and it is far inside north_star's 1e-3 (the gates of the
+    strict-mode GPU tests are max(1e-3, 2 x this) against the float64 vector)."""
+    for name in ("f3_euler50_latent64", "f3_cfg50_latent64"):
+        g32, g64 = golden(name), golden(name + "_f64")
+        dev = np.abs(g32["final"].astype(np.float64) - g64["final"]).max()
+        assert g64["final"].dtype == np.float64
+        assert abs(dev - float(g64["ref_fp32_max_abs"])) < 1e-12
+        assert dev < 2e-4
 
 
 @pytest.fixture(scope="module")

@@ -16,6 +16,13 @@ def test_meta_kernels_give_shapes_dtypes_and_layouts():
         q = torch.empty(2, 1024, 1280, dtype=torch.bfloat16, device="cuda")
         kv = torch.empty(2, 77, 1280, dtype=torch.bfloat16, device="cuda")
         assert torch.ops.st.attention(q, kv, kv, 20, 0.125).shape == q.shape
+        # every head size the C ABI takes is reachable through the dispatcher op (round 5: the schema carries head_dim)
+        for hd in (16, 32, 64, 128):
+            assert torch.ops.st.attention(q, kv, kv, 1280 // hd, hd ** -0.5, hd).shape == q.shape
+        with pytest.raises(RuntimeError):
+            torch.ops.st.attention(q, kv, kv, 20, 0.125, 32)          # 20 heads of 32 are not 1280 channels
+        with pytest.raises(RuntimeError):
+            torch.ops.st.attention(q, kv, kv, 16, 0.125, 80)          # not a head size of st_attention
         img = torch.empty(2, 320, 64, 64, dtype=torch.bfloat16, device="cuda").contiguous(memory_format=torch.channels_last)
         g = torch.empty(320, dtype=torch.bfloat16, device="cuda")
         gn = torch.ops.st.group_norm_silu(img, 32, g, g, 1e-5, True)
@@ -50,3 +57,7 @@ def test_dispatcher_reaches_the_hip_kernels(gpu):
     b = torch.randn(128, device=gpu, dtype=torch.bfloat16)
     assert torch.equal(torch.ops.st.linear_act(x, w, b, True), ops.linear(x, w, b, silu=True))
     assert torch.equal(torch.ops.st.geglu(x, x), ops.geglu(x, x))
+    q = torch.randn(1, 256, 256, device=gpu, dtype=torch.bfloat16)
+    kv = torch.randn(1, 77, 256, device=gpu, dtype=torch.bfloat16)
+    for hd in (32, 64, 128):
+        assert torch.equal(torch.ops.st.attention(q, kv, kv, 256 // hd, hd ** -0.5, hd), ops.attention(q, kv, kv, 256 // hd, hd ** -0.5))

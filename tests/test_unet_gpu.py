@@ -26,7 +26,7 @@ ABS_TOL_STRICT = 1e-3          # north_star: 1e-3 abs on the final latent
 # operators, and recorded its deviation from the reference's fp32 output (tests/golden/*_rounded.npz: F1 bf16 max abs 6.2e-2 /
 # rms 1.8e-2, fp16 8.3e-3 / 2.2e-3; F3 latent 64 bf16 0.36 / 8.8e-2).  The HIP path's own deviation may be at most
 # STORAGE_FACTOR times that: two realisations of the same rounding noise differ, a kernel that adds error of its own shows.
-STORAGE_FACTOR = 2.0
+STORAGE_FACTOR = 1.3          # (round 5, ADVICE r4: 2.0 let a kernel regression that doubles the error pass; measured / storage-alone is 0.95-1.05)
 
 
 def storage_bound(name, dt):
@@ -202,6 +202,51 @@ def test_f2_golden_ops(gpu, dtype, tol):
         check(f"gn{c}", optimize_model(wrap, False)(x))
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2), (torch.float16, 7.5e-3)])
+def test_f2_large_golden_ops(gpu, dtype, tol):
+    """The reference's own outputs at the sizes SURVEY 8(c) names (round 5 fixtures): self-attention at 1024 tokens x 20 heads and
+    4096 tokens x 10 heads (the site that was only reached through the 50-step latent before), the text-context attention at
+    both widths, GroupNorm on the 128 x 128 maps (groups of up to 491,520 elements)."""
+    g = golden("f2_ops_large")
+    seed = 1234
+
+    def check(name, out):
+        ref = torch.from_numpy(g[name])
+        e = rel_err(_sub(out.float().cpu()).reshape(ref.shape), ref)
+        print(f"F2-large {name} {dtype}: rel err {e:.2e}")
+        assert e <= tol, name
+
+    class SelfAttn(torch.nn.Module):
+        def __init__(self, c):
+            super().__init__()
+            self.attn = U.Attention(c, 64)
+
+        def forward(self, x):
+            return self.attn(x)
+
+    class CrossAttn(torch.nn.Module):
+        def __init__(self, c):
+            super().__init__()
+            self.attn = U.Attention(c, 64, 2048)
+
+        def forward(self, x, ctx):
+            return self.attn(x, ctx)
+
+    for c, t in ((1280, 1024), (640, 4096)):
+        x = synth.normal(f"f2.attn_self{c}_T{t}.x", (1, t, c), seed).to(gpu, dtype)
+        h = SelfAttn(c)
+        _filled(h.attn, f"f2.attn_self{c}_T{t}", dtype, gpu)
+        check(f"attn_self{c}_T{t}", optimize_model(h.to(gpu, dtype), False)(x))
+        h = CrossAttn(c)
+        _filled(h.attn, f"f2.attn_cross{c}_T{t}", dtype, gpu)
+        ctx = synth.normal(f"f2.attn_cross{c}_T{t}.ctx", (1, 77, 2048), seed).to(gpu, dtype)
+        check(f"attn_cross{c}_T{t}", optimize_model(h.to(gpu, dtype), False)(x, ctx))
+    for c, eps in ((960, 1e-5), (320, 1e-5), (640, 1e-6)):
+        gn = _filled(torch.nn.GroupNorm(32, c, eps=eps), f"f2.gn{c}_128", dtype, gpu)
+        x = synth.normal(f"f2.gn{c}_128.x", (1, c, 128, 128), seed).to(gpu, dtype)
+        check(f"gn{c}_128", optimize_model(torch.nn.Sequential(gn), False)(x))
+
+
 # ---------------------------------------------------------------------------------- SDXL-base, reference goldens
 # (the SDXL-base fixtures `sdxl_fp32` / `sdxl_bf16` live in conftest.py: one build per session, shared with test_hooks_gpu.py)
 
@@ -261,6 +306,14 @@ def test_sdxl_f3_euler50_fp32(gpu, sdxl_fp32, hw):
     err = float((out - ref).abs().max())
     print(f"F3 latent{hw} fp32: max abs err on final latent {err:.2e} (|ref| max {float(ref.abs().max()):.2f})")
     assert err <= ABS_TOL_STRICT
+    if hw == 64:
+        # anchored to truth, not to another fp32 summation order (round 5): the reference module in float64 through the same loop
+        # (oracle/make_golden.py f3_64_f64); the reference's own fp32 run deviates 2.4e-5 from it, so the bound stays north_star's
+        g64 = golden("f3_euler50_latent64_f64")
+        err64 = float((out.double() - torch.from_numpy(g64["final"])).abs().max())
+        bound = max(ABS_TOL_STRICT, 2.0 * float(g64["ref_fp32_max_abs"]))
+        print(f"F3 latent64 fp32 vs the float64 run: {err64:.2e} (reference fp32 vs float64: {float(g64['ref_fp32_max_abs']):.2e}; bound {bound:.1e})")
+        assert err64 <= bound
 
 
 @pytest.mark.parametrize("hw", [64, 128])

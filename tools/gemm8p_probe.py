@@ -24,18 +24,23 @@ with ctx:
         for _ in range(3):
             ops.linear(x, w, b, geglu=bool(geglu))
         torch.cuda.synchronize()
-        ws[65536:65536 + 32 * 4096].zero_()
-        ops.linear(x, w, b, geglu=bool(geglu))
+        ws[65536:65536 + 64 * 4096].zero_()
+        for _ in range(8):               # back to back, as in the step (the clock settles): the stamps are the last launch's
+            ops.linear(x, w, b, geglu=bool(geglu))
         torch.cuda.synchronize()
-        st = ws[65536:65536 + 32 * 4096].view(torch.int64).view(-1, 4).cpu()
+        st = ws[65536:65536 + 64 * 4096].view(torch.int64).view(-1, 8).cpu()
         st = st[st[:, 0] != 0]
         if st.numel() == 0:
             print(f"M={M} K={K} N={N} g={geglu}: no stamps (not on the eight-phase kernel, or not a probe build)")
             continue
         pro, loop, epi = (st[:, 1] - st[:, 0]).float(), (st[:, 2] - st[:, 1]).float(), (st[:, 3] - st[:, 2]).float()
         span = int(st[:, 3].max() - st[:, 0].min())
+        real_us = (st[:, 5] - st[:, 4]).float() / 100.0                  # s_memrealtime: 100 MHz
+        ghz = ((st[:, 3] - st[:, 0]).float() / real_us / 1e3).median()
+        span_us = float(st[:, 5].max() - st[:, 4].min()) / 100.0
         us = timeit(lambda: ops.linear(x, w, b, geglu=bool(geglu)), iters=20)
         nk = K // 64
         print(f"M={M} K={K} N={N} g={geglu}: {st.shape[0]} blocks | prologue med {pro.median():.0f} max {pro.max():.0f} | loop med {loop.median():.0f} "
-              f"({loop.median() / nk:.0f} / K tile) max {loop.max():.0f} | epilogue med {epi.median():.0f} max {epi.max():.0f} | first entry -> last exit {span} cyc | {us:.1f} us",
+              f"({loop.median() / nk:.0f} / K tile) max {loop.max():.0f} | epilogue med {epi.median():.0f} max {epi.max():.0f} | block life med {real_us.median():.1f} us at {ghz:.3f} GHz | "
+              f"first entry -> last exit {span} cyc = {span_us:.1f} us | {us:.1f} us per launch",
               flush=True)
