@@ -46,13 +46,13 @@ enum {
     ST_EPI_ROWBIAS   = 16   /* + rowbias[batch(m)][n]     (time-embedding add)    */
 };
 
-int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 14
+int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 15
                                               (6: next-weights hint passed per call, st_timestep_sincos; 7: fp8 entry points; 8: GroupNorm partials from the
                                               producer; 9: st_ln_linear_xattn; 10: ST_F16 accepted by every entry point
                                               that takes a dtype, st_ln_linear_xattn takes a dtype; 11: fp8 plan with
                                               delayed per-tensor scaling - st_linear_emit8, st_linear_fp8x, st_fp8_update_scales; 12: readers of a channel
                                               concatenation that is never written - st_group_norm_from_stats_cat, st_conv1x1_cat; 13: ST_F32S split fp32 matrix operands, st_split_f32, st_arm_split_output, st_attention_split; 14: st_attention
-                                              takes head_dim 16 / 32 / 128 beside 64) */
+                                              takes head_dim 16 / 32 / 128 beside 64; 15: st_timestep_features takes the host's table of the reference's own features for integer timesteps) */
 const char* st_last_error(void);           /* host string, thread-local     */
 
 /* GroupNorm (+SiLU).  Replaces reference group_norm_wrapper
@@ -210,9 +210,14 @@ int st_step_advance(int* step, int n_steps, void* stream);
  * fuse_timesteps pass, optimizers/replace_timesteps.py:33-58):
  *   out[b][j] = cos(t_b * f_j), out[b][dim/2 + j] = sin(t_b * f_j),
  *   f_j = exp(-ln(1e4) * j / (dim/2)),  t_b = t[(step ? *step : 0) + b*t_stride].
- * t is fp32 on the device; out is (batch, dim) of `dtype`. */
+ * t is fp32 on the device; out is (batch, dim) of `dtype`.
+ * `table` (optional, device, fp32, table_rows x dim): row i = the features of t = i as the REFERENCE's eager path computes
+ * them (the host fills it with the reference's own op sequence).  The function is ill-conditioned - t_b * f_j reaches 1e3 rad,
+ * so one ulp of exp() moves a feature by 1.2e-4 and two correct fp32 implementations disagree by that much; a timestep that
+ * is an integer in [0, table_rows) (every entry of SDXL's schedules, every size / crop of time_ids) therefore takes its row,
+ * anything else is computed.  NULL: always computed. */
 int st_timestep_features(const float* t, long t_stride, const int* step, void* out,
-                         int batch, int dim, int dtype, void* stream);
+                         int batch, int dim, int dtype, const float* table, int table_rows, void* stream);
 
 /* ---- fp8 projection path (BASELINE config #5).  Seed in the reference: fp8-stored projection
  * weights, up-converted before the product (kernels/attention_proj.py:36-39, 105-155); here both operands stay OCP

@@ -16,7 +16,7 @@ from .build import lib_path
 ST_F32, ST_BF16, ST_F16, ST_F32S = 0, 1, 2, 3
 ST_NCHW, ST_NHWC = 0, 1
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_RESIDUAL, EPI_ROWBIAS = 1, 2, 4, 8, 16
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _p, _i, _l, _f, _z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
@@ -38,7 +38,7 @@ SIGNATURES = {
     "st_conv1x1_cat": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p, _i, _p, _p, _z, _p]),
     "st_euler_step": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p]),
     "st_step_advance": (_i, [_p, _i, _p]),
-    "st_timestep_features": (_i, [_p, _l, _p, _p, _i, _i, _i, _p]),
+    "st_timestep_features": (_i, [_p, _l, _p, _p, _i, _i, _i, _p, _i, _p]),
     "st_timestep_sincos": (_i, [_p, _p, _p, _l, _i, _p]),
     "st_quantize_fp8": (_i, [_p, _l, _p, _p, _i, _i, _i, _p]),
     "st_layer_norm_quantize_fp8": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _i, _p]),

@@ -43,7 +43,7 @@ int st_check_launch(const char* what) {
 }
 
 extern "C" const char* st_last_error(void) { return g_err; }
-extern "C" int st_abi_version(void) { return 14; }
+extern "C" int st_abi_version(void) { return 15; }
 
 // ---- Euler-discrete update ---------------------------------------------------
 template <typename T>
@@ -93,13 +93,20 @@ extern "C" int st_step_advance(int* step, int n_steps, void* stream) {
 // optimizers/replace_timesteps.py:43-58, targets the same sub-graph) -----------
 template <typename T>
 __global__ void timestep_kernel(const float* __restrict__ t, long t_stride, const int* __restrict__ step,
-                                T* __restrict__ out, int batch, int dim) {
+                                T* __restrict__ out, int batch, int dim, const float* __restrict__ table, int table_rows) {
     const int half = dim / 2;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= batch * half) return;
     const int b = idx / half, j = idx - b * half;
     const int base = step ? *step : 0;
     const float tv = t[base + b * t_stride];
+    // an integer timestep inside the host's table: the reference's own bits (the header says why)
+    if (table && tv >= 0.f && tv < (float)table_rows && tv == floorf(tv)) {
+        const float* row = table + (size_t)(int)tv * dim;
+        out[(size_t)b * dim + j] = Elem<T>::from_f(row[j]);
+        out[(size_t)b * dim + half + j] = Elem<T>::from_f(row[half + j]);
+        return;
+    }
     // same fp32 op order as the eager module: (-ln(1e4) * j) / half, exp, * t
     const float e = (-9.210340371976184f * (float)j) / (float)half;
     const float a = tv * expf(e);
@@ -108,16 +115,18 @@ __global__ void timestep_kernel(const float* __restrict__ t, long t_stride, cons
 }
 
 extern "C" int st_timestep_features(const float* t, long t_stride, const int* step, void* out, int batch, int dim,
-                                    int dtype, void* stream) {
+                                    int dtype, const float* table, int table_rows, void* stream) {
     ST_REQUIRE(t && out && batch > 0 && dim > 0 && dim % 2 == 0, "timestep_features: bad arguments");
+    ST_REQUIRE(!table || table_rows > 0, "timestep_features: a table of %d rows", table_rows);
+    if (!table) table_rows = 0;
     const int n = batch * (dim / 2);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ST_BF16)
-        hipLaunchKernelGGL(timestep_kernel<bf16>, dim3(cdiv(n, 256)), dim3(256), 0, st, t, t_stride, step, (bf16*)out, batch, dim);
+        hipLaunchKernelGGL(timestep_kernel<bf16>, dim3(cdiv(n, 256)), dim3(256), 0, st, t, t_stride, step, (bf16*)out, batch, dim, table, table_rows);
     else if (dtype == ST_F16)
-        hipLaunchKernelGGL(timestep_kernel<f16>, dim3(cdiv(n, 256)), dim3(256), 0, st, t, t_stride, step, (f16*)out, batch, dim);
+        hipLaunchKernelGGL(timestep_kernel<f16>, dim3(cdiv(n, 256)), dim3(256), 0, st, t, t_stride, step, (f16*)out, batch, dim, table, table_rows);
     else if (dtype == ST_F32)
-        hipLaunchKernelGGL(timestep_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, t, t_stride, step, (float*)out, batch, dim);
+        hipLaunchKernelGGL(timestep_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, t, t_stride, step, (float*)out, batch, dim, table, table_rows);
     else
         return st_fail("timestep_features: unsupported dtype %d", dtype);
     return st_check_launch("timestep_features");

@@ -1058,6 +1058,38 @@ def conv2d_cat(x0: torch.Tensor, x1: torch.Tensor, weight: torch.Tensor, bias: O
 
 
 # ----------------------------------------------------------------------------- loop pieces
+TIMESTEP_TABLE_ROWS = 4097      # integer timesteps / sizes 0 .. 4096 (SDXL: 1000 train steps; time_ids = sizes and crops in pixels)
+_timestep_tables = {}
+_timestep_lock = threading.Lock()
+
+
+def reference_timestep_features(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """The reference's own op sequence for the sinusoidal features (unet_pt.py:22-36), on the host in fp32: cos first, then sin."""
+    import math
+    half = dim // 2
+    exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32)
+    exponent = exponent / (half - 0.0)
+    emb = t[:, None].float() * torch.exp(exponent)[None, :]
+    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+
+
+def _timestep_table(device: torch.device, dim: int) -> torch.Tensor:
+    """(TIMESTEP_TABLE_ROWS, dim) fp32 on `device`: row i = the features of timestep i as the reference's eager path computes
+    them.  Why a table: t * f_j reaches 1e3 rad, one ulp of exp() moves a feature by 1.2e-4 - two correct fp32 implementations of
+    this function disagree by that much, and the difference enters every resnet through the time embedding (round 5: it was the
+    largest single term of the strict mode's deviation from the reference).  Built once per (device, width) by the host."""
+    key = (device.type, device.index, dim)
+    tbl = _timestep_tables.get(key)
+    if tbl is None:
+        with _timestep_lock:
+            tbl = _timestep_tables.get(key)
+            if tbl is None:
+                with torch.no_grad():
+                    host = reference_timestep_features(torch.arange(TIMESTEP_TABLE_ROWS, dtype=torch.float32), dim)
+                tbl = _timestep_tables[key] = host.to(device)
+    return tbl
+
+
 def timestep_features(t: torch.Tensor, dim: int, dtype: torch.dtype, step: Optional[torch.Tensor] = None,
                       batch: Optional[int] = None, t_stride: int = 1) -> torch.Tensor:
     _C.require_device(t)
@@ -1066,8 +1098,13 @@ def timestep_features(t: torch.Tensor, dim: int, dtype: torch.dtype, step: Optio
     t32 = t32.contiguous()
     nb = t32.numel() if batch is None else batch
     out = torch.empty((nb, dim), dtype=dtype, device=t.device)
+    if torch.cuda.is_current_stream_capturing() and (t.device.type, t.device.index, dim) not in _timestep_tables:
+        tbl_p, tbl_n = None, 0          # (no host-to-device copy inside somebody's capture: the first eager call builds the table)
+    else:
+        tbl = _timestep_table(t.device, dim)
+        tbl_p, tbl_n = tbl.data_ptr(), tbl.shape[0]
     _C.check(lib.st_timestep_features(t32.data_ptr(), t_stride, _ptr(step), out.data_ptr(), nb, dim,
-                                      _C.dtype_code(dtype), _C.stream_ptr()), "timestep_features")
+                                      _C.dtype_code(dtype), tbl_p, tbl_n, _C.stream_ptr()), "timestep_features")
     return out
 
 

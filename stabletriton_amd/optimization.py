@@ -90,6 +90,12 @@ def optimize_model(model: nn.Module, cuda_graph: bool = True, fuse: bool = True,
     # two compiled modules, or two streams each driving their own, never share any (ops.ExecContext)
     gm.exec_context = ops.ExecContext()
     gm.fp8_plan = bool(fp8 and fuse)
+    # the host's tables of the sinusoidal timestep features (ops._timestep_table): built now, eagerly, so that no first call
+    # inside somebody's stream capture has to compute them the other way
+    from .optimizers.wrappers import timestep_embedding_wrapper
+    for n in gm.graph.nodes:
+        if n.op == "call_function" and n.target is timestep_embedding_wrapper and isinstance(n.args[1], int):
+            ops._timestep_table(p0.device, n.args[1])
     if not (fuse and _install_context_split(gm)):
         plain = gm.forward
 

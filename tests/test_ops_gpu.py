@@ -402,11 +402,24 @@ def test_conv2d(gpu, dtype, cfg):
 
 
 def test_timestep_features(gpu):
-    t = torch.tensor([999.0, 500.0, 1.0, 1024.0, 0.0])
+    """Integer timesteps (every schedule entry, every size / crop of SDXL's time_ids) take the host's table of the REFERENCE's own
+    features: bit for bit the eager path.  The function is ill-conditioned (t * f_j up to 1e3 rad: one ulp of exp() moves a
+    feature by 1.2e-4), so anything computed on the device - the non-integer timesteps - is compared at 2e-4."""
+    t = torch.tensor([999.0, 500.0, 1.0, 1024.0, 0.0, 981.0, 21.0, 4096.0])
     for dim in (320, 256):
         out = ops.timestep_features(t.to(gpu), dim, torch.float32)
-        ref = orc.timestep_features(t, dim)
-        assert (out.cpu() - ref).abs().max() < 2e-4          # fp32 sin/cos of arguments up to 1e3 rad
+        assert torch.equal(out.cpu(), orc.timestep_features(t, dim))
+        for dt in (torch.bfloat16, torch.float16):
+            assert torch.equal(ops.timestep_features(t.to(gpu), dim, dt).cpu(), orc.timestep_features(t, dim).to(dt))
+        tf = torch.tensor([999.5, 0.25, 6.0, 2.5, 5000.0, -3.0])          # fractional (the refiner's aesthetic score 2.5), beyond the table, negative
+        out = ops.timestep_features(tf.to(gpu), dim, torch.float32).cpu()
+        ref = orc.timestep_features(tf, dim)
+        assert torch.equal(out[2], ref[2])                                  # 6.0 is an integer: the table row
+        assert (out - ref).abs().max() < 2e-4 * max(1.0, 5000.0 / 1000.0)
+        # the step-indexed form of the denoise loop reads the same rows
+        steps = torch.tensor([981.0, 961.0, 941.0], device=gpu)
+        idx = torch.tensor([1], dtype=torch.int32, device=gpu)
+        assert torch.equal(ops.timestep_features(steps, dim, torch.float32, step=idx, batch=1, t_stride=0).cpu(), orc.timestep_features(torch.tensor([961.0]), dim))
 
 
 def test_euler_step(gpu):
