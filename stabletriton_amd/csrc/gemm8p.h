@@ -10,19 +10,18 @@
 //     256 x 256: 8 waves = 2 (rows) x 4 (columns), wave tile 128 x 64;
 //     256 x 160: 8 waves = 4 x 2, wave tile 64 x 80 - SDXL's widths are 5 * 2^k: 1024 x 10240 (the GEGLU projection at
 //                batch 1) is 160 tiles of 256 x 256 but 256 of 256 x 160, one per CU.
-//   * A K tile is four phases, one quadrant of the wave tile each: (A0,B0) (A0,B1) (A1,B1) (A1,B0), Ah = the two halves of
-//     the wave's rows, B0 / B1 = its first ceil(TN/2) / last floor(TN/2) accumulator columns.  A phase reads only the
-//     fragments it is the first to use (A0+B0, B1, A1, nothing).
+//   * A K tile is two phases per wave group (round 5; four quadrant phases before): (A0, B) then (A1, B), Ah = the two halves
+//     of the wave's rows, B = all its accumulator columns.  The first phase reads A0 and B, the second only A1.
 //   * The two halves of the block's waves run half a phase apart (waves 4-7 pass one extra barrier first): while one
 //     half multiplies, the other reads fragments and issues DMAs, on the same SIMDs - a software ping-pong with two raw
 //     barriers per phase and no wave ever doing both at once.
-//   * LDS: two K tiles, each as four regions (A0, A1, B0, B1: the rows all eight waves read in the same phase), filled by
-//     LDS-DMA one region per phase (two 1-KiB pieces per wave; a region with fewer than sixteen pieces fills up with dummy
-//     pieces so that every wave counts the same vmcnt), swizzled on the source side as in gemm_dma_kernel.  A region is
-//     refilled two phases after its last read and waited for (counted vmcnt, never 0) one phase before its first read,
-//     which leaves four regions in flight at all times.
-// Staged epilogue (GEGLU: tile columns [values | gates]), LayerNorm folding, statistics, next-weights touches and the
-// XCD-aware tile order are the ones of gemm_dma_kernel.  No K split.
+//   * LDS: two K tiles, each as four regions (A0, A1, B0, B1), filled by LDS-DMA (two 1-KiB pieces per wave and region; a
+//     region with fewer than sixteen pieces fills up with dummy pieces so that every wave counts the same vmcnt), swizzled on
+//     the source side as in gemm_dma_kernel.  A region is refilled in the first half phase after both wave groups have read
+//     it and waited for (counted vmcnt, never 0) four half phases later.
+// Epilogue: straight from the accumulator registers over a permuted staging of W where the launch's feature set has such an
+// instance (DIRECT; epilogue.h, direct epilogue), else staged through LDS (GEGLU: tile columns [values | gates]).  LayerNorm
+// folding, statistics, next-weights touches and the XCD-aware tile order are the ones of gemm_dma_kernel.  No K split.
 // =============================================================================
 template <typename T, bool GEGLU, bool LNF, int BN = 256, int WGM = 2, int WGN = 4, bool DIRECT = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
@@ -146,8 +145,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
         const int row = t >> 1, part = t & 1;
         ln_sum.load(st2 + (size_t)(m0 + row) * p.ln_chunks, p.ln_chunks, part);
     }
-    // prologue: K tile 0 whole and A0, B0 of K tile 1 (the loop issues B1(1), A1(1), A0(2), B0(2), B1(2), ...)
-    issue_half(0, 0); issue_half(0, 2); issue_half(0, 3); issue_half(0, 1); issue_half(1, 0); issue_half(1, 2);
+    // prologue: K tile 0 whole and A0, B0, B1 of K tile 1 (the loop issues A1(1), then A0, B0, B1 of tile 2, A1(2), ...)
+    issue_half(0, 0); issue_half(0, 2); issue_half(0, 3); issue_half(0, 1); issue_half(1, 0); issue_half(1, 2); issue_half(1, 3);
     if constexpr (LNF) {
         const float2* st2 = reinterpret_cast<const float2*>(p.ln_stats);
         const int row = t >> 1, part = t & 1;
@@ -158,7 +157,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
         if (part == 0) reinterpret_cast<float2*>(lnrows)[row] = make_float2(mean, rstd);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    wait_vmcnt<8>();                                 // A0(0), B0(0) have landed (and every load older than the DMAs)
+    wait_vmcnt<8>();                                 // A0(0), B0(0), B1(0) have landed (fourteen DMAs issued; and every load older than the DMAs)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::"v"(touch_sink));
     if (wave >= 4) __builtin_amdgcn_s_barrier();     // the second half of the waves runs one barrier (half a phase) behind the first
@@ -179,14 +178,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
         b0_off[kk] = 2 * HA + (wn * TN0 * 16 + r16) * 128 + sw;
         b1_off[kk] = 2 * HA + HB0 + (wn * TN1 * 16 + r16) * 128 + sw;
     }
-    // A half in use, B0 (kept for the fourth phase), B1.  16-bit: [..][kk] = the operand of k step kk; e4m3: [..][0] is the whole
+    // A half in use and the wave's whole B.  16-bit: [..][kk] = the operand of k step kk; e4m3: [..][0] is the whole
     // 128-k operand, assembled from the two 16-byte reads (chunks q and q + 4) where they land
     constexpr int NKK = sizeof(T) == 1 ? 1 : 2;
-    // Round 5: the fragment reads of a K tile used to be 12 / 4 / 8 / 0 ds_read_b128 per wave over the four phases, and phase 0's
-    // read segment (four waves at once) took ~350 cycles against the 256 of the other half's MFMAs.  Phase 3 multiplies from A1
-    // and B0 only - B1's registers are free - so the first TMH/2 row tiles of the NEXT K tile's A0 are read there (fan): 8 / 4 / 8 / 4.
-    constexpr int TMP = TMH / 2;                      // A0 row tiles read one phase early
-    Frag fa[TMH][NKK], fan[TMP][NKK], fb0[TN0][NKK], fb1[TN1][NKK];
+    Frag fa[TMH][NKK], fb[TN][NKK];
     auto read_op = [&](const char* base, const int (&off)[2], Frag (&dst)[NKK]) {
         if constexpr (sizeof(T) == 1) {
             const Half lo = *reinterpret_cast<const Half*>(base + off[0]), hi = *reinterpret_cast<const Half*>(base + off[1]);
@@ -200,43 +195,31 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < TMH; ++i) read_op(tile + h * HA + i * 2048, a_off, fa[i]);
     };
-    auto read_a0_early = [&](const char* tile) {      // row tiles [0, TMP) of A0 -> fan
+    auto read_b = [&](const char* tile) {
 #pragma unroll
-        for (int i = 0; i < TMP; ++i) read_op(tile + i * 2048, a_off, fan[i]);
-    };
-    auto read_a0_rest = [&](const char* tile) {       // row tiles [TMP, TMH) of A0 -> fa
+        for (int j = 0; j < TN0; ++j) read_op(tile + j * 2048, b0_off, fb[j]);
 #pragma unroll
-        for (int i = TMP; i < TMH; ++i) read_op(tile + i * 2048, a_off, fa[i]);
+        for (int j = 0; j < TN1; ++j) read_op(tile + j * 2048, b1_off, fb[TN0 + j]);
     };
-    auto read_b0 = [&](const char* tile) {
-#pragma unroll
-        for (int j = 0; j < TN0; ++j) read_op(tile + j * 2048, b0_off, fb0[j]);
-    };
-    auto read_b1 = [&](const char* tile) {
-#pragma unroll
-        for (int j = 0; j < TN1; ++j) read_op(tile + j * 2048, b1_off, fb1[j]);
-    };
-    auto quadrant = [&](auto mh_, auto nh_) {
-        constexpr int mh = decltype(mh_)::value, nh = decltype(nh_)::value;
+    auto half_tile = [&](auto mh_) {                  // the MFMAs of one row half of the wave tile: TMH x TN accumulator tiles, all of the K tile
+        constexpr int mh = decltype(mh_)::value;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
-            for (int i = 0; i < TMH; ++i) {
-                const Frag& a = (mh == 0 && i < TMP) ? fan[i < TMP ? i : 0][kk] : fa[i][kk];      // A0's first row tiles came a phase early
-                if constexpr (nh == 0) {
+            for (int i = 0; i < TMH; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN0; ++j) Mma<T>::run(acc[mh * TMH + i][j], fb0[j][kk], a);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < TN1; ++j) Mma<T>::run(acc[mh * TMH + i][TN0 + j], fb1[j][kk], a);
-                }
-            }
+                for (int j = 0; j < TN; ++j) Mma<T>::run(acc[mh * TMH + i][j], fb[j][kk], fa[i][kk]);
         __builtin_amdgcn_s_setprio(0);
     };
-    // one phase: [fragment reads] [one region of DMA] [counted wait] barrier [MFMAs of one quadrant] barrier
-    // after the issue of phase ph the eight DMAs of phases ph-3 .. ph may stay in flight: the region issued in
-    // phase ph-4 has landed for this wave, and for everybody once both halves of the waves have passed their next barrier
+    // Round 5: a K tile is TWO phases per wave group, not four - (A0, B) then (A1, B): half as many barriers and counted waits
+    // per K tile (each of the eight cost ~75 cycles beside its 256 of MFMA: 2,650-2,850 cycles per K tile against 2,048; the
+    // fragments in flight are the same 64 registers: one A half + the wave's whole B instead of one A half + B0 + B1).
+    //   L0: read A0, B (12-14 ds_read_b128 pairs)  | issue A1(kt+1)                  | vmcnt(8), barrier | M0: TMH x TN x NKK MFMAs | barrier
+    //   L1: read A1                                 | issue A0, B0, B1 of tile kt+2  | vmcnt(8), barrier | M1                        | barrier
+    // Every region is requested as soon as both wave groups have read its previous content (A1's buffer after L1 of the tile
+    // before, the others after L0 of this tile) and waited for four half phases later: after the issue of a half phase the eight
+    // youngest DMAs (this half's and the one before) may stay in flight.
 #define ST_PHASE_SYNC()                                   \
     __builtin_amdgcn_sched_barrier(0);                    \
     wait_vmcnt<8>();                                      \
@@ -251,34 +234,19 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
 #ifdef ST_PROBE8
     pr_t1 = __builtin_readcyclecounter();
 #endif
-    read_a0_early(lds);                               // (A0 of K tile 0 has landed: the prologue's wait and barrier)
     for (int kt = 0; kt < nk; ++kt) {
         const char* tile = lds + (kt & 1) * TILE_B;
-        // phase 0: (A0, B0); refill B1 of tile kt+1 (last read in phase 1 of tile kt-1)
-        read_a0_rest(tile); read_b0(tile);
-        issue_half(kt + 1, 3);
-        ST_PHASE_SYNC();
-        quadrant(I0{}, I0{});
-        ST_PHASE_END();
-        // phase 1: (A0, B1); refill A1 of tile kt+1 (last read in phase 2 of tile kt-1)
-        read_b1(tile);
+        // L0 / M0: (A0, B); A1 of tile kt+1 (its buffer was last read in L1 of tile kt-1)
+        read_a(tile, 0); read_b(tile);
         issue_half(kt + 1, 1);
         ST_PHASE_SYNC();
-        quadrant(I0{}, I1{});
+        half_tile(I0{});
         ST_PHASE_END();
-        // phase 2: (A1, B1); refill A0 of tile kt+2 (last read in phase 0 of this tile)
+        // L1 / M1: (A1, B from registers); A0, B0, B1 of tile kt+2 (their buffers were last read in L0 of this tile)
         read_a(tile, 1);
-        issue_half(kt + 2, 0);
+        issue_half(kt + 2, 0); issue_half(kt + 2, 2); issue_half(kt + 2, 3);
         ST_PHASE_SYNC();
-        quadrant(I1{}, I1{});
-        ST_PHASE_END();
-        // phase 3: (A1, B0) from registers; the first row tiles of A0 of tile kt+1 (issued in phase 2 of tile kt-1: five phases
-        // back, landed for every wave - the same distance as every other read of the loop; behind the last K tile this reads
-        // stale LDS that nobody multiplies); refill B0 of tile kt+2 (last read in phase 0 of this tile)
-        read_a0_early(lds + ((kt + 1) & 1) * TILE_B);
-        issue_half(kt + 2, 2);
-        ST_PHASE_SYNC();
-        quadrant(I1{}, I0{});
+        half_tile(I1{});
         ST_PHASE_END();
     }
 #undef ST_PHASE_SYNC

@@ -16,7 +16,7 @@ force = lib.st_debug_force_gemm
 force.argtypes, force.restype = [ctypes.c_int, ctypes.c_int], None
 # only configurations the product dispatch can select (the other developer tilings are not maintained: 256x256_W8 faults)
 NAMES = {7: "64x64_W8", 8: "128x64_W8", 9: "128x128_W8", 10: "64x128_W8", 19: "256x128_W8", 23: "128x320_W8",
-         25: "64x320_W8", 26: "64x80_W4", 27: "128x80_W8", 28: "128x160_W8", 100: "256x256_8P", 101: "256x160_8P"}
+         25: "64x320_W8", 26: "64x80_W4", 27: "128x80_W8", 28: "128x160_W8", 100: "256x256_8P", 101: "256x160_8P", 102: "256x256_4W"}
 if os.environ.get("ST_BENCH_DTYPE") == "fp32":      # split operands: two accumulator sets, no eight-phase kernel
     NAMES = {7: "64x64_W8", 8: "128x64_W8", 9: "128x128_W8", 10: "64x128_W8", 27: "128x80_W8", 13: "128x128_W8_S3", 21: "128x64_W8_S3", 22: "64x128_W8_S3",
              15: "64x128_W8_U2", 16: "128x64_W8_U2", 17: "64x64_W8_U2", 20: "128x128_W8_S2"}
