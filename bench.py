@@ -215,6 +215,8 @@ def committed_profile(name, tag=""):
         t = json.load(open(latest))
         traffic = t.get(f"{name}_bytes_per_launch")
         mfma_busy = t.get(f"{name}_mfma_busy")
+        if out and t.get(f"{name}_flops_over_peak") is not None:      # useful flops under the counters (the attention's ones-block MFMAs are busy cycles, not work)
+            out["pmc_flops_over_peak"] = t[f"{name}_flops_over_peak"]
     except Exception:
         pass
     return out, traffic, mfma_busy
@@ -236,6 +238,8 @@ def roofline_of(name, f, boundary_ms, committed=True, tag=""):
          "frac": round(ach / peak, 4), "traffic": traffic, "launches_per_step": f["launches"],
          "avg_launch_us": round(ms * 1e3 / f["launches"], 2), "ms_per_step": round(ms, 3),
          "kernel_only_ms": round(f["ms"], 3)}
+    if BOUND[name] == "mfma":
+        r["flops_over_peak"] = r["frac"]          # algorithmic (useful) flops over the dense peak, live: what mfma_busy must be read against
     if mfma_busy is not None:
         r["mfma_busy"] = mfma_busy
     if prof:

@@ -2,7 +2,7 @@
 # After tools/round_runs.sh and tools/round_profiles.sh (outputs merged under gpurun_out/$R): build the committed set profiles/rNN_*.
 # usage: R=r3 N=03 bash tools/collect_profiles.sh     (delete gpurun_out/$R/prof_final before the GPU run: stale files of an earlier run mix in)
 set -e
-R=${R:-r4}; N=${N:-04}
+R=${R:-r5}; N=${N:-05}
 cd "$(dirname "$0")/.."
 ks=$(ls -t gpurun_out/$R/prof_final/prof/*/*kernel_stats.csv | head -1); ds=$(ls -t gpurun_out/$R/prof_final/prof/*/*domain_stats.csv | head -1)
 cp "$ks" profiles/r${N}_bench_kernel_stats.csv; cp "$ds" profiles/r${N}_bench_domain_stats.csv

@@ -15,6 +15,13 @@ from stabletriton_amd import ops  # noqa: E402
 shapes = [(4096, 1280, 3840, 0), (4096, 1280, 5120, 1), (1024, 1280, 5120, 1), (16384, 640, 2560, 1), (16384, 2560, 640, 0)]
 if len(sys.argv) >= 4:
     shapes = [(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 0)]
+if os.environ.get("ST_PROBE_CFG"):          # force a tile configuration (100 = 256 x 256, 101 = 256 x 160): how does the loop's pace depend on how many CUs pull?
+    import ctypes
+    from stabletriton_amd import _C
+    _f = _C.load().st_debug_force_gemm
+    _f.argtypes, _f.restype = [ctypes.c_int, ctypes.c_int], None
+    _f(int(os.environ["ST_PROBE_CFG"]), -1)
+    shapes = [(256, 1280, 3840, 0), (1024, 1280, 3840, 0), (2048, 1280, 3840, 0), (4096, 1280, 3840, 0), (4096, 1280, 7680, 0), (4096, 5120, 3840, 0)]
 ctx = ops.ExecContext()
 with ctx:
     for M, K, N, geglu in shapes:

@@ -111,7 +111,8 @@ for name in shapes:
         rec["traffic_ratio"] = round(rec["hbm_side_bytes"] / nbytes, 2) if nbytes else None
     per[name] = rec
     if cnt and fam != "calib":
-        a = fam_acc.setdefault(fam, {"n": 0, "bytes": 0.0, "alg": 0.0, "mfma_ns": 0.0, "ns": 0.0})
+        a = fam_acc.setdefault(fam, {"n": 0, "bytes": 0.0, "alg": 0.0, "mfma_ns": 0.0, "ns": 0.0, "flops": 0.0})
+        a["flops"] += flops * cnt
         a["n"] += cnt
         a["bytes"] += rec.get("hbm_side_bytes", 0) * cnt
         a["alg"] += nbytes * cnt
@@ -124,6 +125,8 @@ for fam, a in fam_acc.items():
     out[f"{fam}_bytes_per_launch"] = int(a["bytes"] / a["n"])
     out[f"{fam}_algorithmic_bytes_per_launch"] = int(a["alg"] / a["n"])
     out[f"{fam}_mfma_busy"] = round(a["mfma_ns"] / a["ns"], 4)
+    if a["flops"]:      # USEFUL matrix work over the dense bf16 peak (mfma_busy also counts the attention's ones-block row sums: 4 of its 20 MFMAs per tile)
+        out[f"{fam}_flops_over_peak"] = round(a["flops"] / (a["ns"] * 1e-9) / 2.5e15, 4)
 path = os.path.join(root, "profiles", f"{rnd}_traffic.json")
 json.dump(out, open(path, "w"), indent=1)
 for k, v in per.items():

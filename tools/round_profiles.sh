@@ -1,7 +1,7 @@
 # The round's profile set (run on the GPU box from the repo root): rocprofv3 kernel-trace summary of the bench command, the
 # per-shape PMC passes, the vendor comparison.  Outputs under gpurun_out/; tools/profile_families.py and tools/pmc_ops.py
 # turn them into profiles/.
-R=${R:-r4}
+R=${R:-r5}
 set -x
 out=gpurun_out/$R/prof_final
 rm -rf $out && mkdir -p $out && cd /tmp && export TMPDIR=/tmp

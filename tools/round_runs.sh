@@ -1,7 +1,7 @@
 # The round's bench lines (run on the GPU box from the repo root; outputs under gpurun_out/$R/final): the default call with
 # its cpu_baseline and side measurements, the driver's call, the other batch sizes, fp16, the fp8 mode, the two-rank gloo
 # rehearsal of the multi-GPU path on one card; since round 4 the strict (fp32 / split operands) mode and the refiner img2img lines of config #5.  tools/round_profiles.sh collects the rocprofv3 / PMC set.
-R=${R:-r4}
+R=${R:-r5}
 set -x
 mkdir -p gpurun_out/$R/final && cd $GRAFT_REPO_ROOT
 o=gpurun_out/$R/final
