@@ -13,6 +13,7 @@ reference source is copied.
     python oracle/make_golden.py f1_b4          # ~1 min   (BASELINE config #3 rows: batch 4, per-row distinct conditioning)
     python oracle/make_golden.py f3_b2          # ~8 min   (two independent 50-step trajectories in one batch, latent 64)
     python oracle/make_golden.py f3_cfg         # ~8 min   (the Diffusers call-site protocol: CFG batch 2, 50 steps, latent 64)
+    python oracle/make_golden.py f1_b4_128      # ~3 min   (BASELINE config #3 at its own size: batch 4, latent 128, one step; stored sub-sampled)
     python oracle/make_golden.py f2_large       # ~1 min   (SURVEY 8c's attention sizes: T=1024 @ C=1280, T=4096 @ C=640; GroupNorm at 128 x 128)
     python oracle/make_golden.py f3_64_f64 f3_cfg_f64   # the reference module in DOUBLE precision through the same loops: what
                                                 # the reference's own fp32 arithmetic deviates from (the noise floor the 1e-3 gates are read against)
@@ -182,6 +183,20 @@ def f1_b4(ref):
 
 
 @torch.no_grad()
+def f1_b4_128(ref):
+    """BASELINE config #3 at the size it is benchmarked at (bs=4, 1024 x 1024 = latent 128, per-row distinct 77-token
+    conditioning): one eager step of the reference; every 31st value of the (4, 4, 128, 128) output is kept."""
+    m = ref_unet(ref)
+    x = synth.denoise_inputs(4, 128, INPUT_SEED)
+    cond = {"text_embeds": x["text_embeds"], "time_ids": x["time_ids"]}
+    t0 = time.time()
+    out = m(x["latent"], torch.tensor(500.0), x["encoder_hidden_states"], cond)[0]
+    print(f"F1_b4_128: {time.time() - t0:.0f}s  |ref| max = {float(out.abs().max()):.3f} rms = {float(out.pow(2).mean().sqrt()):.3f}")
+    save("f1_unet_step_latent128_b4", out=subsample(out), timestep=500.0, latent_hw=128, batch=4, out_rms=float(out.pow(2).mean().sqrt()),
+         out_max_abs=float(out.abs().max()))
+
+
+@torch.no_grad()
 def f3_b2(ref, hw=64):
     """Two independent prompts in one batch through the 50-step Euler loop (the batched DenoiseLoop)."""
     m = ref_unet(ref)
@@ -299,6 +314,8 @@ if __name__ == "__main__":
             f1_b4(ref)
         elif what == "f3_b2":
             f3_b2(ref)
+        elif what == "f1_b4_128":
+            f1_b4_128(ref)
         elif what == "f3_cfg":
             f3_cfg(ref)
         elif what == "f2_large":

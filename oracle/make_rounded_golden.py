@@ -10,6 +10,7 @@ path's own bf16 / fp16 deviation by a small factor of these numbers instead of b
     python oracle/make_rounded_golden.py f3_64         # ~10 min (two 50-step trajectories at latent 64)
     python oracle/make_rounded_golden.py f3_128        # ~45 min (latent 128)
     python oracle/make_rounded_golden.py f3_cfg        # ~40 min (the Diffusers call-site protocol: fp16 pipeline, CFG batch 2, latent 64)
+    python oracle/make_rounded_golden.py f1_fp8        # ~1 min (bf16 storage + the fp8 plan's e4m3 operands: what the fp8 mode's format costs on F1)
 """
 from __future__ import annotations
 
@@ -67,6 +68,22 @@ def run_f1(sd):
         rec[f"{name}_out"] = out[0, :, ::4, ::4].contiguous()
     rec["ref_rms"], rec["ref_max"] = ref_rms, ref_max
     save("f1_unet_step_latent64_rounded", **rec)
+
+
+def run_f1_fp8(sd):
+    """bf16 storage AND the projections of the fp8 plan on e4m3 operands (unet_oracle.fp8_plan): the deviation from the reference's
+    fp32 output that the fp8 mode's FORMAT causes on F1, before any kernel is involved."""
+    g = np.load(os.path.join(OUT, "f1_unet_step_latent64.npz"))
+    ref = torch.from_numpy(g["out"])
+    x = synth.denoise_inputs(1, 64, 1234)
+    dt = torch.bfloat16
+    sdr = orc.rounded_state_dict(sd, dt)
+    xr = {k: v.to(dt).float() for k, v in x.items()}
+    with torch.no_grad(), orc.storage(dt), orc.fp8_plan():
+        out = orc.unet_forward(sdr, xr["latent"], torch.tensor(999.0), xr["encoder_hidden_states"], xr["text_embeds"], xr["time_ids"])
+    mx, rms, ref_rms, ref_max = stats(out, ref)
+    print(f"F1 bf16 storage + fp8 plan: max abs {mx:.4f} rms {rms:.5f} = {rms / ref_rms:.3f} of the reference's rms {ref_rms:.4f} (|ref| max {ref_max:.2f})", flush=True)
+    save("f1_unet_step_latent64_fp8plan", max_abs=mx, rms=rms, rel_rms=rms / ref_rms, ref_rms=ref_rms, ref_max=ref_max, out=out[0, :, ::4, ::4].contiguous())
 
 
 def run_f3(sd, hw):
@@ -127,6 +144,8 @@ if __name__ == "__main__":
     sd = weights()
     if "f1" in what:
         run_f1(sd)
+    if "f1_fp8" in what:
+        run_f1_fp8(sd)
     if "f3_64" in what:
         run_f3(sd, 64)
     if "f3_128" in what:

@@ -57,6 +57,63 @@ def rounded_state_dict(sd: SD, dtype: torch.dtype) -> SD:
     return {k: v.to(dtype).float() for k, v in sd.items()}
 
 
+# ---- fp8-plan emulation (tests only): what e4m3 OPERANDS on the planned projections cost -----------------------------------
+# `with fp8_plan():` (inside `storage(torch.bfloat16)`: the fp8 mode runs on a bf16 model) multiplies the projections of the fp8
+# plan (stabletriton_amd/optimizers/plan_fp8.py: the LayerNorm-fed q|k|v, attn2.to_q and GEGLU projections and the feed-forward
+# output projection of every transformer block) the way the product does, in fp32 arithmetic: the activation as ONE e4m3 tensor
+# under a per-tensor scale of margin x max|x| / 448 (the delayed scale: the previous evaluation's maximum - on a single step the
+# calibration pass has seen this very tensor), the weight as e4m3 under per-output-channel scales, the LayerNorm folded around the
+# product (row statistics of the unquantised values; gamma folded into the weight BEFORE it is quantised; the GEGLU output kept
+# only as e4m3).  The deviation of such a run from the reference is what the operand format costs by itself; the gate of
+# tests/test_fp8_gpu.py is a small factor of that (oracle/make_rounded_golden.py f1_fp8), not of a measurement of the kernels.
+_FP8_PLAN = False
+FP8_MAX, FP8_MARGIN = 448.0, 2.0          # (stabletriton_amd/ops.py: FP8_MAX, FP8_MARGIN)
+
+
+class fp8_plan:
+    def __enter__(self):
+        global _FP8_PLAN
+        self.prev, _FP8_PLAN = _FP8_PLAN, True
+        return self
+
+    def __exit__(self, *exc):
+        global _FP8_PLAN
+        _FP8_PLAN = self.prev
+        return False
+
+
+def _e4m3_act(x: torch.Tensor) -> torch.Tensor:
+    s = x.abs().amax().clamp_min(1e-12) * FP8_MARGIN / FP8_MAX
+    return (x / s).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).float() * s
+
+
+def _e4m3_weight(w: torch.Tensor) -> torch.Tensor:
+    s = w.abs().amax(dim=1, keepdim=True).clamp_min(1e-12) / FP8_MAX
+    return (w / s).to(torch.float8_e4m3fn).float() * s
+
+
+def ln_linear_fp8(sd: SD, ln_p: str, lin_ps, x):
+    """LayerNorm(x) -> the projections `lin_ps` as the fp8 plan computes them (st_linear_fp8x with a folded LayerNorm)."""
+    g, b = sd[ln_p + ".weight"], sd[ln_p + ".bias"]
+    mean = x.mean(-1, keepdim=True)
+    rstd = (x.var(-1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    xn = (_e4m3_act(x) - mean) * rstd                  # the e4m3 copy of the un-normalised tensor, the statistics of the stored values
+    outs = []
+    for lp in lin_ps:
+        w = sd[lp + ".weight"]
+        d = w @ b
+        if lp + ".bias" in sd:
+            d = d + sd[lp + ".bias"]
+        outs.append(_r(xn @ _e4m3_weight(w * g[None, :]).T + d))
+    return outs
+
+
+def linear_fp8(sd: SD, p: str, x8):
+    """x8 (already e4m3 values) times the e4m3 weight (+ bias): the feed-forward output projection of the plan."""
+    y = x8 @ _e4m3_weight(sd[p + ".weight"]).T
+    return y + sd[p + ".bias"] if p + ".bias" in sd else y
+
+
 def _has(sd: SD, key: str) -> bool:
     return key in sd
 
@@ -139,8 +196,23 @@ def geglu(x_proj):
     return _r(a * F.gelu(g))
 
 
+def _transformer_layer_fp8(sd: SD, p: str, x, context, head_dim: int):
+    """transformer_layer with the planned projections on e4m3 operands (see fp8_plan); everything else as below."""
+    q, k, v = ln_linear_fp8(sd, p + ".norm1", [p + ".attn1.to_q", p + ".attn1.to_k", p + ".attn1.to_v"], x)
+    x = _r(linear(sd, p + ".attn1.to_out.0", attention_core(q, k, v, q.shape[-1] // head_dim)) + x)
+    (q,) = ln_linear_fp8(sd, p + ".norm2", [p + ".attn2.to_q"], x)
+    k, v = linear(sd, p + ".attn2.to_k", context), linear(sd, p + ".attn2.to_v", context)
+    x = _r(linear(sd, p + ".attn2.to_out.0", attention_core(q, k, v, q.shape[-1] // head_dim)) + x)
+    (hp,) = ln_linear_fp8(sd, p + ".norm3", [p + ".ff.net.0.proj"], x)
+    a, gte = hp.chunk(2, dim=-1)
+    h8 = _e4m3_act(a * F.gelu(gte))                     # the GEGLU projection leaves ONLY the e4m3 copy of its output
+    return _r(linear_fp8(sd, p + ".ff.net.2", h8) + x)
+
+
 def transformer_layer(sd: SD, p: str, x, context, head_dim: int = 64):
     """unet_pt.py:189-210."""
+    if _FP8_PLAN:
+        return _transformer_layer_fp8(sd, p, x, context, head_dim)
     x = _r(attention(sd, p + ".attn1", layer_norm(sd, p + ".norm1", x), None, head_dim) + x)
     x = _r(attention(sd, p + ".attn2", layer_norm(sd, p + ".norm2", x), context, head_dim) + x)
     h = geglu(linear(sd, p + ".ff.net.0.proj", layer_norm(sd, p + ".norm3", x)))

@@ -122,10 +122,11 @@ def test_fp8_mode_claims_the_transformer_projections():
 
 
 def test_fp8_unet_step_vs_oracle(gpu, sdxl_bf16_pair):
-    """One SDXL-base step (F1 input) with fp8 projections against the reference's own output.  Tolerance: the
-    projections carry ~4 % rms error each (above); through 70 transformer layers with residual connections the output
-    deviates by a few tens of percent of its rms in this random-weight network - reported, and gated at 1.5 x the measured value to catch
-    a broken kernel (bf16 mode: 0.04)."""
+    """One SDXL-base step (F1 input) with fp8 projections against the reference's own output.  Round 5: the bound is DERIVED - the
+    oracle (pinned to the reference bit for bit) was run with bf16 storage AND the plan's projections on e4m3 operands, in fp32
+    arithmetic (`unet_oracle.fp8_plan`, `oracle/make_rounded_golden.py f1_fp8`): that format alone moves the output by 0.259 of its
+    rms in this random-weight network (70 layers of ~4 % per projection).  The HIP path may deviate by STORAGE_FACTOR = 1.3 times
+    that; it measures 0.262 - the kernels add nothing of their own."""
     from stabletriton_amd import synth
     from stabletriton_amd.optimization import optimize_model
     from tests.util import golden
@@ -139,7 +140,9 @@ def test_fp8_unet_step_vs_oracle(gpu, sdxl_bf16_pair):
     ref = torch.from_numpy(golden("f1_unet_step_latent64")["out"])
     rms = float((out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
     print(f"F1 with fp8 projections: relative rms error {rms:.3f}, max abs {float((out - ref).abs().max()):.3f} (|ref| max {float(ref.abs().max()):.2f})")
-    assert torch.isfinite(out).all() and rms <= 0.39          # 1.5 x the measured 0.262
+    emulated = float(golden("f1_unet_step_latent64_fp8plan")["rel_rms"])
+    print(f"  (e4m3 operands alone, oracle emulation: {emulated:.3f}; ratio {rms / emulated:.2f})")
+    assert torch.isfinite(out).all() and rms <= 1.3 * emulated
 
 
 # ---------------------------------------------------------------------------------- the fp8 plan: e4m3 copies from epilogues, delayed scales

@@ -151,6 +151,12 @@ def test_storage_emulation_is_the_identity_when_off_and_rounds_when_on():
             err = float((r - plain).abs().max())
             assert lo < err < hi, (dt, err)
         assert torch.equal(orc.unet_forward(sd, *args), plain)           # and the switch is off again
+        with orc.storage(torch.bfloat16), orc.fp8_plan():          # the fp8 plan's operand format on top (round 5): a further, larger deviation
+            r8 = orc.unet_forward(orc.rounded_state_dict(sd, torch.bfloat16), *args)
+        assert float((r8 - plain).abs().max()) > float((r - plain).abs().max()) * 0.5 and torch.isfinite(r8).all()
+        assert torch.equal(orc.unet_forward(sd, *args), plain)           # off again
+    g8 = golden("f1_unet_step_latent64_fp8plan")
+    assert 0.1 < float(g8["rel_rms"]) < 0.5
     for name in ("f1_unet_step_latent64", "f3_euler50_latent64", "f3_euler50_latent128", "f3_cfg50_latent64"):
         g = golden(name + "_rounded")
         assert float(g["fp16_rms"]) < float(g["bf16_rms"]) and float(g["bf16_max_abs"]) > 0          # the fixtures the gates read

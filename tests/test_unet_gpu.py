@@ -401,6 +401,30 @@ def test_sdxl_f3_b2_euler50_bf16(gpu, sdxl_bf16):
     assert torch.isfinite(out).all() and rms <= storage_bound("f3_euler50_latent64", "bf16")[1]      # (per row: the bs=1 storage error)
 
 
+def _sdxl_step_b4_128(gm, dtype, dev):
+    x = synth.denoise_inputs(4, 128, 1234)
+    cond = {"text_embeds": x["text_embeds"].to(dev, dtype), "time_ids": x["time_ids"].to(dev, dtype)}
+    with torch.no_grad():
+        return gm(x["latent"].to(dev, dtype), torch.tensor(500.0, device=dev), x["encoder_hidden_states"].to(dev, dtype), cond)[0].float().cpu()
+
+
+def test_sdxl_f1_b4_latent128_against_the_reference(gpu, sdxl_fp32, sdxl_bf16):
+    """BASELINE config #3 at the size it is benchmarked at - bs=4, latent 128 (1024 x 1024), distinct 77-token conditioning per row -
+    against the REFERENCE's own output of that step (round 5: `oracle/make_golden.py f1_b4_128`, every 31st value kept).  Before
+    this the full-size batch was only compared with its own bs=1 runs."""
+    g = golden("f1_unet_step_latent128_b4")
+    ref = torch.from_numpy(g["out"])
+    out = _sub(_sdxl_step_b4_128(sdxl_fp32, torch.float32, gpu)).reshape(ref.shape)
+    err = float((out - ref).abs().max())
+    print(f"F1-b4 latent128 fp32: max abs err {err:.2e} (|ref| max {float(g['out_max_abs']):.2f})")
+    assert err <= ABS_TOL_STRICT
+    out = _sub(_sdxl_step_b4_128(sdxl_bf16, torch.bfloat16, gpu)).reshape(ref.shape)
+    err, rms = float((out - ref).abs().max()), float((out - ref).pow(2).mean().sqrt())
+    print(f"F1-b4 latent128 bf16: max abs err {err:.2e}, rms err {rms:.2e} (|ref| rms {float(g['out_rms']):.2f})")
+    bound_max, bound_rms = storage_bound("f1_unet_step_latent64", "bf16")      # (one step: what bf16 storage alone costs, measured at latent 64)
+    assert rms <= bound_rms * float(g["out_rms"]) / 0.45 and err <= 2.0 * bound_max
+
+
 @pytest.mark.parametrize("hw", [64, 128])
 def test_sdxl_loop_batch4_rows_are_independent(gpu, sdxl_fp32, hw):
     """DenoiseLoop(batch=4) at BASELINE config #3's size: the samples of a batch never mix, so every row of a batch-4
