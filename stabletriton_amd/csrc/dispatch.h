@@ -112,7 +112,9 @@ static inline int forced_cfg() {
 }
 
 template <typename T, bool CONV>
-static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
+static int gemm_dispatch(const GemmArgs& a_in, hipStream_t st, int depth = 0) {
+    GemmArgs a = a_in;
+    if (a.Ng == 0) a.Ng = a.N;                   // (a whole projection: the gate rows follow the N value rows)
     const long n_eff = (a.epi & ST_EPI_GEGLU) ? 2L * a.N : a.N;
     auto tiles = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(n_eff, bn); };
     constexpr int KB = 128 / (int)sizeof(T);
@@ -154,31 +156,39 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
         const bool can_split = a.partial && !a.ln_c && force_sk != 0 && force_sk != 1;
         int cfg = CFG_64x64_W8, sk = 1;
         double best = 1e30;
-        for (const Cand& c : cands) {
-            if (frag2<T>() && c.bn == 320) continue;                     // fp8 / split fragments are 32 bytes: the 320-wide wave tiles spill
-            if (is_split<T>() && c.cfg == CFG_256x128_W8) continue;      // two accumulator sets: wave tiles of at most 10 x 16 x 16 (128 x 160 as 4 x 2 waves)
-            if ((a.epi & ST_EPI_GEGLU) && c.bn % 32 != 0) continue;      // GEGLU: the value / gate halves of a tile are whole accumulator tiles (BN = 80 is not)
-            const long nt = tiles(c.bm, c.bn);
-            // (split operands: the 128 x 160 tile runs as 4 x 2 waves with ten accumulator tiles in each of two sets; measured
-            //  0.8 us per trip - it wins the GEGLU projection of the 1280 level by whole rounds, 512 tiles against 640, 104 -> 93 us,
-            //  and loses q|k|v to 128 x 128 at its fitted 16-bit constant)
-            const double trip = (is_split<T>() && c.cfg == CFG_128x160_W8 ? 0.8 : c.trip_us) * (CONV ? 1.6 : 1.0);
-            for (int k_ : sks) {
-                if (k_ > 1 && (!can_split || nk / k_ < 4 || nt > 16384)) break;
-                const double slab_mb = (double)k_ * nt * c.bm * c.bn * 4.0 / 1e6;
-                if (k_ > 1 && slab_mb * 1e6 + 65536 > (double)a.partial_bytes) break;
-                const double rounds = (double)((nt * k_ + 255) / 256);
-                // with (nearly) every CU pulling, the K tiles of a round leave L2 at ~14 TB/s together: 256 blocks of
-                // 128 x 80 need 6.8 MB per trip = 0.49 us, not the 0.37 us one of them takes among 160
-                // (tools/gemm_sweep.py: 2048 x 1280 x 5120 on that tile 43 us against 33 predicted)
-                const double in_round = (double)(nt * k_ < 256 ? nt * k_ : 256);
-                const double trip_bw = in_round * (c.bm + c.bn) * 128.0 / 14.0e6;
-                // (the per-trip constants were fitted on one-round launches; launches of several rounds run 25-45 % over them
-                //  - tools/gemm_sweep.py: 2048 x 10240 x 1280 on 256 x 128 tiles 73 us against 52 predicted - hence the factor)
-                const double cost = rounds * (cdiv(nk, k_) * (trip > trip_bw ? trip : trip_bw) + 3.0) * (rounds > 1.0 ? 1.3 : 1.0) + (k_ > 1 ? 2.1 + 0.4 * slab_mb : 0.0);
-                if (cost < best) { best = cost; cfg = c.cfg; sk = k_; }
+        // the model over the LDS-DMA kernel's tiles for a problem of `ncols_` tile columns' worth of W rows (this launch's, or - the
+        // column split below - a remainder's): returns the predicted microseconds, optionally the configuration
+        auto small_model = [&](long ncols_, int* cfg_out, int* sk_out) {
+            auto tiles_ = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(ncols_, bn); };
+            double best_ = 1e30;
+            for (const Cand& c : cands) {
+                if (frag2<T>() && c.bn == 320) continue;                     // fp8 / split fragments are 32 bytes: the 320-wide wave tiles spill
+                if (is_split<T>() && c.cfg == CFG_256x128_W8) continue;      // two accumulator sets: wave tiles of at most 10 x 16 x 16 (128 x 160 as 4 x 2 waves)
+                if ((a.epi & ST_EPI_GEGLU) && c.bn % 32 != 0) continue;      // GEGLU: the value / gate halves of a tile are whole accumulator tiles (BN = 80 is not)
+                const long nt = tiles_(c.bm, c.bn);
+                // (split operands: the 128 x 160 tile runs as 4 x 2 waves with ten accumulator tiles in each of two sets: measured
+                //  0.8 us per trip - it wins the GEGLU projection of the 1280 level by whole rounds, 512 tiles against 640, 104 -> 93 us,
+                //  and loses q|k|v to 128 x 128 at its fitted 16-bit constant)
+                const double trip = (is_split<T>() && c.cfg == CFG_128x160_W8 ? 0.8 : c.trip_us) * (CONV ? 1.6 : 1.0);
+                for (int k_ : sks) {
+                    if (k_ > 1 && (!can_split || nk / k_ < 4 || nt > 16384)) break;
+                    const double slab_mb = (double)k_ * nt * c.bm * c.bn * 4.0 / 1e6;
+                    if (k_ > 1 && slab_mb * 1e6 + 65536 > (double)a.partial_bytes) break;
+                    const double rounds = (double)((nt * k_ + 255) / 256);
+                    // with (nearly) every CU pulling, the K tiles of a round leave L2 at ~14 TB/s together: 256 blocks of
+                    // 128 x 80 need 6.8 MB per trip = 0.49 us, not the 0.37 us one of them takes among 160
+                    // (tools/gemm_sweep.py: 2048 x 1280 x 5120 on that tile 43 us against 33 predicted)
+                    const double in_round = (double)(nt * k_ < 256 ? nt * k_ : 256);
+                    const double trip_bw = in_round * (c.bm + c.bn) * 128.0 / 14.0e6;
+                    // (the per-trip constants were fitted on one-round launches; launches of several rounds run 25-45 % over them
+                    //  - tools/gemm_sweep.py: 2048 x 10240 x 1280 on 256 x 128 tiles 73 us against 52 predicted - hence the factor)
+                    const double cost = rounds * (cdiv(nk, k_) * (trip > trip_bw ? trip : trip_bw) + 3.0) * (rounds > 1.0 ? 1.3 : 1.0) + (k_ > 1 ? 2.1 + 0.4 * slab_mb : 0.0);
+                    if (cost < best_) { best_ = cost; if (cfg_out) *cfg_out = c.cfg; if (sk_out) *sk_out = k_; }
+                }
             }
-        }
+            return best_;
+        };
+        best = small_model(ncols, &cfg, &sk);
         if constexpr (!CONV && sizeof(T) <= 2) {
             // the eight-phase kernel (256 x 256 or 256 x 160 tiles): no K split, whole rounds of 256 blocks.  A K step costs
             // ~1.65 us for 256 x 256 x 64 and ~1.5 us for 256 x 160 x 64 (measured, tools/gemm8p_check.py: a phase is paced by
@@ -197,6 +207,41 @@ static int gemm_dispatch(const GemmArgs& a, hipStream_t st) {
 #endif
             // (near ties go to this kernel: 1.1 - it was 1.3 while the small-tile predictions above still lacked their
             //  several-rounds and all-CUs-pulling corrections, and then took 8192 x 1920 x 640 at 40 us against 33)
+            // Round 5, column split: a launch of 256 x 256 tiles whose last round is at most half full (the GEGLU projection at batch 4:
+            // 640 tiles = 2.5 rounds; at batch 2: 320 = 1.25) pays a whole round for it.  The full rounds' tile COLUMNS stay on this
+            // kernel; the remaining columns are a problem of their own that the model places on smaller tiles (one more launch: the
+            // two write disjoint column ranges of y; GemmArgs::Ng keeps the gate rows of a GEGLU projection where they are).
+            static const bool no_colsplit = dev_env_int("ST_NO_COLSPLIT", 0) != 0;
+            if (f < 0 && depth == 0 && !no_colsplit && c256 < 1e29 && !a.row_stats && !a.col_stats && !a.q8_out && !a.sp_out && !a.row_scale) {
+                const long tm = a.M / 256, total = tiles(256, 256);
+                const long rem = total % 256;
+                if (total > 256 && rem > 0 && rem <= 128 && 256 % tm == 0) {
+                    const long full_cols = (total / 256) * (256 / tm);                           // tile columns of the full rounds
+                    const long rem_rows = n_eff - full_cols * 256;                                // W rows (value + gate) of the remainder
+                    const double c_full = (double)(total / 256) * (nk * 1.65 + 4.0);
+                    const double c_split = c_full + small_model(rem_rows, nullptr, nullptr) + 2.5;
+                    const double c_whole = c256 < c160 ? c256 : c160;
+                    if (c_split < 0.93 * (c_whole < best ? c_whole : best)) {
+                        const int bno = (a.epi & ST_EPI_GEGLU) ? 128 : 256;
+                        const long n1 = full_cols * bno;                                          // output columns of the first launch
+                        typedef typename OutT<T>::type TO_;
+                        GemmArgs a1 = a, a2 = a;
+                        a1.N = (int)n1;
+                        a1.next_w = (const char*)a.W + (size_t)n1 * a.K * sizeof(T); a1.next_bytes = (size_t)(a.N - n1) * a.K * sizeof(T);      // (the remainder's weights)
+                        a2.N = a.N - (int)n1;
+                        a2.W = (const char*)a.W + (size_t)n1 * a.K * sizeof(T);
+                        a2.C = (char*)a.C + (size_t)n1 * sizeof(TO_);
+                        if (a.bias) a2.bias = (const char*)a.bias + (size_t)n1 * sizeof(TO_);
+                        if (a.residual) a2.residual = (const char*)a.residual + (size_t)n1 * sizeof(TO_);
+                        if (a.ln_c) { a2.ln_c = a.ln_c + n1; a2.ln_d = a.ln_d + n1; }
+                        if (a.col_scale) a2.col_scale = a.col_scale + n1;
+                        if (a.stats_chunks_out) *a.stats_chunks_out = 0;
+                        gemm8p_launch<T, 256, 2, 4>(a1, st);
+                        if (int e = st_check_launch(who)) return e;
+                        return gemm_dispatch<T, CONV>(a2, st, depth + 1);
+                    }
+                }
+            }
             const bool take256 = f == CFG_256x256_8P || (f < 0 && c256 <= c160 && c256 < 1.1 * best);
             const bool take160 = f == CFG_256x160_8P || (f < 0 && c160 < c256 && c160 < 1.1 * best);
             if (take256 && c256 < 1e29) { gemm8p_launch<T, 256, 2, 4>(a, st); return st_check_launch(who); }

@@ -22,7 +22,7 @@ __device__ __forceinline__ void epilogue_compute4(const GemmArgs& p, int m, int 
     for (int e = 0; e < 4; ++e) g[e] = g_in[e];
     if (p.col_scale) {                                 // fp8 operands: dequantisation scales
         const float rs = p.row_scale[(size_t)m * p.rs_stride];
-        for (int e = 0; e < 4 && n + e < p.N; ++e) { v[e] *= rs * p.col_scale[n + e]; if (GEGLU) g[e] *= rs * p.col_scale[p.N + n + e]; }
+        for (int e = 0; e < 4 && n + e < p.N; ++e) { v[e] *= rs * p.col_scale[n + e]; if (GEGLU) g[e] *= rs * p.col_scale[p.Ng + n + e]; }
     }
     if (p.ln_c) {                                      // folded LayerNorm: rank-1 correction per row / column
         if (full) {
@@ -31,14 +31,14 @@ __device__ __forceinline__ void epilogue_compute4(const GemmArgs& p, int m, int 
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ln_fold(v[e], ln_mean, ln_rstd, c4[e], d4[e]);
             if (GEGLU) {
-                Out4<float>::load(p.ln_c + p.N + n, c4); Out4<float>::load(p.ln_d + p.N + n, d4);
+                Out4<float>::load(p.ln_c + p.Ng + n, c4); Out4<float>::load(p.ln_d + p.Ng + n, d4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = ln_fold(g[e], ln_mean, ln_rstd, c4[e], d4[e]);
             }
         } else {
             for (int e = 0; e < 4 && n + e < p.N; ++e) {
                 v[e] = ln_fold(v[e], ln_mean, ln_rstd, p.ln_c[n + e], p.ln_d[n + e]);
-                if (GEGLU) g[e] = ln_fold(g[e], ln_mean, ln_rstd, p.ln_c[p.N + n + e], p.ln_d[p.N + n + e]);
+                if (GEGLU) g[e] = ln_fold(g[e], ln_mean, ln_rstd, p.ln_c[p.Ng + n + e], p.ln_d[p.Ng + n + e]);
             }
         }
     }
@@ -52,11 +52,11 @@ __device__ __forceinline__ void epilogue_compute4(const GemmArgs& p, int m, int 
     }
     if (GEGLU) {
         if (p.epi & ST_EPI_BIAS) {
-            if (full) { float b4[4]; Out4<T>::load(bias + p.N + n, b4);
+            if (full) { float b4[4]; Out4<T>::load(bias + p.Ng + n, b4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] += b4[e];
             } else {
-                for (int e = 0; e < 4 && n + e < p.N; ++e) g[e] += Elem<T>::to_f(bias[p.N + n + e]);
+                for (int e = 0; e < 4 && n + e < p.N; ++e) g[e] += Elem<T>::to_f(bias[p.Ng + n + e]);
             }
         }
 #pragma unroll
@@ -168,21 +168,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     csc[j] = *reinterpret_cast<const f32x4*>(p.col_scale + ncol[J0 + j]);
-                    if (GEGLU) gsc[j] = *reinterpret_cast<const f32x4*>(p.col_scale + p.N + ncol[J0 + j]);
+                    if (GEGLU) gsc[j] = *reinterpret_cast<const f32x4*>(p.col_scale + p.Ng + ncol[J0 + j]);
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i) rsc[i] = p.row_scale[(size_t)mrow[i] * p.rs_stride];
             }
             if (has_bias) {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) { braw[j] = ld_raw4<T>(bias + ncol[J0 + j]); if (GEGLU) graw[j] = ld_raw4<T>(bias + p.N + ncol[J0 + j]); }
+                for (int j = 0; j < NJ; ++j) { braw[j] = ld_raw4<T>(bias + ncol[J0 + j]); if (GEGLU) graw[j] = ld_raw4<T>(bias + p.Ng + ncol[J0 + j]); }
             }
             if (has_ln) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int n = ncol[J0 + j];
                     cv[j] = *reinterpret_cast<const f32x4*>(p.ln_c + n); dv[j] = *reinterpret_cast<const f32x4*>(p.ln_d + n);
-                    if (GEGLU) { cg[j] = *reinterpret_cast<const f32x4*>(p.ln_c + p.N + n); dg[j] = *reinterpret_cast<const f32x4*>(p.ln_d + p.N + n); }
+                    if (GEGLU) { cg[j] = *reinterpret_cast<const f32x4*>(p.ln_c + p.Ng + n); dg[j] = *reinterpret_cast<const f32x4*>(p.ln_d + p.Ng + n); }
                 }
             }
             if (has_rb) {
@@ -432,17 +432,17 @@ __device__ __forceinline__ void staged_epilogue_impl(const GemmArgs& p, f32x4 (&
         if (vec_cols) {
             if (has_bias) {
                 bia = *reinterpret_cast<const OV*>(bias + n);
-                if (GEGLU) big = *reinterpret_cast<const OV*>(bias + p.N + n);
+                if (GEGLU) big = *reinterpret_cast<const OV*>(bias + p.Ng + n);
             }
-            if (has_ln) { ldf(p.ln_c + n, lc); ldf(p.ln_d + n, ld); if (GEGLU) { ldf(p.ln_c + p.N + n, lcg); ldf(p.ln_d + p.N + n, ldg); } }
-            if (has_scale) { ldf(p.col_scale + n, cs); if (GEGLU) ldf(p.col_scale + p.N + n, csg); }
+            if (has_ln) { ldf(p.ln_c + n, lc); ldf(p.ln_d + n, ld); if (GEGLU) { ldf(p.ln_c + p.Ng + n, lcg); ldf(p.ln_d + p.Ng + n, ldg); } }
+            if (has_scale) { ldf(p.col_scale + n, cs); if (GEGLU) ldf(p.col_scale + p.Ng + n, csg); }
         } else {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const int ne = (n + e < p.N) ? n + e : p.N - 1;       // clamped: every load unconditional
-                if (has_bias) { bia[e] = bias[ne]; if (GEGLU) big[e] = bias[p.N + ne]; }
-                if (has_ln) { lc[e] = p.ln_c[ne]; ld[e] = p.ln_d[ne]; if (GEGLU) { lcg[e] = p.ln_c[p.N + ne]; ldg[e] = p.ln_d[p.N + ne]; } }
-                if (has_scale) { cs[e] = p.col_scale[ne]; if (GEGLU) csg[e] = p.col_scale[p.N + ne]; }
+                if (has_bias) { bia[e] = bias[ne]; if (GEGLU) big[e] = bias[p.Ng + ne]; }
+                if (has_ln) { lc[e] = p.ln_c[ne]; ld[e] = p.ln_d[ne]; if (GEGLU) { lcg[e] = p.ln_c[p.Ng + ne]; ldg[e] = p.ln_d[p.Ng + ne]; } }
+                if (has_scale) { cs[e] = p.col_scale[ne]; if (GEGLU) csg[e] = p.col_scale[p.Ng + ne]; }
             }
         }
     }
@@ -794,20 +794,20 @@ __device__ __forceinline__ void direct_epilogue_impl(const GemmArgs& p, f32x4 (&
 #pragma unroll
     for (int w = 0; w < NW_; ++w) {
         const int n = nw0 + cb_of(w) + 8 * q;
-        if (has_bias) { bv[w] = *reinterpret_cast<const OV*>(bias + n); if (GEGLU) bg[w] = *reinterpret_cast<const OV*>(bias + p.N + n); }
+        if (has_bias) { bv[w] = *reinterpret_cast<const OV*>(bias + n); if (GEGLU) bg[w] = *reinterpret_cast<const OV*>(bias + p.Ng + n); }
         if (has_ln) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 cv[w][h] = *reinterpret_cast<const f32x4*>(p.ln_c + n + 4 * h); dv[w][h] = *reinterpret_cast<const f32x4*>(p.ln_d + n + 4 * h);
-                if (GEGLU) { cg[w][h] = *reinterpret_cast<const f32x4*>(p.ln_c + p.N + n + 4 * h); dg[w][h] = *reinterpret_cast<const f32x4*>(p.ln_d + p.N + n + 4 * h); }
+                if (GEGLU) { cg[w][h] = *reinterpret_cast<const f32x4*>(p.ln_c + p.Ng + n + 4 * h); dg[w][h] = *reinterpret_cast<const f32x4*>(p.ln_d + p.Ng + n + 4 * h); }
             }
         }
     }
     if constexpr (NARROW) {
-        if (has_bias) { nbv = ld_raw4<TO>(bias + nn); if (GEGLU) nbg = ld_raw4<TO>(bias + p.N + nn); }
+        if (has_bias) { nbv = ld_raw4<TO>(bias + nn); if (GEGLU) nbg = ld_raw4<TO>(bias + p.Ng + nn); }
         if (has_ln) {
             ncv = *reinterpret_cast<const f32x4*>(p.ln_c + nn); ndv = *reinterpret_cast<const f32x4*>(p.ln_d + nn);
-            if (GEGLU) { ncg = *reinterpret_cast<const f32x4*>(p.ln_c + p.N + nn); ndg = *reinterpret_cast<const f32x4*>(p.ln_d + p.N + nn); }
+            if (GEGLU) { ncg = *reinterpret_cast<const f32x4*>(p.ln_c + p.Ng + nn); ndg = *reinterpret_cast<const f32x4*>(p.ln_d + p.Ng + nn); }
         }
     }
     // residual: all rows at once, except on the tall wave tiles (TM = 8: 128 accumulator registers + 64 of residual spill) -

@@ -74,11 +74,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     const T* a_src[2];
     const T* b0_src[2];
     const T* b1_src[2];
-    auto w_row = [&](int c) { return GEGLU ? (c < BN / 2 ? (size_t)(n0 + c) : (size_t)p.N + n0 + (c - BN / 2)) : (size_t)(n0 + c); };
+    auto w_row = [&](int c) { return GEGLU ? (c < BN / 2 ? (size_t)(n0 + c) : (size_t)p.Ng + n0 + (c - BN / 2)) : (size_t)(n0 + c); };
     // DIRECT: W staged permuted (epilogue.h, direct epilogue): accumulator tile j of wave column wc, tile row rho -> row of W
     auto w_row_direct = [&](int wc, int j, int rho) {
         const DirectCol dc = direct_col<TN, GEGLU>(j, rho);
-        return (size_t)(dc.gate ? p.N : 0) + n0 + wc * (GEGLU ? WTN / 2 : WTN) + dc.col;
+        return (size_t)(dc.gate ? p.Ng : 0) + n0 + wc * (GEGLU ? WTN / 2 : WTN) + dc.col;
     };
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -124,11 +124,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
         };
         if (p.epi & ST_EPI_BIAS) {
             touch(p.bias, (long)n0 * 2, BNO * 2);
-            if (GEGLU) touch(p.bias, ((long)p.N + n0) * 2, BNO * 2);
+            if (GEGLU) touch(p.bias, ((long)p.Ng + n0) * 2, BNO * 2);
         }
         if (LNF) {
             touch(p.ln_c, (long)n0 * 4, BNO * 4); touch(p.ln_d, (long)n0 * 4, BNO * 4);
-            if (GEGLU) { touch(p.ln_c, ((long)p.N + n0) * 4, BNO * 4); touch(p.ln_d, ((long)p.N + n0) * 4, BNO * 4); }
+            if (GEGLU) { touch(p.ln_c, ((long)p.Ng + n0) * 4, BNO * 4); touch(p.ln_d, ((long)p.Ng + n0) * 4, BNO * 4); }
         }
         if (p.epi & ST_EPI_RESIDUAL) {
             constexpr int lines = (BNO * 2 + 127) / 128;

@@ -11,6 +11,8 @@
 struct GemmArgs {
     const void* A; const void* W; const void* bias; const void* residual; const void* rowbias; void* C;
     int M, N, K;                 // N = output columns (with GEGLU: W has 2N rows)
+    int Ng;                      // GEGLU: rows between a value row of W (bias, ln_c, ln_d, col_scale entry) and its gate row - N of the whole
+                                 //   projection; a launch over a COLUMN RANGE of it (gemm_dispatch's column split) has N < Ng.  0 = N.
     long lda, ldc, ldr;
     int rows_per_batch;
     int epi;

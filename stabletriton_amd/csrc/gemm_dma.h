@@ -244,7 +244,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
             const int half = row >= BN / 2 ? 1 : 0;
             const int ncol = n0 + row - half * (BN / 2);
             ok = ncol < p.N && (!UNEVEN || wave + i * NW < B_PIECES);
-            wrow = ncol + half * p.N;
+            wrow = ncol + half * p.Ng;
         } else {
             wrow = n0 + row;
             ok = wrow < p.N && (!UNEVEN || wave + i * NW < B_PIECES);
@@ -271,11 +271,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_dma_kernel(const GemmArgs 
         };
         if (p.epi & ST_EPI_BIAS) {
             touch(p.bias, (long)n0 * sizeof(TO), ncols_out * (int)sizeof(TO));
-            if (GEGLU) touch(p.bias, ((long)p.N + n0) * sizeof(TO), ncols_out * (int)sizeof(TO));
+            if (GEGLU) touch(p.bias, ((long)p.Ng + n0) * sizeof(TO), ncols_out * (int)sizeof(TO));
         }
         if (LNF) {
             touch(p.ln_c, (long)n0 * 4, ncols_out * 4); touch(p.ln_d, (long)n0 * 4, ncols_out * 4);
-            if (GEGLU) { touch(p.ln_c, ((long)p.N + n0) * 4, ncols_out * 4); touch(p.ln_d, ((long)p.N + n0) * 4, ncols_out * 4); }
+            if (GEGLU) { touch(p.ln_c, ((long)p.Ng + n0) * 4, ncols_out * 4); touch(p.ln_d, ((long)p.Ng + n0) * 4, ncols_out * 4); }
         }
         if (p.epi & ST_EPI_RESIDUAL) {
             const int lines = (ncols_out * (int)sizeof(TO) + 127) / 128;      // per row

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
             const int half = local >= WTN / 2 ? 1 : 0;
             const int ncol = n0 + w_ * (WTN / 2) + (local - half * (WTN / 2));
             ok = ok && ncol < p.N;
-            wrow = ncol + half * p.N;
+            wrow = ncol + half * p.Ng;
         } else {
             wrow = n0 + row;
             ok = ok && wrow < p.N;

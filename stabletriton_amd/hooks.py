@@ -51,6 +51,7 @@ class _HoistedUNet(nn.Module):
         self._ctx_copy: Dict[tuple, torch.Tensor] = {}
         self._steps: Dict[tuple, object] = {}     # ehs shape -> (graphed) step function
         self._new_prompt = False                  # set when a context was (re)projected: the fp8 plan measures its scales again
+        self._last_t = None                       # fp8 plan only: the last call's (largest) timestep, to tell where a trajectory starts
 
     def refresh_weights(self) -> int:
         """Re-derive fused / folded weight buffers after an in-place weight update (also done at every new prompt).
@@ -99,6 +100,28 @@ class _HoistedUNet(nn.Module):
             self._steps[shape] = fn
         return fn
 
+    def _fp8_restart(self, x, timesteps, shape, cond) -> None:
+        """fp8 plan: the delayed activation scales restart from the first evaluation of every TRAJECTORY, as `DenoiseLoop` does
+        (the hooks only restarted them when the prompt changed, so a new seed under the same prompt quantised its
+        first step with the scales of the previous trajectory's last one).  A trajectory start is a new prompt or a timestep
+        that is larger than the last call's (within a trajectory the timesteps fall); reading the timestep costs one host
+        sync per call, paid only in this mode.  Under a stream capture of the caller's own nothing can be measured: a captured
+        call replays whatever scales the last eager call left - evaluate the trajectory's first step eagerly before capturing."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        t = float(timesteps.max())
+        start = self._new_prompt or self._last_t is None or t > self._last_t
+        self._last_t = t
+        if start:
+            from .optimization import recalibrate_fp8
+            ctx = self._ctx[shape]
+            run_once = lambda: self.compiled.forward_with_context(x, timesteps, ctx, cond)
+            ectx = getattr(self.compiled, "exec_context", None)
+            if ectx is not None and ectx.fp8 is None:
+                with torch.no_grad():
+                    run_once()          # the very first evaluation creates the scale slots; after it this trajectory starts like every later one
+            recalibrate_fp8(self.compiled, run_once)
+
     def _run(self, sample, timesteps, ehs, cond):
         # (.to() is the identity when the caller already computes in this dtype: an fp16 pipeline over an fp16 module)
         io_dtype = sample.dtype
@@ -110,11 +133,9 @@ class _HoistedUNet(nn.Module):
         if timesteps.dim() > 1 or (timesteps.dim() == 1 and timesteps.numel() not in (1, sample.shape[0])):
             raise ValueError(f"timesteps of shape {tuple(timesteps.shape)} do not match batch {sample.shape[0]}")
         x = sample.to(self.compute_dtype)
-        if self._new_prompt:
-            self._new_prompt = False
-            from .optimization import recalibrate_fp8
-            ctx = self._ctx[tuple(ehs.shape)]
-            recalibrate_fp8(self.compiled, lambda: self.compiled.forward_with_context(x, timesteps, ctx, cond))
+        if getattr(self.compiled, "fp8_plan", False):
+            self._fp8_restart(x, timesteps, tuple(ehs.shape), cond)
+        self._new_prompt = False
         with torch.no_grad():
             out = self._step_fn(tuple(ehs.shape))(x, timesteps, cond)
         return out.to(io_dtype)

@@ -264,3 +264,37 @@ def test_fp8_trajectories_do_not_depend_on_what_ran_before(gpu):
     assert gm.exec_context.fp8 is not None and gm.exec_context.fp8.sites, "the tiny model has no fp8 sites: the test checks nothing"
     assert torch.isfinite(first).all() and not torch.equal(first, other)
     assert torch.equal(first, again) and torch.equal(first, third)
+
+
+def test_fp8_trajectories_through_the_diffusers_hook(gpu):
+    """The same property through `hooks.DiffusersUNet` (round 5): the hook sees one call per step and no loop object -
+    it tells a trajectory start by a timestep that is larger than the last call's (or a new prompt) and restarts the delayed
+    scales there.  Identical trajectories under ONE prompt give identical results whatever ran in between."""
+    from stabletriton_amd import hooks, synth
+    from stabletriton_amd.optimization import optimize_model
+    from stabletriton_amd.scheduler import euler_discrete_tables
+    from stabletriton_amd.unet import TINY, UNet2DConditionModel
+    m = UNet2DConditionModel(TINY).eval().requires_grad_(False).to(gpu, torch.bfloat16)
+    synth.fill_module_(m, 0)
+    gm = optimize_model(m, cuda_graph=False, fp8=True)
+    unet = hooks.DiffusersUNet(gm, TINY, torch.bfloat16, cuda_graph=False)
+    x = synth.denoise_inputs(1, 16, 1234, cross_dim=TINY.cross_dim, pooled_dim=TINY.pooled_dim)
+    ehs = x["encoder_hidden_states"].to(gpu, torch.bfloat16)
+    added = {"text_embeds": x["text_embeds"].to(gpu, torch.bfloat16), "time_ids": x["time_ids"].to(gpu, torch.bfloat16)}
+    tb = euler_discrete_tables(6)
+    ts = torch.tensor(tb.timesteps, device=gpu)
+
+    def trajectory(noise):
+        lat = noise.to(gpu, torch.float32) * tb.init_noise_sigma
+        for i, t in enumerate(ts):                                   # 0-dim device tensors, as the pipeline passes them
+            eps = unet((lat * float(tb.in_scale()[i])).to(torch.bfloat16), t, encoder_hidden_states=ehs, added_cond_kwargs=added)[0]
+            lat = lat + eps.float() * float(tb.dsigma()[i])
+        return lat.cpu()
+
+    first = trajectory(x["latent"])
+    again = trajectory(x["latent"])                                  # the same prompt object: no new context, only the timestep jump tells
+    other = trajectory(x["latent"] * 3.0 + 1.0)
+    third = trajectory(x["latent"])
+    assert gm.exec_context.fp8 is not None and gm.exec_context.fp8.sites
+    assert torch.isfinite(first).all() and not torch.equal(first, other)
+    assert torch.equal(first, again) and torch.equal(first, third)

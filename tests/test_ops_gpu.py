@@ -95,7 +95,9 @@ def test_linear(gpu, dtype, M, K, N):
 @pytest.mark.parametrize("M,K,N,geglu", [(4096, 1280, 3840, False),      # 240 tiles of 256 x 256 (wave tiles 128 x 64: two column pairs)
                                          (1024, 1280, 10240, False),     # 256 tiles of 256 x 160 (wave tiles 64 x 80: pair, single tile, pair)
                                          (8192, 640, 640, False),        # 256 x 160 with a short K (ten K tiles)
-                                         (4096, 1280, 5120, True),       # GEGLU on 256 x 256: values and gates of 32 output columns per wave
+                                         (4096, 1280, 5120, True),       # GEGLU on 256 x 256: values and gates of 32 output columns per wave (640 tiles: two full rounds + a column-split remainder)
+                                         (2048, 1280, 5120, True),       # 320 tiles: one full round on 256 x 256, the last eight tile columns as a launch of their own
+                                         (4096, 1280, 10240, False),     # the same split without GEGLU (640 tiles of 256 x 256)
                                          (1024, 1280, 5120, True)])      # GEGLU on 256 x 160: the half tile whose gates come from lane + 32
 def test_linear_eight_phase_register_epilogue(gpu, dtype, M, K, N, geglu):
     """The large Linear problems run on the eight-phase kernel; round 5 stores their results straight from the accumulator
@@ -118,7 +120,12 @@ def test_linear_eight_phase_register_epilogue(gpu, dtype, M, K, N, geglu):
     for res in (None, rg):
         out, stats = ops.linear(xg, wg, bg, residual=res, emit_stats=True)
         plain = ops.linear(xg, wg, bg, residual=res)
-        assert torch.equal(out, plain), "emitting the row partials must not change the output"
+        # (the same bits where both calls run one launch of the same tiles; with row partials the column split of the 640-tile
+        #  shape is off and the two calls sum over K in different tile configurations: equal to rounding there)
+        if M * N == 4096 * 10240:
+            assert_close(out, plain.float().cpu(), dtype, "row partials vs plain")
+        else:
+            assert torch.equal(out, plain), "emitting the row partials must not change the output"
         o = out.double().cpu()
         s = stats.buf.double().sum(1).cpu()
         assert torch.allclose(s[:, 0], o.sum(1), rtol=1e-5, atol=1e-3)
@@ -190,7 +197,9 @@ def test_linear_geglu(gpu, dtype, M, K, F_):
 @pytest.mark.parametrize("M,K,N,geglu", [(1024, 1280, 3840, False), (100, 640, 640, False), (256, 640, 2560, True),
                                          (1024, 1280, 5120, True), (77, 128, 64, False), (4096, 640, 1920, False),
                                          # batch-4 shapes: the 256 x 256 eight-phase kernel (plain and GEGLU; the batch-1 GEGLU shape above takes 256 x 160)
-                                         (4096, 1280, 3840, False), (4096, 1280, 5120, True)])
+                                         (4096, 1280, 3840, False), (4096, 1280, 5120, True),
+                                         # batch 2: 320 tiles of 256 x 256 = one full round + a column-split remainder (round 5)
+                                         (2048, 1280, 5120, True)])
 def test_ln_linear(gpu, dtype, M, K, N, geglu):
     """LayerNorm folded into the consuming GEMM == LayerNorm followed by Linear (/GEGLU)."""
     x = rnd("lnl.x", (M, K)) * 1.7 + 0.4                  # rows with a non-zero mean
