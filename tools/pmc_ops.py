@@ -80,19 +80,21 @@ for name in shapes:
             names = {}
             for d in ds:
                 names[d["kernel"]] = names.get(d["kernel"], 0) + 1
-            top = max(names, key=names.get)
-            return [d for d in ds if d["kernel"] == top]
+            top = max(names.values())
+            # (round 5: a call may be TWO kernels - the column split of dispatch.h: full rounds on the eight-phase kernel + the remaining
+            #  columns on smaller tiles - so every kernel launched as often as the most-launched one belongs to the call)
+            return [d for d in ds if names[d["kernel"]] == top]
         return ds
     sq = only(read(os.path.join(src, name + "__sq", "*", "*counter_collection.csv")))
     if not sq:
         continue
     # one launch of an operator may be several kernels (GroupNorm: three): launches = dispatches / kernels per call
     kernels = sorted({d["kernel"] for d in sq})
-    calls = max(1, len(sq) // max(1, len(kernels))) if fam == "group_norm" else len(sq)
+    calls = max(1, len(sq) // max(1, len(kernels))) if fam in ("group_norm", "linear", "conv2d") else len(sq)
     # round 5: drop a cold first dispatch (code pages of a kernel never run in the process: one launch of 127 us among four of
     # 22.9 us doubled the "average" of a shape) - a single-kernel shape with >= 4 dispatches loses every dispatch that took
     # more than twice the median
-    if fam != "group_norm" and len(sq) >= 4:
+    if fam != "group_norm" and len(kernels) == 1 and len(sq) >= 4:
         med = sorted(d["ns"] for d in sq)[len(sq) // 2]
         kept = [d for d in sq if d["ns"] <= 2.0 * med]
         if len(kept) >= 3:
@@ -112,8 +114,9 @@ for name in shapes:
     write = only(read(os.path.join(src, name + "__write", "*", "*counter_collection.csv")))
     if fetch and write:
         # (per call of THEIR passes: the duration filter above may have dropped a cold dispatch from the SQ pass only)
-        fcalls = max(1, len(fetch) // max(1, len(kernels))) if fam == "group_norm" else len(fetch)
-        wcalls = max(1, len(write) // max(1, len(kernels))) if fam == "group_norm" else len(write)
+        multi = fam in ("group_norm", "linear", "conv2d")
+        fcalls = max(1, len(fetch) // max(1, len(kernels))) if multi else len(fetch)
+        wcalls = max(1, len(write) // max(1, len(kernels))) if multi else len(write)
         fs = sum(d.get("FETCH_SIZE", 0.0) for d in fetch) / fcalls
         wsz = sum(d.get("WRITE_SIZE", 0.0) for d in write) / wcalls
         rec["FETCH_SIZE"], rec["WRITE_SIZE"] = round(fs, 1), round(wsz, 1)
