@@ -100,6 +100,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     // region r of a K tile: 0 = A0, 1 = A1, 2 = B0, 3 = B1.  Always two DMAs per wave: pieces beyond the region's rows and
     // `kt >= nk` are dummies (a zero line into the dump area).
     auto issue_half = [&](int kt, int region) {
+#ifdef ST_PROBE8
+        if (p.korder & 2) kt = nk;                    // (developer probe: only dummy DMAs - one zero line each: the loop without its fill traffic)
+#endif
         const int roff = region == 0 ? 0 : region == 1 ? HA : region == 2 ? 2 * HA : 2 * HA + HB0;
         const int rrows = region < 2 ? RA : region == 2 ? RB0 : RB1;
         const unsigned dst = lds_addr_of(lds) + (kt & 1) * TILE_B + roff + (2 * wave) * 1024;
@@ -203,6 +206,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     };
     auto half_tile = [&](auto mh_) {                  // the MFMAs of one row half of the wave tile: TMH x TN accumulator tiles, all of the K tile
         constexpr int mh = decltype(mh_)::value;
+#ifdef ST_PROBE8
+        if (p.korder & 1) return;                     // (developer probe: the loop without its MFMAs - the load side's own pace)
+#endif
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk)

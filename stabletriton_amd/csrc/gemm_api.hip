@@ -47,6 +47,9 @@ static int linear_impl(const void* x, const void* W, const void* bias, const voi
     a.row_stats = row_stats; a.stats_capacity = row_stats_capacity; a.stats_chunks_out = row_stats_chunks;
     a.col_stats = col_stats; a.col_tiles_cap = col_stats_tiles; a.col_rows_out = col_stats_rows;
     take_hint(a, next_weights, next_weights_bytes);
+#ifdef ST_PROBE8
+    { const char* e_ = getenv("ST_PROBE_KNOB"); a.korder = e_ ? atoi(e_) : 0; }      // (developer probe build only: gemm8p.h)
+#endif
     if (int e = check_epilogue("linear", a)) return e;
     if (q8) {
         ST_REQUIRE(st_dtype_is16(dtype), "linear: the e4m3 copy is emitted by the 16-bit kernels");
