@@ -166,6 +166,40 @@ def test_next_weights_hints_do_not_change_results(gpu, dtype):
 
 
 @pytest.mark.parametrize("dtype", HALF_DTYPES)
+def test_next_weights_hints_other_kernel_families(gpu, dtype):
+    """The same property for the other launches that take a `next_weights` hint: an in-launch split-K GEMM (last arriver's epilogue),
+    a halo conv with a K split, a 1x1 conv on the implicit-GEMM loop, the query projection with the text-context attention in its
+    epilogue - hinted passes give the bits of the unhinted ones."""
+    x = rnd("nwo.x", (1024, 5120)).to(gpu, dtype)
+    w = (rnd("nwo.w", (1280, 5120)) * 5120 ** -0.5).to(gpu, dtype)
+    b, r = rnd("nwo.b", (1280,)).to(gpu, dtype), rnd("nwo.r", (1024, 1280)).to(gpu, dtype)
+    xc = rnd("nwo.xc", (1, 1280, 32, 32)).to(gpu, dtype).contiguous(memory_format=torch.channels_last)
+    wc = (rnd("nwo.wc", (1280, 1280, 3, 3)) * 11520 ** -0.5).to(gpu, dtype).contiguous(memory_format=torch.channels_last)
+    w1 = (rnd("nwo.w1", (640, 1280, 1, 1)) * 1280 ** -0.5).to(gpu, dtype).contiguous(memory_format=torch.channels_last)
+    bc = rnd("nwo.bc", (1280,)).to(gpu, dtype)
+    K = 1280
+    xq = rnd("nwo.xq", (1, 1024, K)) * 1.2 + 0.1
+    g, be = rnd("nwo.g", (K,)) * 0.2 + 1.0, rnd("nwo.be", (K,)) * 0.2
+    wq, bq = rnd("nwo.wq", (K, K)) * K ** -0.5, rnd("nwo.bq", (K,))
+    kk, vv = rnd("nwo.k", (1, 77, K)).to(gpu, dtype), rnd("nwo.v", (1, 77, K)).to(gpu, dtype)
+    xin, st = ops.linear(xq.to(gpu, dtype), torch.eye(K).to(gpu, dtype), None, emit_stats=True)
+    wf, c, d = ops.fold_layer_norm(g.to(gpu, dtype), be.to(gpu, dtype), wq.to(gpu, dtype), bq.to(gpu, dtype))
+
+    def step():
+        return (ops.linear(x, w, b, residual=r), ops.conv2d(xc, wc, bc, 1, 1), ops.conv2d(xc, w1, None, 1, 0),
+                ops.ln_linear_xattn(xin, st, wf, c, d, 1e-5, kk, vv, K // 64, 0.125))
+
+    plain = step()
+    ctx = ops.ExecContext()
+    for _ in range(3):
+        with ctx.step():
+            hinted = step()
+        for a, b_ in zip(plain, hinted):
+            assert torch.equal(a, b_)
+    assert ctx.plan.state == "replay" and len(ctx.plan.entries) == 4
+
+
+@pytest.mark.parametrize("dtype", HALF_DTYPES)
 def test_split_k_is_bit_reproducible(gpu, dtype):
     """The in-launch K split sums its slabs in slice order whichever block finishes last: repeated
     launches (and launches interleaved with other split GEMMs that share the workspace) agree bitwise."""
