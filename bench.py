@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--latent", type=int, default=128)
+    ap.add_argument("--latent-w", type=int, default=None, help="latent width when it differs from --latent (the height): an aspect bucket, "
+                    "e.g. --latent 152 --latent-w 104 = 1216 x 832 px; a side line, the headline workload is square")
     ap.add_argument("--mode", choices=["auto", "loop", "step", "eager"], default="auto")
     ap.add_argument("--dtype", choices=["bf16", "fp16", "fp32"], default="bf16",
                     help="compute / storage type of the timed run (same matrix-pipe rate; fp16 is the reference call site's own type)")
@@ -280,7 +282,7 @@ def extras(args, model, gm, loop, mode, dtype, dev, n_sched, cond, x):
     out = {}
 
     def make(g, dt, md):
-        lp = DenoiseLoop(g, args.batch, args.latent, dt, dev, euler_discrete_tables(n_sched), cross_dim=spec.cross_dim, pooled_dim=spec.pooled_dim,
+        lp = DenoiseLoop(g, args.batch, latent_hw(args), dt, dev, euler_discrete_tables(n_sched), cross_dim=spec.cross_dim, pooled_dim=spec.pooled_dim,
                          mode=md, n_time_ids=spec.n_time_ids)
         lp.set_conditioning(*(c.to(dt) for c in cond))
         lp.set_noise(x["latent"])
@@ -378,6 +380,10 @@ def host_cores():
     return max(1, use), f"{phys or '?'} physical / {logical} logical cores" + (f", cgroup quota {quota}" if quota else "")
 
 
+def latent_hw(args):
+    return args.latent if args.latent_w in (None, args.latent) else (args.latent, args.latent_w)
+
+
 def cpu_baseline(model, latent_hw, spec):
     """Oracle (CPU restatement of the reference eager path, fp32) on the host cores: 1 warm-up + 2 timed steps, median."""
     import torch
@@ -399,7 +405,7 @@ def cpu_baseline(model, latent_hw, spec):
         torch.set_num_threads(before)
     dt = sorted(times[1:])[len(times[1:]) // 2]
     return {"value": round(1.0 / dt, 5), "unit": "it/s", "cores": cores, "kind": "port",
-            "sample": f"UNet steps at latent {latent_hw}x{latent_hw}, bs=1, fp32 eager torch (oracle) on {cores} threads ({desc}): "
+            "sample": f"UNet steps at latent {'x'.join(str(v) for v in synth.latent_size(latent_hw))}, bs=1, fp32 eager torch (oracle) on {cores} threads ({desc}): "
                       f"1 warm-up ({times[0]:.1f} s) + 2 timed ({times[1]:.1f}, {times[2]:.1f} s), median {dt:.1f} s per step"}
 
 
@@ -478,9 +484,9 @@ def main():
         mode = "loop" if (args.steps % n_sched == 0 and args.warmup % n_sched == 0 and args.img2img is None) else "step"
     if args.img2img is not None and mode == "loop":
         raise SystemExit("--img2img starts mid-schedule: use --mode step (or auto)")
-    loop = DenoiseLoop(gm, args.batch, args.latent, dtype, dev, euler_discrete_tables(n_sched), cross_dim=spec.cross_dim,
+    loop = DenoiseLoop(gm, args.batch, latent_hw(args), dtype, dev, euler_discrete_tables(n_sched), cross_dim=spec.cross_dim,
                        pooled_dim=spec.pooled_dim, mode=mode, n_time_ids=spec.n_time_ids)
-    x = synth.denoise_inputs(args.batch, args.latent, 1234 + rank, device=dev, cross_dim=spec.cross_dim, pooled_dim=spec.pooled_dim,
+    x = synth.denoise_inputs(args.batch, latent_hw(args), 1234 + rank, device=dev, cross_dim=spec.cross_dim, pooled_dim=spec.pooled_dim,
                              n_time_ids=spec.n_time_ids)
     cond = (x["encoder_hidden_states"].to(dtype), x["text_embeds"].to(dtype), x["time_ids"].to(dtype))
     loop.set_conditioning(*cond)
@@ -517,13 +523,13 @@ def main():
 
         ms_per_step = elapsed / args.steps * 1e3
         result = {
-            "metric": "denoise it/s, SDXL UNet 1024x1024 50-step, bs=1 per GPU" if args.model == "base" and args.img2img is None else
-                      f"denoise it/s, SDXL-{args.model} UNet {args.latent * 8}x{args.latent * 8}" + (" img2img" if args.img2img is not None else "") + f", bs={args.batch} per GPU",
+            "metric": "denoise it/s, SDXL UNet 1024x1024 50-step, bs=1 per GPU" if args.model == "base" and args.img2img is None and latent_hw(args) == 128 else
+                      f"denoise it/s, SDXL-{args.model} UNet {args.latent * 8}x{(args.latent_w or args.latent) * 8}" + (" img2img" if args.img2img is not None else "") + f", bs={args.batch} per GPU",
             "value": round(world * args.batch * args.steps / elapsed, 3),
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp8" if args.fp8 else args.dtype, "data": "synthetic",
-            "config": {"workload": f"SDXL-{args.model} UNet, latent {args.latent}x{args.latent} ({args.latent * 8}x{args.latent * 8} px), bs={args.batch}/GPU, "
+            "config": {"workload": f"SDXL-{args.model} UNet, latent {args.latent}x{args.latent_w or args.latent} ({args.latent * 8}x{(args.latent_w or args.latent) * 8} px), bs={args.batch}/GPU, "
                                    + (f"{n_sched}-step Euler-discrete loop" if args.img2img is None else
                                       f"img2img strength {args.img2img} ({steps_per_image} of {n_sched} Euler-discrete steps per image)")
                                    + f", hipGraph mode={mode}, no CFG"
@@ -563,6 +569,8 @@ def main():
                     tag = "_strict"
                 elif args.model == "refiner" and args.fp8 and args.img2img is not None and args.batch == 1 and dtype == torch.bfloat16:
                     tag = "_refiner"
+                if args.latent != 128 or args.latent_w not in (None, 128):
+                    tag = None                      # (the profiles are of the 1024 x 1024 workload)
                 plain = tag is not None
                 tag = tag or ""
                 roofs = {k: roofline_of(k, v, boundary_ms, committed=bool(plain), tag=tag) for k, v in fam.items()}
@@ -581,7 +589,7 @@ def main():
                 except Exception as e:          # noqa: BLE001  (never lose the measured headline to a side measurement)
                     result["extras_error"] = {"extras": f"{type(e).__name__}: {e}"[:300]}
             if not args.no_cpu_baseline:
-                result["cpu_baseline"] = cpu_baseline(model, args.latent, spec)
+                result["cpu_baseline"] = cpu_baseline(model, latent_hw(args), spec)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

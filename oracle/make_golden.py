@@ -197,6 +197,24 @@ def f1_b4_128(ref):
 
 
 @torch.no_grad()
+def f1_rect(ref, h=96, w=64):
+    """A RECTANGULAR latent (768 x 512 px = 96 x 64: the reference's convolutions and its token-count-agnostic attention take any
+    size whose sides the two Downsample2D / Upsample2D pairs bring back, unet_pt.py:246-266): one eager step of the reference,
+    every 31st value of the (1, 4, 96, 64) output; the restatement is cross-checked on the full output."""
+    m = ref_unet(ref)
+    x = synth.denoise_inputs(1, (h, w), INPUT_SEED)
+    cond = {"text_embeds": x["text_embeds"], "time_ids": x["time_ids"]}
+    t = torch.tensor(500.0)
+    t0 = time.time()
+    out = m(x["latent"], t, x["encoder_hidden_states"], cond)[0]
+    sd = {k: v for k, v in m.state_dict().items()}
+    mine = orc.unet_forward(sd, x["latent"], t, x["encoder_hidden_states"], x["text_embeds"], x["time_ids"])
+    print(f"F1_rect {h}x{w}: {time.time() - t0:.0f}s  |oracle - reference| max = {float((mine - out).abs().max()):.2e}  |ref| max = {float(out.abs().max()):.3f}")
+    save(f"f1_unet_step_latent{h}x{w}", out=subsample(out), timestep=500.0, latent_h=h, latent_w=w, out_rms=float(out.pow(2).mean().sqrt()),
+         out_max_abs=float(out.abs().max()))
+
+
+@torch.no_grad()
 def f3_b2(ref, hw=64):
     """Two independent prompts in one batch through the 50-step Euler loop (the batched DenoiseLoop)."""
     m = ref_unet(ref)
@@ -316,6 +334,8 @@ if __name__ == "__main__":
             f3_b2(ref)
         elif what == "f1_b4_128":
             f1_b4_128(ref)
+        elif what == "f1_rect":
+            f1_rect(ref)
         elif what == "f3_cfg":
             f3_cfg(ref)
         elif what == "f2_large":

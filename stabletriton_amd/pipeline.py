@@ -21,7 +21,7 @@ from .scheduler import EulerTables, euler_discrete_tables
 
 
 class DenoiseLoop:
-    def __init__(self, unet: Callable, batch: int, latent_hw: int, dtype: torch.dtype, device,
+    def __init__(self, unet: Callable, batch: int, latent_hw, dtype: torch.dtype, device,
                  tables: Optional[EulerTables] = None, cross_dim: int = 2048, pooled_dim: int = 1280,
                  tokens: int = 77, mode: str = "loop", n_time_ids: int = 6):
         assert mode in ("loop", "step", "eager")
@@ -31,8 +31,11 @@ class DenoiseLoop:
         n = self.n_steps = self.tables.n_steps
         dev = self.device
         cl = torch.channels_last
-        self.latent = torch.zeros((batch, 4, latent_hw, latent_hw), dtype=torch.float32, device=dev).contiguous(memory_format=cl)
-        self.x_in = torch.zeros((batch, 4, latent_hw, latent_hw), dtype=dtype, device=dev).contiguous(memory_format=cl)
+        # `latent_hw`: one side of a square latent, or (height, width) - SDXL's aspect buckets (1216 x 832 px = 152 x 104);
+        # both sides multiples of 4: the UNet halves the latent twice (Downsample2D, unet_pt.py:246-256) and doubles it back
+        lh, lw = (int(latent_hw[0]), int(latent_hw[1])) if isinstance(latent_hw, (tuple, list)) else (int(latent_hw), int(latent_hw))
+        self.latent = torch.zeros((batch, 4, lh, lw), dtype=torch.float32, device=dev).contiguous(memory_format=cl)
+        self.x_in = torch.zeros((batch, 4, lh, lw), dtype=dtype, device=dev).contiguous(memory_format=cl)
         self.ehs = torch.zeros((batch, tokens, cross_dim), dtype=dtype, device=dev)
         self.text_embeds = torch.zeros((batch, pooled_dim), dtype=dtype, device=dev)
         self.time_ids = torch.zeros((batch, n_time_ids), dtype=dtype, device=dev)

@@ -95,16 +95,25 @@ def state_dict_for(shapes: Dict[str, Tuple[int, ...]], seed: int = 0, device="cp
     return {k: param_tensor(k, s, seed, device) for k, s in shapes.items()}
 
 
-def denoise_inputs(batch: int, latent_hw: int, seed: int = 1234, device="cpu",
+def latent_size(latent_hw) -> Tuple[int, int]:
+    """(height, width) of a latent given as one side (square) or as a pair (SDXL's aspect buckets: 152 x 104 ...)."""
+    if isinstance(latent_hw, (tuple, list)):
+        h, w = latent_hw
+        return int(h), int(w)
+    return int(latent_hw), int(latent_hw)
+
+
+def denoise_inputs(batch: int, latent_hw, seed: int = 1234, device="cpu",
                    cross_dim: int = 2048, pooled_dim: int = 1280, tokens: int = 77, n_time_ids: int = 6):
     """SURVEY.md 8(d) synthetic inputs: unit-normal latent (caller scales by
-    init sigma), text states, pooled text embedding and SDXL time ids."""
-    px = float(latent_hw * 8)
+    init sigma), text states, pooled text embedding and SDXL time ids.  `latent_hw`: one side, or (height, width)."""
+    lh, lw = latent_size(latent_hw)
+    ph, pw = float(lh * 8), float(lw * 8)
     return {
-        "latent": normal("latent", (batch, 4, latent_hw, latent_hw), seed, device),
+        "latent": normal("latent", (batch, 4, lh, lw), seed, device),
         "encoder_hidden_states": normal("ehs", (batch, tokens, cross_dim), seed, device),
         "text_embeds": normal("text_embeds", (batch, pooled_dim), seed, device),
         # base: (original h, w, crop top, left, target h, w); refiner (5 ids): (original h, w, crop top, left, aesthetic score)
-        "time_ids": torch.tensor([[px, px, 0.0, 0.0, px, px][:n_time_ids] if n_time_ids >= 6 else [px, px, 0.0, 0.0, 6.0][:n_time_ids]] * batch,
+        "time_ids": torch.tensor([[ph, pw, 0.0, 0.0, ph, pw][:n_time_ids] if n_time_ids >= 6 else [ph, pw, 0.0, 0.0, 6.0][:n_time_ids]] * batch,
                                  dtype=torch.float32, device=device),
     }

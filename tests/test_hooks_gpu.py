@@ -87,6 +87,31 @@ def test_diffusers_callsite_tiny(gpu, io_dtype, compute, tol):
         assert err <= (0.05 if compute == torch.bfloat16 else 0.0125) * float(ref.abs().max())
 
 
+def test_diffusers_callsite_changes_resolution(gpu):
+    """One compiled UNet, three images at different sizes - square, a rectangular aspect bucket, square again: the captured
+    graphs and the cached text context are keyed on the shapes, every image matches the oracle, and the first size replays
+    bit-identically after the detour."""
+    tables = euler_discrete_tables(6)
+    m = _tiny(torch.float32, gpu)
+    unet = hooks.compile_unet_from_state_dict(m.state_dict(), TINY, torch.float32, gpu)
+    pipe = StubPipeline(unet, torch.float32, gpu, tables, 5.0)
+    sd = {k: v.float().cpu() for k, v in m.state_dict().items()}
+    outs = {}
+    for hw in (16, (16, 24), (24, 8), 16):
+        x = synth.denoise_inputs(2, hw, 1234, cross_dim=TINY.cross_dim, pooled_dim=TINY.pooled_dim)
+        out = pipe(x["latent"][:1], x["encoder_hidden_states"], x["text_embeds"], x["time_ids"], state_dtype=torch.float32)
+        if hw in outs:
+            assert torch.equal(out, outs[hw])
+            continue
+        outs[hw] = out
+        ref = orc.euler_denoise_cfg(
+            lambda xi, t: orc.unet_forward(sd, xi, t, x["encoder_hidden_states"], x["text_embeds"], x["time_ids"]),
+            x["latent"][:1], tables, 5.0)
+        err = float((out - ref).abs().max())
+        print(f"tiny CFG call site at latent {hw}: max abs err {err:.2e}")
+        assert out.shape == ref.shape and err <= ABS_TOL_STRICT
+
+
 def test_diffusers_callsite_sdxl_fp32(gpu, sdxl_fp32):
     """SDXL-base, the reference protocol (CFG batch 2, 50 steps), strict mode: north_star bound on the final latent."""
     g = golden("f3_cfg50_latent64")

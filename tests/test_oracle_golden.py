@@ -115,6 +115,17 @@ def test_f1_unet_step_matches_reference(sdxl_state_dict):
 
 
 @pytest.mark.slow
+def test_f1_rectangular_latent_matches_reference(sdxl_state_dict):
+    """A 96 x 64 latent (768 x 512 px, `oracle/make_golden.py f1_rect`): oracle == reference on the kept values."""
+    g = golden("f1_unet_step_latent96x64")
+    x = synth.denoise_inputs(1, (int(g["latent_h"]), int(g["latent_w"])), 1234)
+    with torch.no_grad():
+        out = orc.unet_forward(sdxl_state_dict, x["latent"], torch.tensor(float(g["timestep"])), x["encoder_hidden_states"],
+                               x["text_embeds"], x["time_ids"])
+    assert torch.equal(out.flatten()[::31], torch.from_numpy(g["out"]))
+
+
+@pytest.mark.slow
 def test_f3_first_step_matches_reference_trace(sdxl_state_dict):
     """The stored 50-step trajectory starts with the same epsilon the oracle predicts
     (the full loop is replayed on the GPU by tests/test_unet_gpu.py)."""

@@ -50,7 +50,7 @@ def tiny_inputs(dtype, dev, batch=1, hw=16):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, ABS_TOL_STRICT), (torch.bfloat16, 0.1), (torch.float16, 0.025)])
-@pytest.mark.parametrize("batch,hw", [(1, 16), (2, 8), (1, 24)])
+@pytest.mark.parametrize("batch,hw", [(1, 16), (2, 8), (1, 24), (1, (16, 24)), (2, (24, 8)), (1, (12, 20)), (1, (8, 40))])      # (h, w): rectangular latents
 def test_tiny_unet_step(gpu, dtype, tol, batch, hw):
     m, gm = build(TINY, dtype, gpu, graph=False)
     sd = {k: v.float().cpu() for k, v in m.state_dict().items()}
@@ -423,6 +423,41 @@ def test_sdxl_f1_b4_latent128_against_the_reference(gpu, sdxl_fp32, sdxl_bf16):
     print(f"F1-b4 latent128 bf16: max abs err {err:.2e}, rms err {rms:.2e} (|ref| rms {float(g['out_rms']):.2f})")
     bound_max, bound_rms = storage_bound("f1_unet_step_latent64", "bf16")      # (one step: what bf16 storage alone costs, measured at latent 64)
     assert rms <= bound_rms * float(g["out_rms"]) / 0.45 and err <= 2.0 * bound_max
+
+
+def test_sdxl_f1_rectangular_latent_against_the_reference(gpu, sdxl_fp32, sdxl_bf16):
+    """A RECTANGULAR latent - 96 x 64 (768 x 512 px), the shape class of SDXL's aspect buckets - against the reference's own output
+    of that step (`oracle/make_golden.py f1_rect`, every 31st value kept): different row lengths at every level (64 / 32 / 16
+    pixels wide, 6,144 / 1,536 tokens) than any square case; then through DenoiseLoop as a captured graph (finite, replay-identical),
+    and a size the reference itself cannot run (a side not a multiple of 4) fails loudly."""
+    g = golden("f1_unet_step_latent96x64")
+    ref = torch.from_numpy(g["out"])
+    hw = (int(g["latent_h"]), int(g["latent_w"]))
+    x = synth.denoise_inputs(1, hw, 1234)
+
+    def step(gm, dtype):
+        cond = {"text_embeds": x["text_embeds"].to(gpu, dtype), "time_ids": x["time_ids"].to(gpu, dtype)}
+        with torch.no_grad():
+            return gm(x["latent"].to(gpu, dtype), torch.tensor(float(g["timestep"]), device=gpu), x["encoder_hidden_states"].to(gpu, dtype), cond)[0].float().cpu()
+
+    out = _sub(step(sdxl_fp32, torch.float32)).reshape(ref.shape)
+    err = float((out - ref).abs().max())
+    print(f"F1 96x64 fp32: max abs err {err:.2e} (|ref| max {float(g['out_max_abs']):.2f})")
+    assert err <= ABS_TOL_STRICT
+    out = _sub(step(sdxl_bf16, torch.bfloat16)).reshape(ref.shape)
+    err, rms = float((out - ref).abs().max()), float((out - ref).pow(2).mean().sqrt())
+    print(f"F1 96x64 bf16: max abs err {err:.2e}, rms err {rms:.2e} (|ref| rms {float(g['out_rms']):.2f})")
+    bound_max, bound_rms = storage_bound("f1_unet_step_latent64", "bf16")      # (one step: what bf16 storage alone costs, measured at latent 64)
+    assert rms <= bound_rms * float(g["out_rms"]) / 0.45 and err <= 2.0 * bound_max
+    loop = DenoiseLoop(sdxl_bf16, 1, hw, torch.bfloat16, gpu, euler_discrete_tables(4), mode="loop")
+    loop.set_conditioning(x["encoder_hidden_states"].to(gpu, torch.bfloat16), x["text_embeds"].to(gpu, torch.bfloat16), x["time_ids"].to(gpu, torch.bfloat16))
+    with torch.no_grad():
+        a, b = loop.denoise(x["latent"]).cpu(), loop.denoise(x["latent"]).cpu()
+    assert a.shape == (1, 4) + hw and torch.isfinite(a).all() and torch.equal(a, b)
+    bad = synth.denoise_inputs(1, (30, 64), 1234)
+    with pytest.raises(RuntimeError), torch.no_grad():
+        sdxl_fp32(bad["latent"].to(gpu), torch.tensor(500.0, device=gpu), bad["encoder_hidden_states"].to(gpu),
+                  {"text_embeds": bad["text_embeds"].to(gpu), "time_ids": bad["time_ids"].to(gpu)})
 
 
 @pytest.mark.parametrize("hw", [64, 128])

@@ -46,8 +46,12 @@ with ctx:
         ghz = ((st[:, 3] - st[:, 0]).float() / real_us / 1e3).median()
         span_us = float(st[:, 5].max() - st[:, 4].min()) / 100.0
         us = timeit(lambda: ops.linear(x, w, b, geglu=bool(geglu)), iters=20)
+        ent = (st[:, 4] - st[:, 4].min()).float() / 100.0                # when the blocks start / end, against the first entry (us)
+        ext = (st[:, 5] - st[:, 4].min()).float() / 100.0
+        q = lambda v, f: float(v.sort().values[min(int(f * (v.numel() - 1) + 0.5), v.numel() - 1)])
+        ramp = " ".join(f"{q(ent, f):.1f}" for f in (0.1, 0.5, 0.9, 1.0)) + " | exits " + " ".join(f"{q(ext, f):.1f}" for f in (0.0, 0.1, 0.5, 0.9, 1.0))
         nk = K // 64
         print(f"M={M} K={K} N={N} g={geglu}: {st.shape[0]} blocks | prologue med {pro.median():.0f} max {pro.max():.0f} | loop med {loop.median():.0f} "
               f"({loop.median() / nk:.0f} / K tile) max {loop.max():.0f} | epilogue med {epi.median():.0f} max {epi.max():.0f} | block life med {real_us.median():.1f} us at {ghz:.3f} GHz | "
-              f"first entry -> last exit {span} cyc = {span_us:.1f} us | {us:.1f} us per launch",
+              f"first entry -> last exit {span_us:.1f} us (entries at 10/50/90/100 %: {ramp}) | {us:.1f} us per launch",
               flush=True)
