@@ -250,6 +250,19 @@ static int gemm_dispatch(const GemmArgs& a_in, hipStream_t st, int depth = 0) {
             if (take256 && c256 < 1e29) { gemm8p_launch<T, 256, 2, 4>(a, st); return st_check_launch(who); }
             if (take160 && c160 < 1e29) { gemm8p_launch<T, 160, 4, 2>(a, st); return st_check_launch(who); }
         }
+        if constexpr (!CONV && is_split<T>()) {
+            // Strict mode on the eight-phase kernel (round 5): 256 x 160 tiles only - two accumulator sets allow wave tiles of at most
+            // 64 x 80.  A 32-k K tile is 120 MFMAs per SIMD (three per product) = 1,920 cycles against ~1,850 of fill and fragment
+            // reads: the two wave groups put the load side under the matrix work (2,400 cycles per K tile by stamps, 80 % matrix-pipe
+            // share), which the single-phase loop of gemm_dma_kernel adds to it.  Measured (tools/strict8p_ab.py): the GEGLU projections
+            // 86 against 105 us at batch 1, 294 against 364 at batch 4, 370 against 485 on the 640 level at batch 4; q|k|v at batch 4
+            // level, FF2 and the batch-1 q|k|v (96 tiles) stay on the smaller tiles - the model's choices below agree with every
+            // measured pair.  One round of 256 blocks per 256 tiles, no K split; the fp32 epilogue costs 11-27 thousand cycles.
+            const int f = forced_cfg();
+            double c160 = 1e30;
+            if (gemm8p_applies(a, 160, KB)) c160 = (double)((tiles(256, 160) + 255) / 256) * (nk * 1.15 + 5.0);
+            if (c160 < 1e29 && (f == CFG_256x160_8P || (f < 0 && c160 < 0.9 * best))) { gemm8p_launch<T, 160, 4, 2>(a, st); return st_check_launch(who); }
+        }
         GemmArgs b = a;
 #ifdef ST_DEV_CONFIGS
         {   // dev knob: override only the small-problem class (fewer than 150 tiles of 128x128)

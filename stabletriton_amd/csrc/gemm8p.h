@@ -1,4 +1,4 @@
-// GEMM-shaped operators: the eight-phase 256-row kernel (large Linear problems; 16-bit and e4m3 operands) and its launchers.
+// GEMM-shaped operators: the eight-phase 256-row kernel (large Linear problems; 16-bit, e4m3 and split fp32 operands) and its launchers.
 // Internal to csrc/.
 #pragma once
 #include "gemm_dma.h"
@@ -23,11 +23,13 @@
 // instance (DIRECT; epilogue.h, direct epilogue), else staged through LDS (GEGLU: tile columns [values | gates]).  LayerNorm
 // folding, statistics, next-weights touches and the XCD-aware tile order are the ones of gemm_dma_kernel.  No K split.
 // =============================================================================
+template <int BN, int WGM, int WGN> constexpr bool TILE_OK_SPLIT() { return (256 / WGM / 16) * (BN / WGN / 16) <= 20; }
 template <typename T, bool GEGLU, bool LNF, int BN = 256, int WGM = 2, int WGN = 4, bool DIRECT = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
-    static_assert(sizeof(T) <= 2, "16-bit elements (bf16 / f16) or e4m3 bytes");
+    static_assert(sizeof(T) <= 2 || is_split<T>(), "16-bit elements (bf16 / f16), e4m3 bytes, or split fp32 operands (strict mode: 256 x 160 tiles)");
+    static_assert(!is_split<T>() || (TILE_OK_SPLIT<BN, WGM, WGN>()), "split operands carry two accumulator sets: wave tiles of at most 64 x 80");
     constexpr int BM = 256, NW = 8;
-    constexpr int KB = 128 / (int)sizeof(T);           // elements per 128-byte row of a K tile: 64, or 128 e4m3
+    constexpr int KB = 128 / (int)sizeof(T);           // elements per 128-byte row of a K tile: 64, 128 e4m3, or 32 split fp32 (hi chunks 0-3, lo chunks 4-7)
     constexpr int EV = 16 / (int)sizeof(T);            // elements per 16-byte chunk
     typedef typename OutT<T>::type TO;                // element type of C, bias, residual (e4m3 operands: bf16)
     static_assert(WGM * WGN == NW && BM % (32 * WGM) == 0 && BN % (16 * WGN) == 0 && (!GEGLU || BN % 32 == 0), "wave layout");
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     constexpr int BNO = GEGLU ? BN / 2 : BN;
     typedef typename Mma<T>::Frag Frag;
     // what one ds_read_b128 delivers: a whole MFMA operand of 32 k (16-bit), or half of the 128-k operand of the e4m3 instruction
-    typedef typename std::conditional<sizeof(T) == 1, u32x4, Frag>::type Half;
+    typedef typename std::conditional<frag2<T>(), u32x4, Frag>::type Half;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const lnrows = lds + 2 * TILE_B;            // LayerNorm (mean, rstd) per row
     char* const dump = lnrows + BM * 8;               // target of the dummy DMAs
@@ -126,18 +128,18 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
             for (int o = t * 128; o < nbytes; o += 512 * 128) touch_at((const char*)base + byte_off + o);
         };
         if (p.epi & ST_EPI_BIAS) {
-            touch(p.bias, (long)n0 * 2, BNO * 2);
-            if (GEGLU) touch(p.bias, ((long)p.Ng + n0) * 2, BNO * 2);
+            touch(p.bias, (long)n0 * (long)sizeof(TO), BNO * (int)sizeof(TO));
+            if (GEGLU) touch(p.bias, ((long)p.Ng + n0) * (long)sizeof(TO), BNO * (int)sizeof(TO));
         }
         if (LNF) {
             touch(p.ln_c, (long)n0 * 4, BNO * 4); touch(p.ln_d, (long)n0 * 4, BNO * 4);
             if (GEGLU) { touch(p.ln_c, ((long)p.Ng + n0) * 4, BNO * 4); touch(p.ln_d, ((long)p.Ng + n0) * 4, BNO * 4); }
         }
         if (p.epi & ST_EPI_RESIDUAL) {
-            constexpr int lines = (BNO * 2 + 127) / 128;
+            constexpr int lines = (BNO * (int)sizeof(TO) + 127) / 128;
             for (int o = t; o < BM * lines; o += 512) {
                 const int r = o / lines, l = o - r * lines;
-                touch_at((const char*)p.residual + ((size_t)(m0 + r) * p.ldr + n0) * 2 + l * 128);
+                touch_at((const char*)p.residual + ((size_t)(m0 + r) * p.ldr + n0) * sizeof(TO) + l * 128);
             }
         }
     }
@@ -166,10 +168,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     if (wave >= 4) __builtin_amdgcn_s_barrier();     // the second half of the waves runs one barrier (half a phase) behind the first
 
     f32x4 acc[TM][TN];
+    f32x4 corr[is_split<T>() ? TM : 1][is_split<T>() ? TN : 1];      // split operands: the cross products, in units of 2^-11 (gemm_dma_kernel)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) {
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (is_split<T>()) corr[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 
     const int r16 = lane & 15, q = lane >> 4;
     // fragment addresses: region row = w * (tiles * 16) + frag * 16 + r16, chunk 4*kk + q, swizzled by row & 7 = r16 & 7
@@ -182,11 +188,12 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
         b1_off[kk] = 2 * HA + HB0 + (wn * TN1 * 16 + r16) * 128 + sw;
     }
     // A half in use and the wave's whole B.  16-bit: [..][kk] = the operand of k step kk; e4m3: [..][0] is the whole
-    // 128-k operand, assembled from the two 16-byte reads (chunks q and q + 4) where they land
-    constexpr int NKK = sizeof(T) == 1 ? 1 : 2;
+    // 128-k operand, assembled from the two 16-byte reads (chunks q and q + 4) where they land; split fp32: the same two reads
+    // are the hi and the lo halves of one 32-k operand
+    constexpr int NKK = frag2<T>() ? 1 : 2;
     Frag fa[TMH][NKK], fb[TN][NKK];
     auto read_op = [&](const char* base, const int (&off)[2], Frag (&dst)[NKK]) {
-        if constexpr (sizeof(T) == 1) {
+        if constexpr (frag2<T>()) {
             const Half lo = *reinterpret_cast<const Half*>(base + off[0]), hi = *reinterpret_cast<const Half*>(base + off[1]);
             dst[0] = Frag{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
         } else {
@@ -215,7 +222,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < TMH; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) Mma<T>::run(acc[mh * TMH + i][j], fb[j][kk], fa[i][kk]);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (is_split<T>()) Mma<T>::run2(acc[mh * TMH + i][j], corr[mh * TMH + i][j], fb[j][kk], fa[i][kk]);
+                    else Mma<T>::run(acc[mh * TMH + i][j], fb[j][kk], fa[i][kk]);
+                }
         __builtin_amdgcn_s_setprio(0);
     };
     // Round 5: a K tile is TWO phases per wave group, not four - (A0, B) then (A1, B): half as many barriers and counted waits
@@ -263,11 +273,19 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
 #ifdef ST_PROBE8
     pr_t2 = __builtin_readcyclecounter();
 #endif
+    if constexpr (is_split<T>()) {                    // one fused multiply-add per element: the same bits whatever follows (gemm_dma_kernel)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = __builtin_fmaf(corr[i][j][e], ST_SPLIT_INV, acc[i][j][e]);
+    }
     if constexpr (DIRECT)
         direct_epilogue<TO, TM, TN, WTM, WTN, WGM, WGN, GEGLU, LNF>(p, acc, m0, n0, tile_n, wm, wn, r16, q, lds, reinterpret_cast<const float2*>(lnrows),
                                                                     lds_addr_of(lds) + 2 * TILE_B + BM * 8);
     else
-        staged_epilogue<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, 2 * TILE_B, !LNF, sizeof(T) == 1>(p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds,
+        staged_epilogue<TO, BM, BN, WGM, WGN, TM, TN, GEGLU, 2 * TILE_B, !LNF, is_fp8<T>()>(p, acc, m0, n0, tile_n, wm, r16, q, ColsPlain{wn, WTN}, lds,
                                                                             reinterpret_cast<const float2*>(lnrows));
 #ifdef ST_PROBE8
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores acknowledged: the block's whole life

@@ -60,6 +60,28 @@ def test_linear_split_against_float64(gpu, M, K, N):
     assert e_split <= 8 * e_exact + 2e-7, (e_split, e_exact)
 
 
+@pytest.mark.parametrize("M,K,N,geglu,res", [(1024, 1280, 5120, True, False),      # the strict GEGLU projection at batch 1: 256 tiles of 256 x 160, one round
+                                             (2048, 1280, 5120, False, True),      # plain, bias + residual, 256 tiles
+                                             (4096, 640, 2560, True, False),       # the 640 level: 512 tiles = two rounds, ten K tiles
+                                             (512, 2560, 10240, False, False)])    # long K: 80 K tiles of 32
+def test_linear_split_eight_phase_against_float64(gpu, M, K, N, geglu, res):
+    """Round 5: split operands on the eight-phase kernel (256 x 160 tiles, 64 x 80 wave tiles, two accumulator sets; staged fp32
+    epilogue) where a launch is whole rounds of such tiles - same error class as the single-phase loop it replaces there, and the
+    same bits from launch to launch."""
+    rows = 2 * N if geglu else N
+    x, w, b = rnd("sp8.x", (M, K)), rnd("sp8.w", (rows, K)) * K ** -0.5, rnd("sp8.b", (rows,))
+    r = rnd("sp8.r", (M, N)) if res else None
+    ref = F.linear(x.double(), w.double(), b.double())
+    if geglu:
+        ref = ref[:, :N] * F.gelu(ref[:, N:])
+    if res:
+        ref = ref + r.double()
+    xg, wg, bg = x.to(gpu), w.to(gpu), b.to(gpu)
+    out = ops.linear(xg, wg, bg, geglu=geglu, residual=None if r is None else r.to(gpu))
+    assert torch.equal(out, ops.linear(xg, wg, bg, geglu=geglu, residual=None if r is None else r.to(gpu)))
+    assert _err(out, ref) <= 3e-6, _err(out, ref)
+
+
 def test_linear_split_is_deterministic_and_matches_operand_rounding(gpu):
     """The product of the split images equals, to accumulation order, the fp64 product of the values the images hold."""
     M, K, N = 256, 640, 320

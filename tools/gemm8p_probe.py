@@ -50,7 +50,7 @@ with ctx:
         ext = (st[:, 5] - st[:, 4].min()).float() / 100.0
         q = lambda v, f: float(v.sort().values[min(int(f * (v.numel() - 1) + 0.5), v.numel() - 1)])
         ramp = " ".join(f"{q(ent, f):.1f}" for f in (0.1, 0.5, 0.9, 1.0)) + " | exits " + " ".join(f"{q(ext, f):.1f}" for f in (0.0, 0.1, 0.5, 0.9, 1.0))
-        nk = K // 64
+        nk = K // (32 if os.environ.get("ST_BENCH_DTYPE") == "fp32" else 64)      # (split fp32 operands: K tiles of 32)
         print(f"M={M} K={K} N={N} g={geglu}: {st.shape[0]} blocks | prologue med {pro.median():.0f} max {pro.max():.0f} | loop med {loop.median():.0f} "
               f"({loop.median() / nk:.0f} / K tile) max {loop.max():.0f} | epilogue med {epi.median():.0f} max {epi.max():.0f} | block life med {real_us.median():.1f} us at {ghz:.3f} GHz | "
               f"first entry -> last exit {span_us:.1f} us (entries at 10/50/90/100 %: {ramp}) | {us:.1f} us per launch",
