@@ -111,6 +111,12 @@ static inline int forced_cfg() {
     return v;
 }
 
+#ifndef ST_SPLIT_DENSE_TRIP
+#define ST_SPLIT_DENSE_TRIP 1.0      // (developer A/B of the strict mode's tile choices: -DST_SPLIT_DENSE_TRIP=<factor> -DST_SPLIT_160_TRIP=<us>; profiles/r05_strict_model_ab.txt)
+#endif
+#ifndef ST_SPLIT_160_TRIP
+#define ST_SPLIT_160_TRIP 0.8
+#endif
 template <typename T, bool CONV>
 static int gemm_dispatch(const GemmArgs& a_in, hipStream_t st, int depth = 0) {
     GemmArgs a = a_in;
@@ -169,10 +175,11 @@ static int gemm_dispatch(const GemmArgs& a_in, hipStream_t st, int depth = 0) {
                 // (split operands: the 128 x 160 tile runs as 4 x 2 waves with ten accumulator tiles in each of two sets: measured
                 //  0.8 us per trip - it wins the GEGLU projection of the 1280 level by whole rounds, 512 tiles against 640, 104 -> 93 us,
                 //  and loses q|k|v to 128 x 128 at its fitted 16-bit constant)
-                // (round 5: the other split-operand trips cost ~1.8x the 16-bit constants - the same bytes, three MFMAs per product, K tiles of 32:
-                //  tools/gemm_sweep.py with ST_BENCH_DTYPE=fp32, profiles/r05_gemm_sweep_strict.txt: the 1024 x 1280 x 1280 projection ran a 64 x 128
-                //  tile at 26.7 us where 128 x 128 with three K slices takes 25.2; dense launches only: the convs keep their fitted factor)
-                const double trip = (is_split<T>() && c.cfg == CFG_128x160_W8 ? 0.8 : c.trip_us * (is_split<T>() && !CONV ? 1.8 : 1.0)) * (CONV ? 1.6 : 1.0);
+                // (round 5: an isolated sweep - tools/gemm_sweep.py with ST_BENCH_DTYPE=fp32 - suggested pricing the other split-operand trips at
+                //  1.8x their 16-bit constants, which moved the 1280-level projections, FF2 and q|k|v of the strict step onto the 128 x 160 tile;
+                //  IN the step that was 3.6 % slower at batch 1 (tools/ab_step.py --dtype fp32: 31.99 against 30.82 ms on one box; 1.4x: 31.58;
+                //  level at batch 2 and 4): the fitted 16-bit constants stand, as in round 4 - factor 1.0)
+                const double trip = (is_split<T>() && c.cfg == CFG_128x160_W8 ? ST_SPLIT_160_TRIP : c.trip_us * (is_split<T>() && !CONV ? ST_SPLIT_DENSE_TRIP : 1.0)) * (CONV ? 1.6 : 1.0);
                 for (int k_ : sks) {
                     if (k_ > 1 && (!can_split || nk / k_ < 4 || nt > 16384)) break;
                     const double slab_mb = (double)k_ * nt * c.bm * c.bn * 4.0 / 1e6;
