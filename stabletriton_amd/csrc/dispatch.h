@@ -111,6 +111,40 @@ static inline int forced_cfg() {
     return v;
 }
 
+// (developer A/B of the model's tile choices IN the step - tools/ab_step.py against a variant built with e.g. -DST_TW_128x64=1.2:
+//  the per-trip constant of that tile scaled for the 16-bit dense launches; all 1.0 in the product)
+#ifndef ST_TW_128x128
+#define ST_TW_128x128 1.0
+#endif
+#ifndef ST_TW_64x128
+#define ST_TW_64x128 1.0
+#endif
+#ifndef ST_TW_128x64
+#define ST_TW_128x64 1.0
+#endif
+#ifndef ST_TW_64x64
+#define ST_TW_64x64 1.0
+#endif
+#ifndef ST_TW_128x80
+#define ST_TW_128x80 1.0
+#endif
+#ifndef ST_TW_128x160
+#define ST_TW_128x160 1.0
+#endif
+#ifndef ST_TW_SPLITK
+#define ST_TW_SPLITK 1.0
+#endif
+static inline double model_tweak(int cfg) {
+    switch (cfg) {
+        case 9: return ST_TW_128x128;      // CFG_128x128_W8
+        case 10: return ST_TW_64x128;      // CFG_64x128_W8
+        case 8: return ST_TW_128x64;       // CFG_128x64_W8
+        case 7: return ST_TW_64x64;        // CFG_64x64_W8
+        case 27: return ST_TW_128x80;      // CFG_128x80_W8
+        case 28: return ST_TW_128x160;     // CFG_128x160_W8
+        default: return 1.0;
+    }
+}
 #ifndef ST_SPLIT_DENSE_TRIP
 #define ST_SPLIT_DENSE_TRIP 1.0      // (developer A/B of the strict mode's tile choices: -DST_SPLIT_DENSE_TRIP=<factor> -DST_SPLIT_160_TRIP=<us>; profiles/r05_strict_model_ab.txt)
 #endif
@@ -179,7 +213,7 @@ static int gemm_dispatch(const GemmArgs& a_in, hipStream_t st, int depth = 0) {
                 //  1.8x their 16-bit constants, which moved the 1280-level projections, FF2 and q|k|v of the strict step onto the 128 x 160 tile;
                 //  IN the step that was 3.6 % slower at batch 1 (tools/ab_step.py --dtype fp32: 31.99 against 30.82 ms on one box; 1.4x: 31.58;
                 //  level at batch 2 and 4): the fitted 16-bit constants stand, as in round 4 - factor 1.0)
-                const double trip = (is_split<T>() && c.cfg == CFG_128x160_W8 ? ST_SPLIT_160_TRIP : c.trip_us * (is_split<T>() && !CONV ? ST_SPLIT_DENSE_TRIP : 1.0)) * (CONV ? 1.6 : 1.0);
+                const double trip = (is_split<T>() && c.cfg == CFG_128x160_W8 ? ST_SPLIT_160_TRIP : c.trip_us * (is_split<T>() && !CONV ? ST_SPLIT_DENSE_TRIP : 1.0)) * (CONV ? 1.6 : 1.0) * ((!CONV && sizeof(T) == 2) ? model_tweak(c.cfg) : 1.0);
                 for (int k_ : sks) {
                     if (k_ > 1 && (!can_split || nk / k_ < 4 || nt > 16384)) break;
                     const double slab_mb = (double)k_ * nt * c.bm * c.bn * 4.0 / 1e6;
@@ -192,7 +226,7 @@ static int gemm_dispatch(const GemmArgs& a_in, hipStream_t st, int depth = 0) {
                     const double trip_bw = in_round * (c.bm + c.bn) * 128.0 / 14.0e6;
                     // (the per-trip constants were fitted on one-round launches; launches of several rounds run 25-45 % over them
                     //  - tools/gemm_sweep.py: 2048 x 10240 x 1280 on 256 x 128 tiles 73 us against 52 predicted - hence the factor)
-                    const double cost = rounds * (cdiv(nk, k_) * (trip > trip_bw ? trip : trip_bw) + 3.0) * (rounds > 1.0 ? 1.3 : 1.0) + (k_ > 1 ? 2.1 + 0.4 * slab_mb : 0.0);
+                    const double cost = rounds * (cdiv(nk, k_) * (trip > trip_bw ? trip : trip_bw) + 3.0) * (rounds > 1.0 ? 1.3 : 1.0) + (k_ > 1 ? (2.1 + 0.4 * slab_mb) * ((!CONV && sizeof(T) == 2) ? ST_TW_SPLITK : 1.0) : 0.0);
                     if (cost < best_) { best_ = cost; if (cfg_out) *cfg_out = c.cfg; if (sk_out) *sk_out = k_; }
                 }
             }
