@@ -134,6 +134,9 @@ static inline int forced_cfg() {
 #ifndef ST_TW_SPLITK
 #define ST_TW_SPLITK 1.0
 #endif
+#ifndef ST_TW_8P
+#define ST_TW_8P 1.1                 // the eight-phase kernel takes the launches it prices below this x the small tiles' best
+#endif
 static inline double model_tweak(int cfg) {
     switch (cfg) {
         case 9: return ST_TW_128x128;      // CFG_128x128_W8
@@ -286,8 +289,8 @@ static int gemm_dispatch(const GemmArgs& a_in, hipStream_t st, int depth = 0) {
                     }
                 }
             }
-            const bool take256 = f == CFG_256x256_8P || (f < 0 && c256 <= c160 && c256 < 1.1 * best);
-            const bool take160 = f == CFG_256x160_8P || (f < 0 && c160 < c256 && c160 < 1.1 * best);
+            const bool take256 = f == CFG_256x256_8P || (f < 0 && c256 <= c160 && c256 < ST_TW_8P * best);
+            const bool take160 = f == CFG_256x160_8P || (f < 0 && c160 < c256 && c160 < ST_TW_8P * best);
             if (take256 && c256 < 1e29) { gemm8p_launch<T, 256, 2, 4>(a, st); return st_check_launch(who); }
             if (take160 && c160 < 1e29) { gemm8p_launch<T, 160, 4, 2>(a, st); return st_check_launch(who); }
         }
