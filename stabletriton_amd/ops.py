@@ -246,13 +246,28 @@ def current_context(device: Optional[torch.device] = None) -> ExecContext:
     return ctx
 
 
-def _next_weights(w: torch.Tensor):
-    """(pointer, bytes) of the weights the launch after this one reads, from the current context's plan."""
+# What a touch is worth (round 5; whole-step A/Bs on one box, tools/ab_step.py with product:nohints / product:hintcap<n>,
+# profiles/r05_hints_ab.txt): the touching launch waits for its touches before it exits - bytes at HBM speed, 26 MB of a GEGLU
+# projection's weights = 6-7 us of its tail - and saves the next launch a cold start of 1-2 us: hints pay for SMALL weight matrices
+# only.  bs=1 bf16: no hints +2.4 %, every matrix hinted (rounds 3-4) 0, up to 4 / 10 / 12 / 14 / 20 MB -1.0 / -1.4 / -1.3 / -0.8 / -0.9 %;
+# bs=2: up to 4 MB -0.8 %, 12 MB -0.55 %, none +0.4 %; bs=4: up to 2 / 4 / 8 MB -2.6 / -2.8 / -2.1 %, none -2.4 %, 12 MB -1.8 %.
+# The rule: up to 10 MB from launches of at most 1,024 rows (the 1280 level at batch 1), up to 4 MB from larger ones.
+HINT_SMALL_ROWS = 1024
+HINT_MAX_BYTES_SMALL_ROWS = 10 << 20
+HINT_MAX_BYTES = 4 << 20
+
+
+def _next_weights(w: torch.Tensor, rows: int = 0):
+    """(pointer, bytes) of the weights the launch after this one reads, from the current context's plan - or (None, 0) where a
+    touch would cost this launch (`rows` rows of output) more than it saves the next one (the rule above)."""
     ctx = current_context(w.device)
     nxt = ctx.plan.next_after(w) if (ctx.plan is not None and ctx.hinting) else None
     if nxt is None:
         return None, 0
-    return nxt.data_ptr(), nxt.numel() * nxt.element_size()
+    nbytes = nxt.numel() * nxt.element_size()
+    if nbytes > (HINT_MAX_BYTES_SMALL_ROWS if 0 < rows <= HINT_SMALL_ROWS else HINT_MAX_BYTES):
+        return None, 0
+    return nxt.data_ptr(), nbytes
 
 
 def _gemm_workspace(device: torch.device) -> torch.Tensor:
@@ -624,7 +639,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         cap = min(STATS_MAX_CHUNKS, (N + 63) // 64)
         stats = torch.empty((M, cap, 2), dtype=torch.float32, device=x.device)
         chunks = ctypes.c_int(0)
-    nxt_p, nxt_b = _next_weights(w)
+    nxt_p, nxt_b = _next_weights(w, M)
     cbuf = ctiles = crows = None
     rows_per_image = 0
     if emit_colstats:
@@ -693,7 +708,7 @@ def ln_linear(x: torch.Tensor, stats: "RowStats", w_folded: torch.Tensor, c: tor
         # (c must be the row sums of the values the split image holds: the fold subtracts mean * c from their products)
         w_folded, c = _split_weight(w_folded, want_rowsum=True)
         x2, lda, code = _split_of(x2, M, K, lda), K, _C.ST_F32S
-    nxt_p, nxt_b = _next_weights(w_folded)
+    nxt_p, nxt_b = _next_weights(w_folded, M)
     # strict mode: the GEGLU projection's output (read by ff.net.2) and, on request, the q|k|v projection's (its K and V columns
     # are attention operands) leave their split images
     with _Armed(_arm_split(out, M, N) if (code == _C.ST_F32S and (geglu or emit_split)) else None) as img:
@@ -737,7 +752,7 @@ def ln_linear_xattn(x: torch.Tensor, stats: "RowStats", w_folded: torch.Tensor, 
         raise BackendError("ln_linear_xattn: layout not supported (bf16 / fp16, context < 256 tokens, 128 | rows per batch, dense batches)")
     x2, M, lda = _rows2d(x)
     out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
-    nxt_p, nxt_b = _next_weights(w_folded)
+    nxt_p, nxt_b = _next_weights(w_folded, M)
     S = k.shape[1]
     _C.check(lib.st_ln_linear_xattn(x2.data_ptr(), stats.buf.data_ptr(), stats.chunks, w_folded.data_ptr(),
                     c.data_ptr(), d.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), M, N, K, lda, N, float(eps),
@@ -827,7 +842,7 @@ def linear_fp8(x: "Fp8Rows", wq: torch.Tensor, w_scale: torch.Tensor, bias: Opti
         residual, _, ldr = _rows2d(residual)
         epi |= _C.EPI_RESIDUAL
     gws = _gemm_workspace(wq.device)
-    nxt_p, nxt_b = _next_weights(wq)
+    nxt_p, nxt_b = _next_weights(wq, x.q.shape[0])
     _C.check(lib.st_linear_fp8(x.q.data_ptr(), x.scale.data_ptr(), wq.data_ptr(), w_scale.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
                     M, N, K, K, N, ldr, epi, gws.data_ptr(), gws.numel(), nxt_p, nxt_b, _C.stream_ptr()), "linear_fp8")
     return out
@@ -880,7 +895,7 @@ def linear_fp8x(x: "Fp8Act", wq: torch.Tensor, w_scale: torch.Tensor, bias: Opti
         q8 = torch.empty((M, N), dtype=torch.uint8, device=dev)
         act8 = Fp8Act(q8, idx_out, tuple(x.shape[:-1]) + (N,))
     gws = _gemm_workspace(dev)
-    nxt_p, nxt_b = _next_weights(wq)
+    nxt_p, nxt_b = _next_weights(wq, M)
     _C.check(lib.st_linear_fp8x(x.q.data_ptr(), sc.scale[x.index:].data_ptr(), 0, wq.data_ptr(), w_scale.data_ptr(), _ptr(bias), _ptr(residual),
                                 _ptr(out), M, N, K, K, N, ldr, epi,
                                 None if st_in is None else st_in.buf.data_ptr(), 0 if st_in is None else st_in.chunks, _ptr(c), _ptr(d), float(eps),
@@ -992,7 +1007,7 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
         # strict mode: the pixels' channel vectors and the filter taps as split images (32 channels per segment)
         x = _split_of(x, N * H * W, Cin, Cin)
         w, code = _split_weight(weight, _conv_weight_rows)[0], _C.ST_F32S
-    nxt_p, nxt_b = _next_weights(w)
+    nxt_p, nxt_b = _next_weights(w, N * H * W)
     cbuf = ctiles = crows = None
     if emit_colstats:
         import ctypes
@@ -1044,7 +1059,7 @@ def conv2d_cat(x0: torch.Tensor, x1: torch.Tensor, weight: torch.Tensor, bias: O
         x0 = _split_of(x0, N * H * W, C0, C0)
         x1 = _split_of(x1, N * H * W, C1, C1)
         w, code = _split_weight(weight, _conv_weight_rows)[0], _C.ST_F32S
-    nxt_p, nxt_b = _next_weights(w)
+    nxt_p, nxt_b = _next_weights(w, N * H * W)
     cbuf = ctiles = crows = None
     if emit_colstats:
         import ctypes

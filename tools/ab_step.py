@@ -1,7 +1,8 @@
 """Developer A/B of whole denoise steps on ONE box: the product library against tools/_variants/<name> builds (same ABI),
 alternating processes so that device-to-device and thermal drift cancel.
 usage: python tools/ab_step.py [--batch B] [--dtype bf16|fp16] [--rounds R] variantA variantB ...     ('product' = the in-tree build;
-       'product:<pass>' = the same with the graph pass stabletriton_amd.optimization.<pass> switched off)"""
+       'product:<pass>' = the same with the graph pass stabletriton_amd.optimization.<pass> switched off;
+       'product:nohints' / 'product:allhints' / 'product:hintcap<n>' = next-weights hints off / for every matrix / only for weight matrices of at most n MB)"""
 import argparse, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,7 +13,12 @@ def one(variant, batch, dtype_name, latent):
     from tools.devlib import use_variant
     variant, _, without = variant.partition(":")          # "product:fuse_skip_cat" = the build with that graph pass switched off
     use_variant(None if variant == "product" else variant)
-    if without:
+    if without == "nohints" or without == "allhints" or without.startswith("hintcap"):
+        # next-weights hints off / for every matrix (rounds 3-4) / only for weight matrices up to <n> MB ("product:hintcap8") instead of the rule of ops._next_weights
+        from stabletriton_amd import ops as ops_mod
+        cap = 0 if without == "nohints" else (1 << 40) if without == "allhints" else int(without[7:]) << 20
+        ops_mod.HINT_MAX_BYTES = ops_mod.HINT_MAX_BYTES_SMALL_ROWS = cap
+    elif without:
         import stabletriton_amd.optimization as opt_mod
         assert hasattr(opt_mod, without), f"no pass {without}"
         setattr(opt_mod, without, lambda gm, *a, **k: 0)
