@@ -46,13 +46,14 @@ enum {
     ST_EPI_ROWBIAS   = 16   /* + rowbias[batch(m)][n]     (time-embedding add)    */
 };
 
-int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 15
+int         st_abi_version(void);          /* bumps on any signature or contract change; this header is ABI 16
                                               (6: next-weights hint passed per call, st_timestep_sincos; 7: fp8 entry points; 8: GroupNorm partials from the
                                               producer; 9: st_ln_linear_xattn; 10: ST_F16 accepted by every entry point
                                               that takes a dtype, st_ln_linear_xattn takes a dtype; 11: fp8 plan with
                                               delayed per-tensor scaling - st_linear_emit8, st_linear_fp8x, st_fp8_update_scales; 12: readers of a channel
                                               concatenation that is never written - st_group_norm_from_stats_cat, st_conv1x1_cat; 13: ST_F32S split fp32 matrix operands, st_split_f32, st_arm_split_output, st_attention_split; 14: st_attention
-                                              takes head_dim 16 / 32 / 128 beside 64; 15: st_timestep_features takes the host's table of the reference's own features for integer timesteps) */
+                                              takes head_dim 16 / 32 / 128 beside 64; 15: st_timestep_features takes the host's table of the reference's own features for integer timesteps;
+                                              16: next_weights_bytes carries the geometry of a strided touch in bits 40-61) */
 const char* st_last_error(void);           /* host string, thread-local     */
 
 /* GroupNorm (+SiLU).  Replaces reference group_norm_wrapper
@@ -122,7 +123,10 @@ int st_geglu(const void* state, const void* gate, void* out, int rows, int F,
  * GEMM-shaped launch AFTER this one will read.  This launch touches it (one dword per 128-byte line, spread
  * over its blocks, during its epilogue or from helper blocks on idle CUs) so that it waits in the memory-side
  * cache when its own GEMM starts; without it cold weights cost every GEMM an HBM round trip in its prologue.
- * The buffer must stay allocated until this launch has run (also under graph replay). */
+ * The launch waits for its touches before it exits - the matrix's bytes at HBM speed -, so a caller hints small matrices whole
+ * and large ones STRIDED: `next_weights_bytes` = byte count (bits 0-39) | row length in 128-byte lines << 40 (bits 40-59,
+ * 0 = every line) | s << 60 (bits 60-61): the first 2^s lines of every row are touched - the K tiles the next launch's
+ * prologue asks for.  The buffer must stay allocated until this launch has run (also under graph replay). */
 int st_linear(const void* x, const void* W, const void* bias, const void* residual,
               const void* rowbias, void* y, int M, int N, int K,
               long lda, long ldc, long ldr, int rows_per_batch,

@@ -16,7 +16,7 @@ from .build import lib_path
 ST_F32, ST_BF16, ST_F16, ST_F32S = 0, 1, 2, 3
 ST_NCHW, ST_NHWC = 0, 1
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_RESIDUAL, EPI_ROWBIAS = 1, 2, 4, 8, 16
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _p, _i, _l, _f, _z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 

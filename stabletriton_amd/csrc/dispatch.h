@@ -274,7 +274,7 @@ static int gemm_dispatch(const GemmArgs& a_in, hipStream_t st, int depth = 0) {
                         typedef typename OutT<T>::type TO_;
                         GemmArgs a1 = a, a2 = a;
                         a1.N = (int)n1;
-                        a1.next_w = (const char*)a.W + (size_t)n1 * a.K * sizeof(T); a1.next_bytes = (size_t)(a.N - n1) * a.K * sizeof(T);      // (the remainder's weights)
+                        a1.next_w = (const char*)a.W + (size_t)n1 * a.K * sizeof(T); a1.next_bytes = (size_t)(a.N - n1) * a.K * sizeof(T); a1.next_row_lines = 0; a1.next_lead_shift = 0;      // (the remainder's weights)
                         a2.N = a.N - (int)n1;
                         a2.W = (const char*)a.W + (size_t)n1 * a.K * sizeof(T);
                         a2.C = (char*)a.C + (size_t)n1 * sizeof(TO_);
@@ -389,7 +389,18 @@ static int gemm_dispatch(const GemmArgs& a_in, hipStream_t st, int depth = 0) {
 
 // `next_weights` (optional argument of the three GEMM-shaped entry points): the weight matrix the launch AFTER this one
 // will read; this launch touches it (one dword per 128-byte line, spread over its blocks) so it waits in the memory-side cache.
+// Bits 40-59 of the byte count non-zero: a STRIDED touch - that many 128-byte lines per row of the matrix, of which the first
+// 2^(bits 60-61) are touched (the K tiles the next launch's prologue asks for: a large matrix costs the touching launch its bytes at
+// HBM speed, the leading columns cost 1-4 % of that and save the same cold start).
 static inline void take_hint(GemmArgs& a, const void* next_w, size_t next_bytes) {
+    const size_t row_lines = (next_bytes >> 40) & 0xfffff, shift = (next_bytes >> 60) & 3;
+    next_bytes &= ((size_t)1 << 40) - 1;
+    a.next_row_lines = 0; a.next_lead_shift = 0;
+    if (next_w && row_lines && (row_lines >> shift) >= 2 && next_bytes >= (row_lines << 7)) {
+        const size_t rows = (next_bytes >> 7) / row_lines;
+        a.next_row_lines = (unsigned)row_lines; a.next_lead_shift = (unsigned)shift;
+        next_bytes = (rows << shift) << 7;                  // what is touched
+    }
     a.next_w = next_bytes ? next_w : nullptr;
     a.next_bytes = next_w ? next_bytes : 0;
 }

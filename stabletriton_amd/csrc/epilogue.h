@@ -735,7 +735,7 @@ __device__ __forceinline__ void touch_next_weights_dma(const GemmArgs& p, unsign
     const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < lines ? lo + per : lines;
     const size_t step = blockDim.x;
     for (size_t l = lo + threadIdx.x; l < hi; l += step)
-        __builtin_amdgcn_global_load_lds((epi_gbl_cvoid_t*)((const char*)p.next_w + (l << 7)), (epi_lds_void_t*)(uintptr_t)lds_dump_addr, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((epi_gbl_cvoid_t*)((const char*)p.next_w + (touch_line(p, l) << 7)), (epi_lds_void_t*)(uintptr_t)lds_dump_addr, 4, 0, 0);
 }
 
 struct DirectCol { int col; bool gate; };

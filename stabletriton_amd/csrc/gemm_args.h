@@ -47,6 +47,8 @@ struct GemmArgs {
     unsigned tm_mg_splitk, tm_mg_per_panel, tm_mg_rows, tm_mg_last;
     int nk_base, nk_rem;         // K stages per slice: slice s takes nk_base + (s < nk_rem), slices in order
     unsigned next_per;           // 128-byte lines of next_w per touching block (0: the kernel divides)
+    unsigned next_row_lines;     // strided touch (a large matrix: only the leading K columns of every row): the row length in 128-byte lines,
+    unsigned next_lead_shift;    //   2^next_lead_shift lines touched per row; next_bytes then counts the TOUCHED bytes (0: every line of next_bytes)
     // fp8 operands (st_linear_fp8): acc * row_scale[m] * col_scale[n] before anything else (col_scale has 2N entries with GEGLU)
     const float* row_scale; const float* col_scale;
     int rs_stride;               // stride of row_scale: 1 = a scale per row, 0 = one scale for the whole activation tensor
@@ -188,6 +190,11 @@ template <> struct Out4<float> {
 // The next launch's weights (the `next_weights` argument of the entry points) are touched one dword per 128-byte line, each block
 // its slice, so that they sit in the memory-side cache when that launch starts (cold weights cost a GEMM 2-10 us:
 // DESIGN.md section 6).  The loads are fire-and-forget: `sink` stays allocated until retire_touches(sink).
+// touched line l -> line of the matrix: l itself, or (strided touch) line l mod 2^s of row l >> s
+__device__ __forceinline__ size_t touch_line(const GemmArgs& p, size_t l) {
+    if (!p.next_row_lines) return l;
+    return (l >> p.next_lead_shift) * p.next_row_lines + (l & ((1u << p.next_lead_shift) - 1u));
+}
 __device__ __forceinline__ void touch_next_weights(const GemmArgs& p, unsigned int& sink, bool helper = false) {
     if (!p.next_w || (p.helper_blocks > 0) != helper) return;
     const size_t lines = p.next_bytes >> 7;
@@ -198,7 +205,7 @@ __device__ __forceinline__ void touch_next_weights(const GemmArgs& p, unsigned i
     const size_t lo = me * per, hi = lo + per < lines ? lo + per : lines;
     const size_t step = blockDim.x;                  // read once: inside the loop the asm's memory clobber would force a reload (and a vmcnt(0)) per trip
     for (size_t l = lo + threadIdx.x; l < hi; l += step) {
-        const char* a_ = (const char*)p.next_w + (l << 7);
+        const char* a_ = (const char*)p.next_w + (touch_line(p, l) << 7);
         asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(a_) : "memory");
     }
 }

@@ -43,7 +43,7 @@ int st_check_launch(const char* what) {
 }
 
 extern "C" const char* st_last_error(void) { return g_err; }
-extern "C" int st_abi_version(void) { return 15; }
+extern "C" int st_abi_version(void) { return 16; }
 
 // ---- Euler-discrete update ---------------------------------------------------
 template <typename T>

@@ -252,9 +252,12 @@ def current_context(device: Optional[torch.device] = None) -> ExecContext:
 # only.  bs=1 bf16: no hints +2.4 %, every matrix hinted (rounds 3-4) 0, up to 4 / 10 / 12 / 14 / 20 MB -1.0 / -1.4 / -1.3 / -0.8 / -0.9 %;
 # bs=2: up to 4 MB -0.8 %, 12 MB -0.55 %, none +0.4 %; bs=4: up to 2 / 4 / 8 MB -2.6 / -2.8 / -2.1 %, none -2.4 %, 12 MB -1.8 %.
 # The rule: up to 10 MB from launches of at most 1,024 rows (the 1280 level at batch 1), up to 4 MB from larger ones.
+# Larger matrices get a STRIDED touch: the first 2^HINT_LEAD_SHIFT 128-byte lines of every row - the K tiles the next launch's
+# prologue asks for - through bits 40-61 of the byte count (include/stabletriton_amd.h, `next_weights_bytes`); None: no touch.
 HINT_SMALL_ROWS = 1024
 HINT_MAX_BYTES_SMALL_ROWS = 10 << 20
 HINT_MAX_BYTES = 4 << 20
+HINT_LEAD_SHIFT = 1
 
 
 def _next_weights(w: torch.Tensor, rows: int = 0):
@@ -266,7 +269,10 @@ def _next_weights(w: torch.Tensor, rows: int = 0):
         return None, 0
     nbytes = nxt.numel() * nxt.element_size()
     if nbytes > (HINT_MAX_BYTES_SMALL_ROWS if 0 < rows <= HINT_SMALL_ROWS else HINT_MAX_BYTES):
-        return None, 0
+        row_bytes = nbytes // nxt.shape[0] if nxt.dim() >= 2 else 0
+        if HINT_LEAD_SHIFT is None or row_bytes % 128 or (row_bytes >> 7) < (2 << HINT_LEAD_SHIFT) or nbytes >= (1 << 40):
+            return None, 0
+        return nxt.data_ptr(), nbytes | ((row_bytes >> 7) << 40) | (HINT_LEAD_SHIFT << 60)
     return nxt.data_ptr(), nbytes
 
 

@@ -18,6 +18,9 @@ def one(variant, batch, dtype_name, latent):
         from stabletriton_amd import ops as ops_mod
         cap = 0 if without == "nohints" else (1 << 40) if without == "allhints" else int(without[7:]) << 20
         ops_mod.HINT_MAX_BYTES = ops_mod.HINT_MAX_BYTES_SMALL_ROWS = cap
+    elif without == "nolead" or (without.startswith("lead") and without[4:].isdigit()):      # strided touches of the large matrices off / 2^n lines per row
+        from stabletriton_amd import ops as ops_mod
+        ops_mod.HINT_LEAD_SHIFT = None if without == "nolead" else int(without[4:])
     elif without:
         import stabletriton_amd.optimization as opt_mod
         assert hasattr(opt_mod, without), f"no pass {without}"
