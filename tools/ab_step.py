@@ -2,6 +2,7 @@
 alternating processes so that device-to-device and thermal drift cancel.
 usage: python tools/ab_step.py [--batch B] [--dtype bf16|fp16] [--rounds R] variantA variantB ...     ('product' = the in-tree build;
        'product:<pass>' = the same with the graph pass stabletriton_amd.optimization.<pass> switched off;
+       '<variant>+KNOB=value' = a -DST_DEV_CONFIGS variant with that developer knob set;
        'product:nohints' / 'product:allhints' / 'product:hintcap<n>' = next-weights hints off / for every matrix / only for weight matrices of at most n MB)"""
 import argparse, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -69,8 +70,10 @@ if __name__ == "__main__":
     res = {v: [] for v in a.variants}
     for r in range(a.rounds):
         for v in a.variants:
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", v, "--batch", str(a.batch), "--dtype", a.dtype, "--latent", str(a.latent)],
-                                 capture_output=True, text=True)
+            name, *sets = v.split("+")                   # "dev+ST_ATT_NW=4": the variant with that developer knob in the child's environment
+            env = dict(os.environ, **dict(kv.split("=", 1) for kv in sets))
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", name, "--batch", str(a.batch), "--dtype", a.dtype, "--latent", str(a.latent)],
+                                 capture_output=True, text=True, env=env)
             line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
             if not line:
                 print(v, "FAILED", out.stderr[-800:])
