@@ -257,6 +257,7 @@ def current_context(device: Optional[torch.device] = None) -> ExecContext:
 HINT_SMALL_ROWS = 1024
 HINT_MAX_BYTES_SMALL_ROWS = 10 << 20
 HINT_MAX_BYTES = 4 << 20
+HINT_MAX_BYTES_FP8 = 8 << 20
 HINT_LEAD_SHIFT = 1
 
 
@@ -268,7 +269,10 @@ def _next_weights(w: torch.Tensor, rows: int = 0):
     if nxt is None:
         return None, 0
     nbytes = nxt.numel() * nxt.element_size()
-    if nbytes > (HINT_MAX_BYTES_SMALL_ROWS if 0 < rows <= HINT_SMALL_ROWS else HINT_MAX_BYTES):
+    # (e4m3 matrices: the fp8 launches are shorter and a cold start weighs more - up to 8 MB from the larger launches:
+    #  fp8 mode at bs=2 18.60 ms against 18.96 with 4 MB and 18.67 with every matrix hinted, bs=4 30.72 / 30.82 / 30.64)
+    big = HINT_MAX_BYTES_FP8 if nxt.element_size() == 1 else HINT_MAX_BYTES
+    if nbytes > (HINT_MAX_BYTES_SMALL_ROWS if 0 < rows <= HINT_SMALL_ROWS else big):
         row_bytes = nbytes // nxt.shape[0] if nxt.dim() >= 2 else 0
         if HINT_LEAD_SHIFT is None or row_bytes % 128 or (row_bytes >> 7) < (2 << HINT_LEAD_SHIFT) or nbytes >= (1 << 40):
             return None, 0

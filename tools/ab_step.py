@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def one(variant, batch, dtype_name, latent):
+def one(variant, batch, dtype_name, latent, fp8=False):
     import torch
     from tools.devlib import use_variant
     variant, _, without = variant.partition(":")          # "product:fuse_skip_cat" = the build with that graph pass switched off
@@ -18,7 +18,7 @@ def one(variant, batch, dtype_name, latent):
         # next-weights hints off / for every matrix (rounds 3-4) / only for weight matrices up to <n> MB ("product:hintcap8") instead of the rule of ops._next_weights
         from stabletriton_amd import ops as ops_mod
         cap = 0 if without == "nohints" else (1 << 40) if without == "allhints" else int(without[7:]) << 20
-        ops_mod.HINT_MAX_BYTES = ops_mod.HINT_MAX_BYTES_SMALL_ROWS = cap
+        ops_mod.HINT_MAX_BYTES = ops_mod.HINT_MAX_BYTES_SMALL_ROWS = ops_mod.HINT_MAX_BYTES_FP8 = cap
     elif without == "nolead" or (without.startswith("lead") and without[4:].isdigit()):      # strided touches of the large matrices off / 2^n lines per row
         from stabletriton_amd import ops as ops_mod
         ops_mod.HINT_LEAD_SHIFT = None if without == "nolead" else int(without[4:])
@@ -37,7 +37,7 @@ def one(variant, batch, dtype_name, latent):
         m = UNet2DConditionModel(SDXL_BASE)
     m = m.to_empty(device=dev).to(dtype).eval().requires_grad_(False)
     synth.fill_module_(m, 0)
-    gm = optimize_model(m, cuda_graph=False)
+    gm = optimize_model(m, cuda_graph=False, fp8=fp8)
     loop = DenoiseLoop(gm, batch, latent, dtype, dev, euler_discrete_tables(50), mode="step")
     x = synth.denoise_inputs(batch, latent, 1234, device=dev)
     loop.set_conditioning(x["encoder_hidden_states"].to(dtype), x["text_embeds"].to(dtype), x["time_ids"].to(dtype))
@@ -62,17 +62,18 @@ if __name__ == "__main__":
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--latent", type=int, default=128)
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--fp8", action="store_true", help="the projections of the fp8 plan on e4m3 operands (bf16 modules)")
     ap.add_argument("variants", nargs="*")
     a = ap.parse_args()
     if a.one:
-        one(a.one, a.batch, a.dtype, a.latent)
+        one(a.one, a.batch, a.dtype, a.latent, a.fp8)
         sys.exit(0)
     res = {v: [] for v in a.variants}
     for r in range(a.rounds):
         for v in a.variants:
             name, *sets = v.split("+")                   # "dev+ST_ATT_NW=4": the variant with that developer knob in the child's environment
             env = dict(os.environ, **dict(kv.split("=", 1) for kv in sets))
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", name, "--batch", str(a.batch), "--dtype", a.dtype, "--latent", str(a.latent)],
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", name, "--batch", str(a.batch), "--dtype", a.dtype, "--latent", str(a.latent)] + (["--fp8"] if a.fp8 else []),
                                  capture_output=True, text=True, env=env)
             line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
             if not line:
