@@ -53,6 +53,34 @@ def test_step_scope_hints_only_inside_steps_and_contexts_nest_per_thread():
     assert ops.current_context(cpu) is ops.current_context(cpu)
 
 
+def test_hint_size_rule_and_strided_encoding():
+    """Which matrices a launch is asked to touch (ops._next_weights): whole up to 10 MB from launches of at most 1,024 rows, up to
+    4 MB from larger ones (8 MB for e4m3), the others strided - byte count | row length in 128-byte lines << 40 | log2(lines per
+    row) << 60 (include/stabletriton_amd.h, next_weights_bytes) - and nothing where a row is not a whole number of lines."""
+    small = torch.empty((1280, 1280), dtype=torch.bfloat16)           # 3.3 MB
+    mid = torch.empty((3840, 1280), dtype=torch.bfloat16)             # 9.8 MB
+    big = torch.empty((10240, 1280), dtype=torch.bfloat16)            # 26 MB: rows of 20 lines
+    q8 = torch.empty((5120, 1280), dtype=torch.uint8)                 # 6.5 MB of e4m3
+    odd = torch.empty((40000, 100), dtype=torch.bfloat16)             # 8 MB, 200-byte rows
+    order = [small, mid, big, q8, odd]
+    ctx = ops.ExecContext()
+
+    def hints(rows):
+        for _ in range(2):
+            with ctx.step():
+                got = [ops._next_weights(t, rows) for t in order]
+        return got                                                    # got[i] = the hint of the matrix AFTER order[i]
+    nb = lambda t: t.numel() * t.element_size()
+    strided = lambda t: nb(t) | ((nb(t) // t.shape[0] // 128) << 40) | (ops.HINT_LEAD_SHIFT << 60)
+    g = hints(1024)
+    assert g[4] == (small.data_ptr(), nb(small)) and g[0] == (mid.data_ptr(), nb(mid)) and g[1] == (big.data_ptr(), strided(big))
+    assert g[2] == (q8.data_ptr(), nb(q8)) and g[3] == (odd.data_ptr(), nb(odd))          # (8 MB: whole from a small launch)
+    g = hints(4096)
+    assert g[4] == (small.data_ptr(), nb(small)) and g[0] == (mid.data_ptr(), strided(mid)) and g[1] == (big.data_ptr(), strided(big))
+    assert g[2] == (q8.data_ptr(), nb(q8)) and g[3] == (None, 0)
+    assert (strided(big) >> 40) & 0xfffff == 20 and strided(big) >> 60 == ops.HINT_LEAD_SHIFT and strided(big) & ((1 << 40) - 1) == nb(big)
+
+
 def test_derived_weights_refresh_in_place():
     lin = [torch.nn.Linear(8, 4, bias=False), torch.nn.Linear(8, 6, bias=False)]
     ctx = ops.ExecContext()
