@@ -19,6 +19,8 @@ python bench.py --steps 50 --warmup 10 --mode step --no-cpu-baseline --no-extras
 python bench.py --model refiner --img2img 0.3 --steps 30 --warmup 15 --no-cpu-baseline --no-extras > $o/bench_refiner_img2img.json 2>/dev/null
 python bench.py --model refiner --img2img 0.3 --steps 30 --warmup 15 --no-cpu-baseline --no-extras --fp8 > $o/bench_refiner_img2img_fp8.json 2>/dev/null
 python bench.py --gpus 2 --same-device --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $o/bench_2rank_gloo_same_device.json 2> $o/bench_2rank.err
+# the driver's own launcher for N > 1 (torch.distributed.run, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from its env; fresh children, nothing here has touched the GPU)
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 5 --same-device > $o/bench_2rank_torchrun_same_device.json 2> $o/bench_2rank_torchrun.err
 for f in $o/bench_*.json; do python - "$f" <<'PY'
 import json,sys
 try:
